@@ -1,0 +1,180 @@
+"""Thin Python host wrapper over the C ABI (include/pbr_hip.h).
+
+PyTorch is used only as plumbing: device allocations (torch tensors), the current HIP stream
+and torch.distributed.  Every method below is one C-ABI call on device pointers; errors raise
+RuntimeError with pbr_last_error(), mirroring the reference's throw-on-failure
+(ThrowIfFailed, Engine/Include/Renderer/Device/Direct12/D3DUtils.h:12-41).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .structs import (BLOOM_KNEE, BLOOM_THRESHOLD, CLUSTER_DTYPE, ENV_MIPS, HISTOGRAM_BINS,
+                      INV_LOG_LUMINANCE_RANGE, LIGHT_DTYPE, LOG_LUMINANCE_RANGE, MIN_LOG_LUMINANCE,
+                      NUM_CLUSTERS, CubeF32, GBuffer, Global, Tile, bloom_chain_texels, cube_texels)
+
+
+class PbrError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, torch.Tensor):
+        if not t.is_cuda:
+            raise PbrError("expected a device tensor")
+        if not t.is_contiguous():
+            raise PbrError("expected a contiguous tensor")
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(int(t))
+
+
+class PbrContext:
+    """One context per device per host thread (pbr_ctx is not thread-safe)."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        self.lib = _lib.load()
+        self.device = int(device)
+        h = C.c_void_p()
+        st = self.lib.pbr_ctx_create(self.device, C.byref(h))
+        if st != 0:
+            raise PbrError(f"pbr_ctx_create({device}) failed: status {st}")
+        self.h = h
+        self.torch_device = torch.device("cuda", self.device)
+        if use_torch_stream:
+            self.bind_torch_stream()
+
+    def bind_torch_stream(self):
+        """Enqueue on torch's current stream so torch allocations/events order with our kernels."""
+        s = torch.cuda.current_stream(self.torch_device)
+        self._check(self.lib.pbr_ctx_set_stream(self.h, C.c_void_p(s.cuda_stream)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pbr_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            msg = self.lib.pbr_last_error(self.h)
+            raise PbrError(f"status {st}: {msg.decode() if msg else '?'}")
+
+    def sync(self):
+        self._check(self.lib.pbr_sync(self.h))
+
+    # ---- allocation helpers (torch = device memory plumbing) ---------------------------------
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.torch_device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.torch_device)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype in (LIGHT_DTYPE, CLUSTER_DTYPE):
+            arr = arr.view(np.uint8)
+        if arr.dtype == np.uint32:
+            return torch.from_numpy(arr.view(np.int32)).to(self.torch_device)
+        if arr.dtype == np.uint16:
+            return torch.from_numpy(arr.view(np.int16)).to(self.torch_device)
+        return torch.from_numpy(arr).to(self.torch_device)
+
+    # ---- one-shot IBL --------------------------------------------------------------------------
+    def brdf_lut(self, res, out=None):
+        out = out if out is not None else self.empty((res, res, 2), torch.float16)
+        self._check(self.lib.pbr_brdf_lut(self.h, res, _ptr(out)))
+        return out
+
+    def cube_gen_mips(self, cube, size, mips):
+        self._check(self.lib.pbr_cube_gen_mips(self.h, _ptr(cube), size, mips))
+        return cube
+
+    def prefilter_env(self, sky, sky_size, sky_mips, size=512, mips=ENV_MIPS, out=None):
+        out = out if out is not None else self.empty((cube_texels(size, mips), 4), torch.float16)
+        c = CubeF32(sky.data_ptr(), sky_size, sky_mips)
+        self._check(self.lib.pbr_prefilter_env(self.h, C.byref(c), size, mips, _ptr(out)))
+        return out
+
+    def sh9_project(self, sky, sky_size, sky_mips=1, out=None):
+        out = out if out is not None else self.empty((28,), torch.float32)
+        c = CubeF32(sky.data_ptr(), sky_size, sky_mips)
+        self._check(self.lib.pbr_sh9_project(self.h, C.byref(c), _ptr(out)))
+        return out
+
+    # ---- per-frame -------------------------------------------------------------------------------
+    def alloc_clusters(self):
+        return self.zeros((NUM_CLUSTERS * CLUSTER_DTYPE.itemsize,), torch.uint8)
+
+    def cluster_build(self, g: Global, clusters):
+        self._check(self.lib.pbr_cluster_build(self.h, C.byref(g), _ptr(clusters)))
+
+    def cluster_cull(self, g: Global, lights, n, clusters):
+        self._check(self.lib.pbr_cluster_cull(self.h, C.byref(g), _ptr(lights), int(n), _ptr(clusters)))
+
+    def deferred_shade(self, g: Global, tile: Tile, gb, pitch, lut, lut_res, env, env_size, env_mips,
+                       clusters, lights, num_lights, hdr, hdr_pitch):
+        """gb: dict with device tensors A,B,C,depth,stencil."""
+        s = GBuffer(gb["A"].data_ptr(), gb["B"].data_ptr(), gb["C"].data_ptr(), gb["depth"].data_ptr(),
+                    gb["stencil"].data_ptr(), pitch)
+        self._check(self.lib.pbr_deferred_shade(self.h, C.byref(g), C.byref(tile), C.byref(s), _ptr(lut), lut_res,
+                                                _ptr(env), env_size, env_mips, _ptr(clusters), _ptr(lights),
+                                                int(num_lights), _ptr(hdr), hdr_pitch))
+
+    def bloom_prefilter(self, hdr, w, h, pitch, out, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE):
+        self._check(self.lib.pbr_bloom_prefilter(self.h, _ptr(hdr), w, h, pitch, _ptr(out), threshold, knee))
+
+    def blur_h(self, src, iw, ih, out, ow, oh):
+        self._check(self.lib.pbr_blur_h(self.h, _ptr(src), iw, ih, _ptr(out), ow, oh))
+
+    def blur_v(self, src, iw, ih, out, ow, oh):
+        self._check(self.lib.pbr_blur_v(self.h, _ptr(src), iw, ih, _ptr(out), ow, oh))
+
+    def bloom_upsample_add(self, upper, uw, uh, lower, lw, lh, out):
+        self._check(self.lib.pbr_bloom_upsample_add(self.h, _ptr(upper), uw, uh, _ptr(lower), lw, lh, _ptr(out)))
+
+    def bloom_merge(self, hdr, pitch, src, w, h):
+        self._check(self.lib.pbr_bloom_merge(self.h, _ptr(hdr), pitch, _ptr(src), w, h))
+
+    def alloc_bloom_chain(self, w, h):
+        return self.zeros((bloom_chain_texels(w, h), 4), torch.float16)
+
+    def bloom(self, hdr, w, h, pitch, chain_a, chain_b, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE):
+        self._check(self.lib.pbr_bloom(self.h, _ptr(hdr), w, h, pitch, _ptr(chain_a), _ptr(chain_b), threshold, knee))
+
+    def lum_histogram(self, hdr, w, h, pitch, hist, min_log=MIN_LOG_LUMINANCE, inv_range=INV_LOG_LUMINANCE_RANGE):
+        self._check(self.lib.pbr_lum_histogram(self.h, _ptr(hdr), w, h, pitch, min_log, inv_range, _ptr(hist)))
+
+    def lum_average(self, hist, pixel_count, dt, avg, min_log=MIN_LOG_LUMINANCE, log_range=LOG_LUMINANCE_RANGE):
+        self._check(self.lib.pbr_lum_average(self.h, _ptr(hist), pixel_count, min_log, log_range, dt, _ptr(avg)))
+
+    def tonemap(self, hdr, w, h, pitch, avg, out, out_pitch):
+        self._check(self.lib.pbr_tonemap(self.h, _ptr(hdr), w, h, pitch, _ptr(avg), _ptr(out), out_pitch))
+
+    # ---- multi-GPU --------------------------------------------------------------------------------
+    def comm_init(self, world, rank, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        self._check(self.lib.pbr_comm_init(self.h, world, rank, C.cast(buf, C.c_void_p) if buf else None))
+
+    def allreduce_hist(self, hist):
+        self._check(self.lib.pbr_allreduce_hist(self.h, _ptr(hist)))
+
+
+def comm_unique_id() -> bytes:
+    lib = _lib.load()
+    buf = C.create_string_buffer(128)
+    st = lib.pbr_comm_unique_id(C.cast(buf, C.c_void_p))
+    if st != 0:
+        raise PbrError(f"pbr_comm_unique_id failed: status {st}")
+    return buf.raw
+
+
+HIST_BINS = HISTOGRAM_BINS

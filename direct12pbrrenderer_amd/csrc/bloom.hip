@@ -1,0 +1,222 @@
+// bloom.hip — bloom chain on gfx950: soft-knee prefilter, separable 9-tap Gaussian pyramid,
+// upsample-add and merge (bloom_prefilter.hlsl, blur.hlsli, blur_horizontal/vertical.hlsl,
+// bloom_upsample_add.hlsl, bloom_merge.hlsl; schedule BloomPass::Execute,
+// DeferredPipeline.cpp:400-570).
+//
+// This translation unit is compiled with -ffp-contract=off and follows the shader's operation
+// order, so every stage is bit-identical to the CPU oracle on the same input (the path is
+// HBM-bound; un-fused multiplies cost nothing measurable).
+//
+// Layout / mapping for MI355X:
+//  * H passes keep the reference's 256-texel row groups (one 64-lane wave = 64 consecutive
+//    texels = one 512-byte half4 segment), the bilinear-sampled row is cached in LDS as float4
+//    (264 entries, ds_read_b128, conflict-free) exactly like blur.hlsli's Cache[].
+//  * V passes do NOT use the reference's 1x256 column groups (one texel per 8 KiB-strided row =
+//    64 cache lines per wave); they use 64x16 tiles: lanes run along x, the (16+8) sampled rows
+//    of the tile are staged through LDS, so global accesses stay 512-byte coalesced.
+#include "pbr_internal.hpp"
+#include "pbr_device.hpp"
+
+using namespace pbr;
+
+__constant__ float c_gauss[9] = {0.0148f, 0.0459f, 0.1050f, 0.1941f, 0.2803f, 0.1941f, 0.1050f, 0.0459f, 0.0148f};   // blur.hlsli:17
+
+__device__ __forceinline__ float4 to4(F4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ F4 from4(float4 v) { return f4(v.x, v.y, v.z, v.w); }
+
+// ---------------------------------------------------------------- bloom_prefilter.hlsl:17-60
+// grid (ceil(ow/64), ceil(oh/4)), block (64,4): one thread per half-res texel
+__global__ __launch_bounds__(256) void k_bloom_prefilter(const pbr_half* __restrict__ hdr, int w, int h, int pitch,
+                                                           pbr_half* __restrict__ out, int ow, int oh,
+                                                           float tx, float ty, float threshold, float knee) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= ow || y >= oh) return;
+    const float u = (float)x * tx, v = (float)y * ty;   // no +0.5 (Q9)
+    const float ox[5] = {0.0f, -1.0f, -1.0f, 1.0f, 1.0f};
+    const float oy[5] = {0.0f, -1.0f, 1.0f, -1.0f, 1.0f};
+    float tr = 0.0f, tg = 0.0f, tb = 0.0f, tw = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const F4 c = sample_2d_h4(hdr, w, h, pitch, u + ox[i] * tx, v + oy[i] * ty);
+        const float brightness = fmaxf(c.x, fmaxf(c.y, c.z));
+        float soft = fminf(fmaxf(brightness - threshold + threshold * knee, 0.0f), 2.0f * threshold * knee);
+        soft /= 4.0f * threshold * knee + 0.00001f;
+        const float contribution = fmaxf(soft, brightness - threshold) / fmaxf(brightness, 0.00001f);
+        const float cr = c.x * contribution, cg = c.y * contribution, cb = c.z * contribution;
+        const float wgt = 1.0f / (luminance(cr, cg, cb) + 1.0f);
+        tr += cr * wgt; tg += cg * wgt; tb += cb * wgt;
+        tw += wgt;
+    }
+    if (tw > 0.0f) { tr /= tw; tg /= tw; tb /= tw; }
+    store_h4(out + 4 * ((size_t)y * ow + x), f4(tr, tg, tb, 1.0f));
+}
+
+// ---------------------------------------------------------------- blur.hlsli:24-55
+// Fills one 264-entry cache for the 256-texel group starting at gx0 of output row y.
+__device__ __forceinline__ void blur_h_fill(float4* cache, const pbr_half* in, int iw, int ih, float tx, float ty, int gx0, int y) {
+    const int t = threadIdx.x;
+    const float uvx = ((float)(gx0 + t) + 0.5f) * tx;
+    const float uvy = ((float)y + 0.5f) * ty;
+    if (t < 4) {
+        const float xx = fmaxf(uvx - 4.0f * tx, 0.0f);
+        cache[t] = to4(sample_2d_h4(in, iw, ih, iw, xx, uvy));
+    }
+    if (t >= 252) {
+        const float xx = fminf(uvx + 4.0f * tx, 1.0f);
+        cache[t + 8] = to4(sample_2d_h4(in, iw, ih, iw, xx, uvy));
+    }
+    cache[t + 4] = to4(sample_2d_h4(in, iw, ih, iw, uvx, uvy));
+}
+__device__ __forceinline__ F4 gauss9(const float4* c) {
+    F4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 9; i++) v = v + from4(c[i]) * c_gauss[i];
+    return v;
+}
+
+// grid (ceil(ow/256), oh), block 256.  DUAL: bloom_upsample_add.hlsl:13-25 (lower first, then upper)
+template <bool DUAL>
+__global__ __launch_bounds__(256) void k_blur_h(const pbr_half* __restrict__ in, int iw, int ih,
+                                                 const pbr_half* __restrict__ in2, int iw2, int ih2,
+                                                 pbr_half* __restrict__ out, int ow, int oh, float tx, float ty) {
+    __shared__ float4 cache[DUAL ? 2 : 1][264];
+    const int gx0 = blockIdx.x * 256, y = blockIdx.y;
+    blur_h_fill(cache[0], in, iw, ih, tx, ty, gx0, y);
+    if (DUAL) blur_h_fill(cache[1], in2, iw2, ih2, tx, ty, gx0, y);
+    __syncthreads();
+    const int x = gx0 + threadIdx.x;
+    if (x >= ow) return;
+    F4 v = gauss9(cache[0] + threadIdx.x);
+    if (DUAL) v = v + gauss9(cache[1] + threadIdx.x);
+    store_h4(out + 4 * ((size_t)y * ow + x), v);
+}
+
+// ---------------------------------------------------------------- blur.hlsli:58-89
+// 64 x 16 output tiles; TR divides 256 so a tile never straddles one of the reference's
+// 256-row groups, which decides whether a halo row uses the group-edge position formula.
+constexpr int VT_W = 64, VT_R = 16;
+__global__ __launch_bounds__(256) void k_blur_v(const pbr_half* __restrict__ in, int iw, int ih,
+                                                 pbr_half* __restrict__ out, int ow, int oh, float tx, float ty) {
+    __shared__ float4 smp[VT_R + 8][VT_W];
+    const int x = blockIdx.x * VT_W + threadIdx.x;
+    const int y0 = blockIdx.y * VT_R;
+    const bool top_edge = (y0 & 255) == 0;
+    const bool bot_edge = ((y0 + VT_R) & 255) == 0;
+    const float uvx = ((float)x + 0.5f) * tx;
+    for (int r = threadIdx.y; r < VT_R + 8; r += 4) {
+        const int j = y0 - 4 + r;   // sampled row (may be outside [0, oh))
+        float vy;
+        if (r < 4 && top_edge) {
+            vy = fmaxf(((float)(j + 4) + 0.5f) * ty - 4.0f * ty, 0.0f);     // Cache[gtid.y], gtid.y < 4
+        } else if (r >= VT_R + 4 && bot_edge) {
+            vy = fminf(((float)(j - 4) + 0.5f) * ty + 4.0f * ty, 1.0f);     // Cache[gtid.y + 8], gtid.y >= 252
+        } else {
+            vy = ((float)j + 0.5f) * ty;
+        }
+        smp[r][threadIdx.x] = to4(sample_2d_h4(in, iw, ih, iw, uvx, vy));
+    }
+    __syncthreads();
+    if (x >= ow) return;
+    for (int r = threadIdx.y; r < VT_R; r += 4) {
+        const int y = y0 + r;
+        if (y >= oh) break;
+        F4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int i = 0; i < 9; i++) v = v + from4(smp[r + i][threadIdx.x]) * c_gauss[i];
+        store_h4(out + 4 * ((size_t)y * ow + x), v);
+    }
+}
+
+// ---------------------------------------------------------------- bloom_merge.hlsl:7-11
+__global__ __launch_bounds__(256) void k_bloom_merge(pbr_half* __restrict__ hdr, int pitch, const pbr_half* __restrict__ in, int w, int h) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    pbr_half* p = hdr + 4 * ((size_t)y * pitch + x);
+    store_h4(p, load_h4(p) + load_h4(in + 4 * ((size_t)y * w + x)));
+}
+
+extern "C" {
+
+pbr_status pbr_bloom_prefilter(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                               pbr_half* out, float threshold, float knee) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hdr && out, "pbr_bloom_prefilter: null pointer");
+    PBR_REQUIRE(ctx, (w >> 1) >= 1 && (h >> 1) >= 1 && w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom_prefilter: bad size");
+    const uint32_t ow = w >> 1, oh = h >> 1;
+    const float tx = 1.0f / (float)ow, ty = 1.0f / (float)oh;   // DeferredPipeline.cpp:418
+    dim3 grid((ow + 63) / 64, (oh + 3) / 4);
+    hipLaunchKernelGGL(k_bloom_prefilter, grid, dim3(64, 4), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, tx, ty, threshold, knee);
+    return launched(ctx, "k_bloom_prefilter");
+}
+
+pbr_status pbr_blur_h(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih, pbr_half* out, uint32_t ow, uint32_t oh) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, in && out, "pbr_blur_h: null pointer");
+    PBR_REQUIRE(ctx, iw && ih && ow && oh && iw <= 65535 && ih <= 65535 && ow <= 65535 && oh <= 65535, "pbr_blur_h: bad size");
+    const float tx = 1.0f / (float)ow, ty = 1.0f / (float)oh;
+    dim3 grid((ow + 255) / 256, oh);
+    hipLaunchKernelGGL(k_blur_h<false>, grid, dim3(256), 0, ctx->stream, in, (int)iw, (int)ih, (const pbr_half*)nullptr, 0, 0, out, (int)ow, (int)oh, tx, ty);
+    return launched(ctx, "k_blur_h");
+}
+
+pbr_status pbr_blur_v(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih, pbr_half* out, uint32_t ow, uint32_t oh) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, in && out, "pbr_blur_v: null pointer");
+    PBR_REQUIRE(ctx, iw && ih && ow && oh && iw <= 65535 && ih <= 65535 && ow <= 65535 && oh <= 65535, "pbr_blur_v: bad size");
+    const float tx = 1.0f / (float)ow, ty = 1.0f / (float)oh;
+    dim3 grid((ow + VT_W - 1) / VT_W, (oh + VT_R - 1) / VT_R);
+    hipLaunchKernelGGL(k_blur_v, grid, dim3(VT_W, 4), 0, ctx->stream, in, (int)iw, (int)ih, out, (int)ow, (int)oh, tx, ty);
+    return launched(ctx, "k_blur_v");
+}
+
+pbr_status pbr_bloom_upsample_add(pbr_ctx* ctx, const pbr_half* upper, uint32_t uw, uint32_t uh,
+                                  const pbr_half* lower, uint32_t lw, uint32_t lh, pbr_half* out) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, upper && lower && out, "pbr_bloom_upsample_add: null pointer");
+    PBR_REQUIRE(ctx, uw && uh && lw && lh && uw <= 65535 && uh <= 65535, "pbr_bloom_upsample_add: bad size");
+    const float tx = 1.0f / (float)uw, ty = 1.0f / (float)uh;
+    dim3 grid((uw + 255) / 256, uh);
+    hipLaunchKernelGGL(k_blur_h<true>, grid, dim3(256), 0, ctx->stream, lower, (int)lw, (int)lh, upper, (int)uw, (int)uh, out, (int)uw, (int)uh, tx, ty);
+    return launched(ctx, "k_blur_h<dual>");
+}
+
+pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pbr_half* in, uint32_t w, uint32_t h) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hdr && in, "pbr_bloom_merge: null pointer");
+    PBR_REQUIRE(ctx, w && h && w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom_merge: bad size");
+    dim3 grid((w + 255) / 256, h);
+    hipLaunchKernelGGL(k_bloom_merge, grid, dim3(256), 0, ctx->stream, hdr, (int)pitch, in, (int)w, (int)h);
+    return launched(ctx, "k_bloom_merge");
+}
+
+// BloomPass::Execute (DeferredPipeline.cpp:400-570; schedule comment :379-399)
+pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                     pbr_half* A, pbr_half* B, float threshold, float knee) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hdr && A && B, "pbr_bloom: null pointer");
+    // BloomStep < CalculateMaxMipLevels (DeferredPipeline.cpp:343): every level must be >= 1 texel
+    PBR_REQUIRE(ctx, (w >> (PBR_BLOOM_MIPS - 1)) >= 1 && (h >> (PBR_BLOOM_MIPS - 1)) >= 1, "pbr_bloom: image too small for 5 mips");
+    auto a = [&](uint32_t l) { return A + 4 * pbr_bloom_level_offset(w, h, l); };
+    auto b = [&](uint32_t l) { return B + 4 * pbr_bloom_level_offset(w, h, l); };
+    auto W = [&](uint32_t l) { return w >> l; };
+    auto H = [&](uint32_t l) { return h >> l; };
+    pbr_status r;
+    if ((r = pbr_bloom_prefilter(ctx, hdr, w, h, pitch, a(1), threshold, knee))) return r;
+    for (uint32_t i = 0; i < PBR_BLOOM_STEP; i++) {
+        uint32_t up = i + 1, lo = i + 2;
+        if ((r = pbr_blur_h(ctx, a(up), W(up), H(up), b(lo), W(lo), H(lo)))) return r;
+        if ((r = pbr_blur_v(ctx, b(lo), W(lo), H(lo), a(lo), W(lo), H(lo)))) return r;
+    }
+    for (int i = PBR_BLOOM_STEP - 1; i >= 0; i--) {
+        uint32_t up = (uint32_t)i + 1;
+        if ((r = pbr_bloom_upsample_add(ctx, a(up), W(up), H(up), a(up + 1), W(up + 1), H(up + 1), b(up)))) return r;
+        if ((r = pbr_blur_v(ctx, b(up), W(up), H(up), a(up), W(up), H(up)))) return r;
+    }
+    if ((r = pbr_blur_h(ctx, a(1), W(1), H(1), b(0), w, h))) return r;
+    if ((r = pbr_blur_v(ctx, b(0), w, h, a(0), w, h))) return r;
+    return pbr_bloom_merge(ctx, hdr, pitch, a(0), w, h);
+}
+
+}  // extern "C"

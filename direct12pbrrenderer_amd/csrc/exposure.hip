@@ -1,0 +1,164 @@
+// exposure.hip — auto-exposure (256-bin log2-luminance histogram + weighted-bin average) and
+// ACES tone-map (hdr_luminance_histogram.hlsl, hdr_average_histogram.hlsl, hdr_tone_mapping.hlsl).
+//
+// Histogram on MI355X: the reference uses 16x16 groups with 256 LDS atomics and then 256
+// global atomics PER GROUP (32 400 groups at 4K = 8.3 M global atomics).  Here a fixed grid of
+// persistent blocks streams pixel pairs with 16-byte loads, each WAVE owns a private 256-bin LDS
+// histogram (no cross-wave LDS contention), and a block issues at most 256 global atomics in
+// total — ~0.3 M for a 4K frame.  Integer sums are order-independent, so the result is
+// bit-identical to the reference's.
+#include "pbr_internal.hpp"
+#include "pbr_device.hpp"
+
+using namespace pbr;
+
+// hdr_luminance_histogram.hlsl:23-35.  log2f is the OCML (1 ulp) function, not v_log_f32 raw:
+// the value is floor()ed into a bin.  Un-contracted so the arithmetic matches the shader's.
+__device__ __forceinline__ uint32_t luminance_bin(float r, float g, float b, float min_log, float inv_range) {
+#pragma clang fp contract(off)
+    const float lum = (r * 0.2126f + g * 0.7152f) + b * 0.0722f;
+    if (lum < EPSILON_F) return 0u;
+    const float l = saturatef((log2f(lum) - min_log) * inv_range);
+    return (uint32_t)floorf(l * 254.0f + 1.0f);
+}
+
+constexpr int HIST_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void k_lum_histogram(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                                         float min_log, float inv_range, uint32_t* __restrict__ hist, bool vec2) {
+    __shared__ uint32_t sh[4][PBR_HISTOGRAM_BINS];
+    const int wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * PBR_HISTOGRAM_BINS; i += 256) (&sh[0][0])[i] = 0u;
+    __syncthreads();
+    uint32_t* my = sh[wave];
+    // vec2 (host-checked): base 16-byte aligned, w and pitch even -> rows are whole 16-byte pixel pairs
+    if (vec2) {
+        const uint32_t wp = w >> 1;
+        const size_t n = (size_t)wp * h;
+        for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+            const uint32_t y = (uint32_t)(t / wp), xp = (uint32_t)(t % wp);
+            const uint4 raw = *reinterpret_cast<const uint4*>(hdr + 4 * ((size_t)y * pitch + 2 * xp));
+            const H4 p0 = *reinterpret_cast<const H4*>(&raw.x);
+            const H4 p1 = *reinterpret_cast<const H4*>(&raw.z);
+            atomicAdd(&my[luminance_bin((float)p0.x, (float)p0.y, (float)p0.z, min_log, inv_range)], 1u);
+            atomicAdd(&my[luminance_bin((float)p1.x, (float)p1.y, (float)p1.z, min_log, inv_range)], 1u);
+        }
+    } else {
+        const size_t n = (size_t)w * h;
+        for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+            const uint32_t y = (uint32_t)(t / w), x = (uint32_t)(t % w);
+            const F4 c = load_h4(hdr + 4 * ((size_t)y * pitch + x));
+            atomicAdd(&my[luminance_bin(c.x, c.y, c.z, min_log, inv_range)], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (s) atomicAdd(&hist[threadIdx.x], s);
+}
+
+// hdr_average_histogram.hlsl:26-73 — one 256-thread group, the same LDS tree (fixed fp32 order).
+__global__ __launch_bounds__(256) void k_lum_average(uint32_t* __restrict__ hist, uint32_t pixel_count, float min_log, float range,
+                                                       float delta_time, float* __restrict__ avg) {
+#pragma clang fp contract(off)
+    __shared__ float sh[PBR_HISTOGRAM_BINS];
+    const uint32_t index = threadIdx.x;
+    const uint32_t num_pixels = hist[index];
+    sh[index] = (float)(uint32_t)(num_pixels * index);   // uint32 product (Q15)
+    __syncthreads();
+    hist[index] = 0u;   // clear for the next frame
+    for (uint32_t step = PBR_HISTOGRAM_BINS >> 1; step > 0; step >>= 1) {
+        if (index < step) sh[index] += sh[index + step];
+        __syncthreads();
+    }
+    if (index == 0) {
+        const float sum_value = sh[0];
+        const float average_bin = sum_value / (float)(pixel_count - num_pixels);   // Q14
+        // BinIndexToLuminance(uint): float -> uint truncation (Q13); NaN / negative -> 0
+        uint32_t bin = (average_bin == average_bin && average_bin > 0.0f)
+                           ? (average_bin >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)average_bin) : 0u;
+        const float log_l = ((float)bin - 1.0f) / 254.0f;
+        const float lum = exp2f(log_l * range + min_log);
+        const float prev = avg[0];
+        const float tt = saturatef(1.0f - expf(-delta_time * 1.6f));   // SMOOTH_TIME 1.6
+        avg[0] = prev + tt * (lum - prev);
+    }
+}
+
+// hdr_tone_mapping.hlsl:27-36
+__device__ __forceinline__ float aces1(float x) {
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return saturatef((x * (a * x + b)) / (x * (c * x + d) + e));
+}
+__device__ __forceinline__ uint32_t tonemap_px(float r, float g, float b, float inv_exposure_den) {
+    // exposed = luminance / (l_max + 0.001); pow(x, 0.454545) = exp2(0.454545*log2(x)) (x in [0,1])
+    const float m[3] = {aces1(r * inv_exposure_den), aces1(g * inv_exposure_den), aces1(b * inv_exposure_den)};
+    uint32_t px = 0xFF000000u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float gc = m[k] > 0.0f ? __builtin_amdgcn_exp2f(0.454545f * __builtin_amdgcn_logf(m[k])) : 0.0f;
+        px |= (uint32_t)floorf(saturatef(gc) * 255.0f + 0.5f) << (8 * k);
+    }
+    return px;
+}
+
+// grid (ceil(w/512), h), block 256: two pixels per lane (16-byte load, 8-byte store) when aligned
+__global__ __launch_bounds__(256) void k_tonemap(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                                   const float* __restrict__ avg, uint32_t* __restrict__ out, uint32_t out_pitch, bool aligned) {
+    const uint32_t y = blockIdx.y;
+    const uint32_t x = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (x >= w || y >= h) return;
+    const float l_max = 9.6f * avg[0];
+    const float den = l_max + 0.001f;
+    const bool vec2 = aligned && (x + 1 < w);
+    if (vec2) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(hdr + 4 * ((size_t)y * pitch + x));
+        const H4 p0 = *reinterpret_cast<const H4*>(&raw.x);
+        const H4 p1 = *reinterpret_cast<const H4*>(&raw.z);
+        uint2 o;
+        o.x = tonemap_px((float)p0.x / den, (float)p0.y / den, (float)p0.z / den, 1.0f);
+        o.y = tonemap_px((float)p1.x / den, (float)p1.y / den, (float)p1.z / den, 1.0f);
+        *reinterpret_cast<uint2*>(out + (size_t)y * out_pitch + x) = o;
+    } else {
+        for (uint32_t xx = x; xx < min(x + 2, w); xx++) {
+            const F4 c = load_h4(hdr + 4 * ((size_t)y * pitch + xx));
+            out[(size_t)y * out_pitch + xx] = tonemap_px(c.x / den, c.y / den, c.z / den, 1.0f);
+        }
+    }
+}
+
+extern "C" {
+
+pbr_status pbr_lum_histogram(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                             float min_log, float inv_range, uint32_t* hist256) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hdr && hist256, "pbr_lum_histogram: null pointer");
+    PBR_REQUIRE(ctx, w && h && w <= 65535 && h <= 65535 && pitch >= w, "pbr_lum_histogram: bad size");
+    size_t n = (size_t)w * h;
+    int blocks = (int)((n + 511) / 512);
+    if (blocks > HIST_BLOCKS) blocks = HIST_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const bool vec2 = (((uintptr_t)hdr & 15u) == 0u) && (((w | pitch) & 1u) == 0u);
+    hipLaunchKernelGGL(k_lum_histogram, dim3(blocks), dim3(256), 0, ctx->stream, hdr, w, h, pitch, min_log, inv_range, hist256, vec2);
+    return launched(ctx, "k_lum_histogram");
+}
+
+pbr_status pbr_lum_average(pbr_ctx* ctx, uint32_t* hist256, uint32_t pixel_count, float min_log, float range,
+                           float delta_time, float* avg_inout) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hist256 && avg_inout, "pbr_lum_average: null pointer");
+    hipLaunchKernelGGL(k_lum_average, dim3(1), dim3(256), 0, ctx->stream, hist256, pixel_count, min_log, range, delta_time, avg_inout);
+    return launched(ctx, "k_lum_average");
+}
+
+pbr_status pbr_tonemap(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                       const float* avg, uint32_t* rgba8, uint32_t out_pitch) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hdr && avg && rgba8, "pbr_tonemap: null pointer");
+    PBR_REQUIRE(ctx, w && h && w <= 65535 && h <= 65535 && pitch >= w && out_pitch >= w, "pbr_tonemap: bad size");
+    dim3 grid((w + 511) / 512, h);
+    const bool aligned = (((uintptr_t)hdr & 15u) == 0u) && (((uintptr_t)rgba8 & 7u) == 0u) && (((pitch | out_pitch) & 1u) == 0u);
+    hipLaunchKernelGGL(k_tonemap, grid, dim3(256), 0, ctx->stream, hdr, w, h, pitch, avg, rgba8, out_pitch, aligned);
+    return launched(ctx, "k_tonemap");
+}
+
+}  // extern "C"

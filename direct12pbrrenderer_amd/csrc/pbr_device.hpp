@@ -1,0 +1,212 @@
+// pbr_device.hpp — device-side helpers shared by the gfx950 kernels of the deferred-PBR path.
+// References are to /root/reference (zrlhahaha/Direct12PBRRenderer), "Shader/" =
+// DeferredRendering/Shader/.  Nothing here is shared with oracle/ — the oracle is an
+// independent CPU restatement; this file is the product's own arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pbr_hip.h"
+
+namespace pbr {
+
+// global.hlsli:4-7
+constexpr float PI_F = 3.14159265359f;
+constexpr float INV_PI_F = 0.31830988618f;
+constexpr float EPSILON_F = 1e-6f;
+constexpr float TWO_PI_F = (float)(2.0 * 3.14159265359);
+
+typedef _Float16 h16;
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// 1/sqrt: v_rsq_f32 (1 ulp) — fine inside the 1e-4 tolerance of the float paths
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ V3 normalize3(V3 v) { return v * rsq(dot3(v, v)); }
+// IEEE-exact variant (correctly rounded sqrt + divide) for the places whose result is thresholded
+__device__ __forceinline__ V3 normalize3_exact(V3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+__device__ __forceinline__ float saturatef(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }  // NaN -> 0
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+struct F4 { float x, y, z, w; };
+__device__ __forceinline__ F4 f4(float x, float y, float z, float w) { return F4{x, y, z, w}; }
+__device__ __forceinline__ F4 operator+(F4 a, F4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ F4 operator*(F4 a, float s) { return f4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+// ---- half4 texel access (R16G16B16A16_FLOAT) : one 8-byte load/store per texel -------------
+struct alignas(8) H4 { h16 x, y, z, w; };
+__device__ __forceinline__ F4 load_h4(const pbr_half* p) {
+    H4 h = *reinterpret_cast<const H4*>(p);
+    return f4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+}
+__device__ __forceinline__ void store_h4(pbr_half* p, F4 v) {
+    H4 h;
+    h.x = (h16)v.x; h.y = (h16)v.y; h.z = (h16)v.z; h.w = (h16)v.w;   // v_cvt_f16_f32: RNE, overflow -> inf
+    *reinterpret_cast<H4*>(p) = h;
+}
+struct alignas(4) H2 { h16 x, y; };
+
+// ---- software samplers (sampler s3 LinearClamp / s1 PointClamp, D3D12Device.cpp:665-684) -----
+struct BilinearCoord { int i0, i1; float f; };
+__device__ __forceinline__ BilinearCoord bilinear_coord(float u, int size) {
+    float x = u * (float)size - 0.5f;
+    x = (x == x) ? x : 0.0f;
+    x = fminf(fmaxf(x, -2.0f), (float)size + 1.0f);
+    float fl = floorf(x);
+    BilinearCoord c;
+    c.i0 = (int)fl;
+    c.i1 = c.i0 + 1;
+    c.f = x - fl;
+    return c;
+}
+__device__ __forceinline__ F4 bilerp(F4 c00, F4 c10, F4 c01, F4 c11, float fx, float fy) {
+    float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    F4 top = c00 * wx0 + c10 * fx;
+    F4 bot = c01 * wx0 + c11 * fx;
+    return top * wy0 + bot * fy;
+}
+// Texture2D<half4>.SampleLevel(LinearClamp, uv, 0)
+__device__ __forceinline__ F4 sample_2d_h4(const pbr_half* img, int w, int h, int pitch, float u, float v) {
+    BilinearCoord cx = bilinear_coord(u, w), cy = bilinear_coord(v, h);
+    int x0 = clampi(cx.i0, 0, w - 1), x1 = clampi(cx.i1, 0, w - 1);
+    int y0 = clampi(cy.i0, 0, h - 1), y1 = clampi(cy.i1, 0, h - 1);
+    F4 c00 = load_h4(img + 4 * ((size_t)y0 * pitch + x0));
+    F4 c10 = load_h4(img + 4 * ((size_t)y0 * pitch + x1));
+    F4 c01 = load_h4(img + 4 * ((size_t)y1 * pitch + x0));
+    F4 c11 = load_h4(img + 4 * ((size_t)y1 * pitch + x1));
+    return bilerp(c00, c10, c01, c11, cx.f, cy.f);
+}
+
+// ---- cube addressing: env_map_gen.hlsl:20-44 and its D3D inverse -----------------------------
+__device__ __forceinline__ V3 cube_dir_raw(uint32_t face, float u, float v) {
+    switch (face) {
+        case 0: return v3(1.0f, -v, -u);
+        case 1: return v3(-1.0f, -v, u);
+        case 2: return v3(u, 1.0f, v);
+        case 3: return v3(u, -1.0f, -v);
+        case 4: return v3(u, -v, 1.0f);
+        default: return v3(-u, -v, -1.0f);
+    }
+}
+__device__ __forceinline__ void cube_face_uv(V3 d, uint32_t& face, float& u, float& v) {
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    float sc, tc, ma;
+    if (ax >= ay && ax >= az) {
+        ma = ax;
+        if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; }
+        else             { face = 1; sc = d.z;  tc = -d.y; }
+    } else if (ay >= az) {
+        ma = ay;
+        if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; }
+        else             { face = 3; sc = d.x; tc = -d.z; }
+    } else {
+        ma = az;
+        if (d.z >= 0.0f) { face = 4; sc = d.x;  tc = -d.y; }
+        else             { face = 5; sc = -d.x; tc = -d.y; }
+    }
+    float inv = 1.0f / ma;   // IEEE divide: u,v feed floor()
+    u = (sc * inv + 1.0f) * 0.5f;
+    v = (tc * inv + 1.0f) * 0.5f;
+}
+__host__ __device__ __forceinline__ size_t cube_mip_offset(uint32_t size, uint32_t mip) {
+    size_t off = 0;
+    for (uint32_t m = 0; m < mip; m++) { size_t s = size >> m; off += 6 * s * s; }
+    return off;
+}
+
+// Seamless edge rule (same definition as the oracle): a tap outside the face is re-projected
+// onto the neighbouring face through the direction of its texel centre; a tap that leaves the
+// face in both axes is clamped in y first.
+template <class Texel>
+__device__ __forceinline__ F4 cube_fetch_seamless(int s, uint32_t face, int x, int y, const Texel& texel) {
+    bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
+    if (xo | yo) {
+        if (xo & yo) y = clampi(y, 0, s - 1);
+        float uu = 2.0f * ((float)x + 0.5f) / (float)s - 1.0f;
+        float vv = 2.0f * ((float)y + 0.5f) / (float)s - 1.0f;
+        V3 d = cube_dir_raw(face, uu, vv);
+        float u2, v2;
+        cube_face_uv(d, face, u2, v2);
+        x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
+        y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
+    }
+    return texel(face, x, y);
+}
+template <class Texel>
+__device__ __forceinline__ F4 cube_bilinear(int s, V3 dir, const Texel& texel) {
+    uint32_t face; float u, v;
+    cube_face_uv(dir, face, u, v);
+    BilinearCoord cx = bilinear_coord(u, s), cy = bilinear_coord(v, s);
+    F4 c00 = cube_fetch_seamless(s, face, cx.i0, cy.i0, texel);
+    F4 c10 = cube_fetch_seamless(s, face, cx.i1, cy.i0, texel);
+    F4 c01 = cube_fetch_seamless(s, face, cx.i0, cy.i1, texel);
+    F4 c11 = cube_fetch_seamless(s, face, cx.i1, cy.i1, texel);
+    return bilerp(c00, c10, c01, c11, cx.f, cy.f);
+}
+
+struct CubeTexelF32 {
+    const float* base; int s;
+    __device__ __forceinline__ F4 operator()(uint32_t f, int x, int y) const {
+        const float4 v = *reinterpret_cast<const float4*>(base + 4 * (((size_t)f * s + y) * s + x));
+        return f4(v.x, v.y, v.z, v.w);
+    }
+};
+struct CubeTexelF16 {
+    const pbr_half* base; int s;
+    __device__ __forceinline__ F4 operator()(uint32_t f, int x, int y) const {
+        return load_h4(base + 4 * (((size_t)f * s + y) * s + x));
+    }
+};
+// TextureCube.SampleLevel(LinearClamp, dir, lod): trilinear, lod clamped to [0, mips-1]
+template <class TexelT, class Ptr>
+__device__ __forceinline__ F4 cube_trilinear(Ptr data, uint32_t size, uint32_t mips, V3 dir, float lod) {
+    float maxl = (float)(mips - 1);
+    lod = (lod == lod) ? lod : 0.0f;
+    lod = fminf(fmaxf(lod, 0.0f), maxl);
+    float fl = floorf(lod);
+    uint32_t l0 = (uint32_t)fl;
+    uint32_t l1 = min(l0 + 1, mips - 1);
+    float f = lod - fl;
+    TexelT t0{data + 4 * cube_mip_offset(size, l0), (int)(size >> l0)};
+    F4 a = cube_bilinear((int)(size >> l0), dir, t0);
+    if (f == 0.0f || l1 == l0) return a;
+    TexelT t1{data + 4 * cube_mip_offset(size, l1), (int)(size >> l1)};
+    F4 b = cube_bilinear((int)(size >> l1), dir, t1);
+    return a * (1.0f - f) + b * f;
+}
+
+// ---- brdf.hlsli:71-114 --------------------------------------------------------------------------
+__device__ __forceinline__ float radical_inverse_vdc(uint32_t bits) {
+    return (float)__brev(bits) * 2.3283064365386963e-10f;   // the 5 swap steps == 32-bit bit reversal
+}
+// precise version (sinf/cosf/sqrtf from OCML): used to build per-sample tables once per block
+__device__ inline V3 ggx_important_sample(float roughness, V3 normal, float xi_x, float xi_y) {
+    float a = roughness * roughness;
+    float phi = TWO_PI_F * xi_x;
+    float cos_theta = sqrtf((1.0f - xi_y) / (1.0f + (a * a - 1.0f) * xi_y));
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    V3 h = v3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
+    V3 up = fabsf(normal.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+    V3 tangent = normalize3_exact(cross3(normal, up));
+    V3 bitangent = cross3(normal, tangent);
+    return normalize3_exact(tangent * h.x + bitangent * h.y + normal * h.z);
+}
+__device__ __forceinline__ float distribution_ggx(float NdotH, float roughness) {   // brdf.hlsli:6-11
+    float a = roughness * roughness;
+    float t = (NdotH * NdotH) * (a * a - 1.0f) + 1.0f;
+    return a * a / fmaxf(PI_F * t * t, EPSILON_F);
+}
+
+__device__ __forceinline__ float luminance(float r, float g, float b) {   // global.hlsli:140-143
+    return r * 0.2126f + g * 0.7152f + b * 0.0722f;
+}
+
+}  // namespace pbr

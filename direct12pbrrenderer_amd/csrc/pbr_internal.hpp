@@ -1,0 +1,48 @@
+// pbr_internal.hpp — host-side context shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <cstdio>
+#include "../../include/pbr_hip.h"
+
+struct pbr_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    void* scratch = nullptr;          // device scratch (SH partials, ...)
+    size_t scratch_bytes = 0;
+    std::string err;
+    // RCCL (loaded lazily with dlopen so a 1-GPU run never needs librccl)
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;
+    int world = 1;
+    int rank = 0;
+};
+
+namespace pbr {
+
+inline pbr_status fail(pbr_ctx* ctx, pbr_status code, const char* what) {
+    if (ctx) ctx->err = what;
+    return code;
+}
+inline pbr_status hip_fail(pbr_ctx* ctx, hipError_t e, const char* where) {
+    if (ctx) {
+        ctx->err = std::string(where) + ": " + hipGetErrorString(e);
+    }
+    return PBR_ERR_HIP;
+}
+// after a kernel launch
+inline pbr_status launched(pbr_ctx* ctx, const char* where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(ctx, e, where);
+    return PBR_OK;
+}
+
+constexpr size_t SCRATCH_BYTES = 1u << 20;
+
+}  // namespace pbr
+
+#define PBR_REQUIRE(ctx, cond, msg) \
+    do { if (!(cond)) return pbr::fail((ctx), PBR_ERR_INVALID, msg); } while (0)
+#define PBR_HIP(ctx, call) \
+    do { hipError_t e__ = (call); if (e__ != hipSuccess) return pbr::hip_fail((ctx), e__, #call); } while (0)

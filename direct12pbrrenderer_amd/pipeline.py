@@ -1,0 +1,164 @@
+"""Per-frame pass sequence of the deferred pipeline for one GPU's tile of a frame.
+
+Order = the order FrameGraph derives from the passes' declared reads/writes
+(Engine/Source/Renderer/FrameGraph.cpp:191-250 on Engine/Include/Renderer/Pipeline/DeferredPipeline.h):
+Clustered -> DeferredShading -> Bloom -> AutoExposure -> ToneMapping; bloom is applied to the HDR
+buffer BEFORE the luminance histogram and the tone-map.
+
+Multi-GPU: a rank owns an interior tile and shades/blooms it plus an apron of
+`apron` pixels on every side that has a neighbour, so the interior is what a single GPU would
+produce; the only collective is the 256-bin histogram all-reduce between a16 and a17.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from .api import PbrContext
+from .structs import (ENV_MIPS, HISTOGRAM_BINS, Global, Tile)
+
+# bloom's cumulative support is ~220 full-res pixels (3 down + 3 up levels of a radius-4 kernel on
+# a 2x pyramid); 256 also keeps every mip of the extended tile on the full frame's texel grid
+# (multiple of 16 = 2^(BLOOM_MIPS-1)).
+DEFAULT_APRON = 256
+
+
+@dataclass
+class TileSpec:
+    """Interior tile (x0,y0,w,h) of a full_w x full_h frame and its apron-extended rectangle."""
+    x0: int
+    y0: int
+    w: int
+    h: int
+    full_w: int
+    full_h: int
+    apron: int = 0
+
+    @property
+    def ex0(self):
+        return max(self.x0 - self.apron, 0)
+
+    @property
+    def ey0(self):
+        return max(self.y0 - self.apron, 0)
+
+    @property
+    def ex1(self):
+        return min(self.x0 + self.w + self.apron, self.full_w)
+
+    @property
+    def ey1(self):
+        return min(self.y0 + self.h + self.apron, self.full_h)
+
+    @property
+    def ew(self):
+        return self.ex1 - self.ex0
+
+    @property
+    def eh(self):
+        return self.ey1 - self.ey0
+
+    @property
+    def ix(self):   # interior offset inside the extended rectangle
+        return self.x0 - self.ex0
+
+    @property
+    def iy(self):
+        return self.y0 - self.ey0
+
+
+def grid_for_world(world):
+    """Tile grid (cols, rows) for `world` ranks: 1->1x1, 2->2x1, 4->2x2, 8->4x2 (BASELINE cfg5 is 2x4 of 8)."""
+    cols = 1
+    while cols * cols < world:
+        cols *= 2
+    rows = max(world // cols, 1)
+    if cols * rows != world:
+        raise ValueError(f"world size {world} is not a power of two")
+    return cols, rows
+
+
+def tile_for_rank(rank, world, tile_w, tile_h, apron=DEFAULT_APRON):
+    """Weak scaling: every rank owns one tile_w x tile_h tile of a (cols*tile_w) x (rows*tile_h) frame."""
+    cols, rows = grid_for_world(world)
+    cx, cy = rank % cols, rank // cols
+    return TileSpec(cx * tile_w, cy * tile_h, tile_w, tile_h, cols * tile_w, rows * tile_h, apron if world > 1 else 0)
+
+
+class DeferredFrame:
+    """Owns the device buffers of one rank and runs the per-frame passes through the C ABI."""
+
+    def __init__(self, ctx: PbrContext, spec: TileSpec, g: Global, lights_np, lut, lut_res, env, env_size,
+                 env_mips=ENV_MIPS, allreduce=None):
+        self.ctx, self.spec, self.g = ctx, spec, g
+        self.n_lights = int(len(lights_np))
+        self.lights = ctx.upload(lights_np) if self.n_lights else None
+        self.lut, self.lut_res, self.env, self.env_size, self.env_mips = lut, lut_res, env, env_size, env_mips
+        self.allreduce = allreduce
+        ew, eh = spec.ew, spec.eh
+        self.clusters = ctx.alloc_clusters()
+        self.hdr = ctx.zeros((eh, ew, 4), torch.float16)
+        self.chain_a = ctx.alloc_bloom_chain(ew, eh)
+        self.chain_b = ctx.alloc_bloom_chain(ew, eh)
+        self.hist = ctx.zeros((HISTOGRAM_BINS,), torch.int32)
+        self.avg = ctx.zeros((1,), torch.float32)
+        self.ldr = ctx.zeros((spec.h, spec.w), torch.int32)
+        self.gb = None
+        self.tile = Tile(spec.ex0, spec.ey0, ew, eh, spec.full_w, spec.full_h)
+
+    def upload_gbuffer(self, gb_np):
+        """gb_np: dict of numpy planes covering the EXTENDED rectangle (eh x ew)."""
+        assert gb_np["A"].shape == (self.spec.eh, self.spec.ew)
+        self.gb = {k: self.ctx.upload(v) for k, v in gb_np.items()}
+
+    def set_prev_luminance(self, v):
+        self.avg.fill_(float(v))
+
+    # interior views (pointer + pitch) of the extended HDR buffer
+    def _hdr_interior_ptr(self):
+        s = self.spec
+        return self.hdr.data_ptr() + 8 * (s.iy * s.ew + s.ix)
+
+    def clustered(self):
+        self.ctx.cluster_build(self.g, self.clusters)
+        self.ctx.cluster_cull(self.g, self.lights, self.n_lights, self.clusters)
+
+    def shade(self):
+        s = self.spec
+        self.ctx.deferred_shade(self.g, self.tile, self.gb, s.ew, self.lut, self.lut_res, self.env, self.env_size,
+                                self.env_mips, self.clusters, self.lights, self.n_lights, self.hdr, s.ew)
+
+    def bloom(self):
+        s = self.spec
+        self.ctx.bloom(self.hdr, s.ew, s.eh, s.ew, self.chain_a, self.chain_b)
+
+    def histogram(self):
+        s = self.spec
+        self.ctx.lum_histogram(self._hdr_interior_ptr(), s.w, s.h, s.ew, self.hist)
+
+    def average(self):
+        s = self.spec
+        self.ctx.lum_average(self.hist, s.full_w * s.full_h, float(self.g.DeltaTime), self.avg)
+
+    def tonemap(self):
+        s = self.spec
+        self.ctx.tonemap(self._hdr_interior_ptr(), s.w, s.h, s.ew, self.avg, self.ldr, s.w)
+
+    def render(self):
+        """One frame: every per-frame dispatch of the reference, in the frame graph's order."""
+        self.clustered()
+        self.shade()
+        self.bloom()
+        self.histogram()
+        if self.allreduce is not None:
+            self.allreduce(self.hist)
+        self.average()
+        self.tonemap()
+
+    # ---- read-back helpers for tests ---------------------------------------------------------------
+    def hdr_interior(self):
+        s = self.spec
+        return self.hdr[s.iy:s.iy + s.h, s.ix:s.ix + s.w].cpu().numpy()
+
+    def ldr_numpy(self):
+        return self.ldr.cpu().numpy().view(np.uint32)

@@ -1,0 +1,227 @@
+/*
+ * pbr_hip.h — C ABI of the MI355X-native deferred-PBR shading path.
+ *
+ * This is the drop-in boundary for the DeferredRendering HLSL compute / full-screen
+ * passes of zrlhahaha/Direct12PBRRenderer.  The reference has no FFI: its seam is
+ * D3D12CommandList::Dispatch(ShadingState*, gx, gy, gz) / DrawScreen(ShadingState*)
+ * (Engine/Include/Renderer/Device/Direct12/D3D12CommandList.h:83,103).  Every entry
+ * point below replaces ONE reference dispatch (cited per function); the C++ pass
+ * classes under direct12pbrrenderer_amd/host/ call them from their Execute() bodies.
+ *
+ * Conventions
+ *  - all image/buffer pointers are DEVICE pointers to linear, row-major planes;
+ *  - every call enqueues on the context's stream and returns immediately
+ *    (pbr_sync() blocks); a context is NOT thread-safe (one recording thread, as the
+ *    reference: Engine/Source/App.cpp:370-377);
+ *  - return value: 0 = ok, <0 = error (text via pbr_last_error);
+ *  - "half" storage is IEEE binary16 in a uint16_t (R16G16_FLOAT / R16G16B16A16_FLOAT
+ *    targets of the reference), RGBA8 planes are one uint32_t per pixel, R in the low
+ *    byte (DXGI_FORMAT_R8G8B8A8_UNORM memory order).
+ */
+#ifndef PBR_HIP_H
+#define PBR_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int pbr_status;
+enum {
+    PBR_OK              =  0,
+    PBR_ERR_INVALID     = -1,  /* bad argument (null pointer, zero size, limits exceeded) */
+    PBR_ERR_HIP         = -2,  /* HIP runtime error, see pbr_last_error                    */
+    PBR_ERR_NOMEM       = -3,
+    PBR_ERR_UNSUPPORTED = -4,
+    PBR_ERR_COMM        = -5   /* RCCL error                                               */
+};
+
+typedef struct pbr_ctx pbr_ctx;
+typedef uint16_t pbr_half;
+
+/* ---- constants the reference hard-codes (kept in sync by hand there) ------------------ */
+#define PBR_CLUSTER_X              24   /* DeferredRendering/Shader/clustered.hlsli:10-12   */
+#define PBR_CLUSTER_Y              16
+#define PBR_CLUSTER_Z              8
+#define PBR_MAX_LIGHTS_PER_CLUSTER 32   /* clustered.hlsli:9                                */
+#define PBR_MAX_SCENE_LIGHTS       1024 /* Engine/Include/Renderer/Pipeline/DeferredPipeline.h:329 */
+#define PBR_NUM_CLUSTERS           (PBR_CLUSTER_X * PBR_CLUSTER_Y * PBR_CLUSTER_Z)
+#define PBR_HISTOGRAM_BINS         256  /* DeferredPipeline.h:409                           */
+#define PBR_SAMPLE_COUNT           1024 /* precompute_brdf.hlsl:3, env_map_gen.hlsl:3       */
+#define PBR_ENV_MIPS               5    /* global.hlsli:9 PREFILTER_ENVMAP_MIPMAP_SIZE      */
+#define PBR_BLOOM_STEP             3    /* DeferredPipeline.h:211                           */
+#define PBR_BLOOM_MIPS             5    /* DeferredPipeline.h:212                           */
+
+/* ---- POD mirrors of reference structs -------------------------------------------------- */
+
+/* SH2CoefficientsPack, Engine/Include/Utils/SH.h:20-29 (7 x float4 = 112 B). */
+typedef struct pbr_sh_pack {
+    float sha_r[4], shb_r[4], sha_g[4], shb_g[4], sha_b[4], shb_b[4], shc[4];
+} pbr_sh_pack;
+
+/* ConstantBufferGlobal, Engine/Include/Renderer/Pipeline/IPipeline.h:38-62 == HLSL cbuffer
+ * GlobalConstant, global.hlsli:38-57.  Matrices row-major, mul(M, v) = M*v (column vector). */
+typedef struct pbr_global {
+    pbr_sh_pack SkyBoxSH;
+    float InvView[16];
+    float View[16];
+    float Projection[16];
+    float InvProjection[16];
+    float CameraPos[3];
+    float Ratio;
+    float Resolution[2];
+    float Near;
+    float Far;
+    float Fov;
+    float DeltaTime;
+    float Time;
+} pbr_global;                       /* 412 bytes */
+
+/* PointLight, DeferredPipeline.h:341-347 / clustered.hlsli:31-37 (44 B). */
+typedef struct pbr_light {
+    float Position[3];
+    float Color[3];
+    float Intensity;
+    float Radius, C0, C1, C2;       /* PointLightAttenuation, Scene.h:115-124 */
+} pbr_light;
+
+/* Cluster, DeferredPipeline.h:333-339 / clustered.hlsli:15-21 (156 B). */
+typedef struct pbr_cluster {
+    float MinBound[3];
+    float MaxBound[3];
+    int32_t NumLights;
+    int32_t LightIndex[PBR_MAX_LIGHTS_PER_CLUSTER];
+} pbr_cluster;
+
+/* A tile of a larger frame (new: multi-GPU split).  Planes passed with a tile
+ * cover w x h pixels (tile-local addressing); uv, the camera ray and ClusterIndex use the
+ * GLOBAL pixel (x0 + x, y0 + y) of a full_w x full_h frame.  Single GPU: {0,0,W,H,W,H}. */
+typedef struct pbr_tile {
+    uint32_t x0, y0, w, h, full_w, full_h;
+} pbr_tile;
+
+/* G-buffer as written by gbuffer.hlsl::ps_main (gbuffer.hlsl:10-26,144-146); formats
+ * DeferredPipeline.h:107-110.  A: rgb albedo (linear), a emission.  B: rg octahedral normal.
+ * C: r roughness, g metallic, b AO.  depth: D32 in [0,1].  stencil > 0 <=> geometry.
+ * pitch = row pitch in pixels of every plane. */
+typedef struct pbr_gbuffer {
+    const uint32_t* A;
+    const uint32_t* B;
+    const uint32_t* C;
+    const float*    depth;
+    const uint8_t*  stencil;
+    uint32_t        pitch;
+} pbr_gbuffer;
+
+/* fp32 RGBA cube with a mip chain: mips concatenated (mip 0 first); inside a mip the six
+ * faces +X,-X,+Y,-Y,+Z,-Z; each face row-major [y][x][4].  size = mip-0 edge. */
+typedef struct pbr_cube_f32 {
+    const float* data;
+    uint32_t size;
+    uint32_t mips;
+} pbr_cube_f32;
+
+/* ---- layout helpers (pure host functions) ----------------------------------------------- */
+/* texels (not bytes) in a cube with `mips` levels */
+size_t pbr_cube_texels(uint32_t size, uint32_t mips);
+/* texel offset of (mip, face 0) */
+size_t pbr_cube_mip_offset(uint32_t size, uint32_t mip);
+/* texels of a PBR_BLOOM_MIPS-level 2D chain of a w x h image (level l is (w>>l) x (h>>l)) */
+size_t pbr_bloom_chain_texels(uint32_t w, uint32_t h);
+size_t pbr_bloom_level_offset(uint32_t w, uint32_t h, uint32_t level);
+
+/* ---- context ------------------------------------------------------------------------------ */
+pbr_status  pbr_ctx_create(int hip_device, pbr_ctx** out);
+void        pbr_ctx_destroy(pbr_ctx* ctx);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
+pbr_status  pbr_ctx_set_stream(pbr_ctx* ctx, void* hip_stream);
+const char* pbr_last_error(const pbr_ctx* ctx);
+pbr_status  pbr_sync(pbr_ctx* ctx);
+const char* pbr_version(void);
+
+/* ---- one-shot IBL precompute --------------------------------------------------------------- */
+/* precompute_brdf.hlsl:20-62 dispatched by PrecomputeBRDFPass::Execute (DeferredPipeline.cpp:117-136).
+ * out: res*res half2, row-major [y][x]; x -> roughness, y -> NdotV. */
+pbr_status pbr_brdf_lut(pbr_ctx* ctx, uint32_t res, pbr_half* out_rg);
+
+/* 2x2 box mips of an fp32 RGBA cube in place (stands in for DirectXTex GenerateMipMaps,
+ * ResourceLoader.cpp:465-507).  cube->data mip 0 must be filled; mips 1.. are written. */
+pbr_status pbr_cube_gen_mips(pbr_ctx* ctx, float* cube_data, uint32_t size, uint32_t mips);
+
+/* env_map_gen.hlsl:50-105, all PBR_ENV_MIPS dispatches of PreFilterEnvMapPass::Execute
+ * (DeferredPipeline.cpp:77-115): mip i is filtered with roughness i/(mips-1).
+ * out: half4 cube chain, layout as pbr_cube_f32 with edge `size`. */
+pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t size, uint32_t mips,
+                             pbr_half* out_rgba);
+
+/* SHBaker::ProjectEnvironmentMap + PackCubeMapSHCoefficient (Engine/Source/Utils/SH.cpp:87-153,
+ * 201-222) as a deterministic solid-angle quadrature over every mip-0 texel.
+ * out_pack: DEVICE pointer to 28 floats (pbr_sh_pack). */
+pbr_status pbr_sh9_project(pbr_ctx* ctx, const pbr_cube_f32* sky, float* out_pack);
+
+/* ---- per-frame passes ----------------------------------------------------------------------- */
+/* clustered_compute.hlsl:18-42 (ClusteredPass::Execute, DeferredPipeline.cpp:253).
+ * g: HOST pointer (copied into kernel arguments).  clusters: device, PBR_NUM_CLUSTERS. */
+pbr_status pbr_cluster_build(pbr_ctx* ctx, const pbr_global* g, pbr_cluster* clusters);
+
+/* clustered_culling.hlsl:18-41 (DeferredPipeline.cpp:256).  lights: device, n <= 1024. */
+pbr_status pbr_cluster_cull(pbr_ctx* ctx, const pbr_global* g, const pbr_light* lights, int n,
+                            pbr_cluster* clusters);
+
+/* deferred_shading.hlsl:91-192 full-screen pass, stencil-masked (DeferredPipeline.cpp:187-206).
+ * gb: HOST struct of device planes.  lut: res x res half2.  env: half4 cube chain.
+ * lights / num_lights: the PointLights buffer the cluster lists index (num_lights <= 1024; the
+ * kernel stages exactly num_lights records into LDS, indices are clamped to that range).
+ * hdr: tile-local w x h half4, pitch hdr_pitch pixels; untouched where stencil == 0. */
+pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile,
+                              const pbr_gbuffer* gb,
+                              const pbr_half* lut, uint32_t lut_res,
+                              const pbr_half* env, uint32_t env_size, uint32_t env_mips,
+                              const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
+                              pbr_half* hdr, uint32_t hdr_pitch);
+
+/* bloom_prefilter.hlsl:17-60 (DeferredPipeline.cpp:411-427): hdr (w x h) -> out (w>>1 x h>>1). */
+pbr_status pbr_bloom_prefilter(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h,
+                               uint32_t pitch, pbr_half* out, float threshold, float knee);
+/* blur_horizontal.hlsl / blur.hlsli:24-55: in (iw x ih) sampled bilinearly at the texel
+ * centres of out (ow x oh), 9 taps one OUTPUT texel apart in x. */
+pbr_status pbr_blur_h(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih,
+                      pbr_half* out, uint32_t ow, uint32_t oh);
+/* blur_vertical.hlsl / blur.hlsli:58-89 */
+pbr_status pbr_blur_v(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih,
+                      pbr_half* out, uint32_t ow, uint32_t oh);
+/* bloom_upsample_add.hlsl:13-25: out = H(lower) + H(upper), out has upper's size. */
+pbr_status pbr_bloom_upsample_add(pbr_ctx* ctx, const pbr_half* upper, uint32_t uw, uint32_t uh,
+                                  const pbr_half* lower, uint32_t lw, uint32_t lh, pbr_half* out);
+/* bloom_merge.hlsl:7-11: hdr += in (both w x h; hdr pitch in pixels). */
+pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pbr_half* in,
+                           uint32_t w, uint32_t h);
+/* BloomPass::Execute (DeferredPipeline.cpp:400-570), all 16 dispatches.  chain_a / chain_b:
+ * pbr_bloom_chain_texels(w,h) half4 texels each (BloomMipchain / BloomTempTexture). */
+pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                     pbr_half* chain_a, pbr_half* chain_b, float threshold, float knee);
+
+/* hdr_luminance_histogram.hlsl:23-59 (DeferredPipeline.cpp:276-298): ADDS into hist256. */
+pbr_status pbr_lum_histogram(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h,
+                             uint32_t pitch, float min_log, float inv_range, uint32_t* hist256);
+/* hdr_average_histogram.hlsl:26-73 (DeferredPipeline.cpp:300-317): updates *avg_inout, zeroes hist. */
+pbr_status pbr_lum_average(pbr_ctx* ctx, uint32_t* hist256, uint32_t pixel_count, float min_log,
+                           float range, float delta_time, float* avg_inout);
+/* hdr_tone_mapping.hlsl:9-52 (DeferredPipeline.cpp:320-336): hdr -> RGBA8 UNORM. */
+pbr_status pbr_tonemap(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                       const float* avg, uint32_t* rgba8, uint32_t out_pitch);
+
+/* ---- multi-GPU (new) -------------------------------------------------------------- */
+/* RCCL communicator over the ranks of one node.  unique_id: 128 bytes from
+ * pbr_comm_unique_id() on rank 0, broadcast by the caller (e.g. torch.distributed store). */
+pbr_status pbr_comm_unique_id(void* out_128_bytes);
+pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_id_128_bytes);
+/* ncclAllReduce(sum, uint32, 256) on the ctx stream; no-op without a communicator / world 1 */
+pbr_status pbr_allreduce_hist(pbr_ctx* ctx, uint32_t* hist256);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBR_HIP_H */

@@ -1,0 +1,45 @@
+"""Shared deterministic test scenes (inputs are regenerated from seeds; goldens hold outputs only)."""
+import numpy as np
+
+from direct12pbrrenderer_amd import scene, synth
+from direct12pbrrenderer_amd.structs import Tile
+
+SKY_SIZE = 16
+SKY_MIPS = 5
+ENV_SIZE = 16
+ENV_MIPS = 5
+LUT_RES = 32
+
+
+def small_ibl(orc):
+    """sky cube (with box mips), prefiltered env, LUT and SH pack from the oracle (16^3 / 32^2)."""
+    sky = synth.env_cube(SKY_SIZE, SKY_MIPS)
+    orc.cube_gen_mips(sky, SKY_SIZE, SKY_MIPS)
+    env = orc.prefilter_env(sky, SKY_SIZE, SKY_MIPS, ENV_SIZE, ENV_MIPS)
+    lut = orc.brdf_lut(LUT_RES)
+    sh = orc.sh9_project(sky, SKY_SIZE)
+    return sky, env, lut, sh
+
+
+def shade_scene(w, h, n_lights, sh, full=None, x0=0, y0=0, rough_min=0, coverage_mask=True):
+    """Global constants, lights and a G-buffer tile for a w x h region of a full frame."""
+    full_w, full_h = full if full else (w, h)
+    cam = scene.Camera.reference_default(full_w, full_h)
+    g = scene.make_global(cam, full_w, full_h, sh_pack=sh)
+    if n_lights == 0:
+        lights = scene.make_lights(np.zeros((0, 3)), np.zeros((0, 3)), 2.0, 10.0)
+    elif n_lights == 1:
+        lights = synth.reference_scene_light()
+    else:
+        lights = synth.lights_in_view_box(n_lights, cam)
+    gb = synth.gbuffer_tile(x0, y0, w, h, full_w, full_h, rough_min=rough_min, coverage_mask=coverage_mask)
+    tile = Tile(x0, y0, w, h, full_w, full_h)
+    return cam, g, lights, gb, tile
+
+
+def half_ulp_diff(a, b):
+    """ULP distance between two float16 arrays (sign-magnitude -> monotone integer)."""
+    def key(x):
+        u = np.ascontiguousarray(x, dtype=np.float16).view(np.uint16).astype(np.int32)
+        return np.where(u & 0x8000, 0x8000 - u, u)
+    return np.abs(key(a) - key(b))

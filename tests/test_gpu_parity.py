@@ -1,0 +1,385 @@
+"""GPU parity: every HIP kernel, called through the C ABI (libpbr_hip.so), against the CPU oracle
+on the same seeded inputs and against the committed golden fixtures.
+
+Tolerances: LUT <= 1 fp16 ULP; prefiltered env <= 1 fp16 ULP or 1e-3 rel; shaded HDR
+<= 1e-4 relative L-inf (relative to the frame's max radiance) and <= a few fp16 ULP per texel; bloom
+stages bit-exact (the bloom TU is built -ffp-contract=off in the oracle's operation order);
+histogram exact up to boundary flips <= 1e-5 N; average luminance exact given an equal histogram;
+RGBA8 <= 1 LSB; SH <= 1e-5 relative.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import common
+from direct12pbrrenderer_amd import scene, synth
+from direct12pbrrenderer_amd.structs import (CLUSTER_DTYPE, NUM_CLUSTERS, Tile, bloom_level_offset, cube_mip_offset)
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_half(ctx, arr):
+    return ctx.upload(np.ascontiguousarray(arr, dtype=np.float16).view(np.uint16)).view(torch.float16)
+
+
+def to_np_half(t):
+    return t.cpu().view(torch.int16).numpy().view(np.float16)
+
+
+def assert_half_close(got, want, max_ulp, what, frac_over=0.0, hard_ulp=None):
+    d = common.half_ulp_diff(got, want)
+    nan_mismatch = np.isnan(got.astype(np.float32)) != np.isnan(want.astype(np.float32))
+    assert not nan_mismatch.any(), f"{what}: NaN pattern differs"
+    over = (d > max_ulp) & ~np.isnan(want.astype(np.float32))
+    assert over.mean() <= frac_over, f"{what}: {over.sum()} of {d.size} texels differ by > {max_ulp} ULP (max {d.max()})"
+    if hard_ulp is not None:
+        assert d[~np.isnan(want.astype(np.float32))].max() <= hard_ulp, f"{what}: max ULP {d.max()} > {hard_ulp}"
+
+
+# ------------------------------------------------------------------------------------------ a3
+@pytest.mark.parametrize("res", [32, 256])
+def test_brdf_lut_vs_oracle(ctx, orc, golden, res):
+    got = to_np_half(ctx.brdf_lut(res))
+    if res == 32:
+        want = orc.brdf_lut(32)
+        assert np.array_equal(want, golden["lut32"])
+        assert_half_close(got, want, 1, "LUT 32")
+    else:
+        for r in (0, 100, 255):
+            assert_half_close(got[r], golden[f"lut256_row{r}"], 1, f"LUT 256 row {r}")
+        rows = orc.brdf_lut_rows(256, 37, 2)
+        assert_half_close(got[37:39], rows, 1, "LUT 256 rows 37-38")
+
+
+def test_brdf_lut_512_reference_default(ctx, golden):
+    # the reference's real LUT size (DeferredPipeline.h:80,85)
+    got = to_np_half(ctx.brdf_lut(512))
+    for r in (0, 255, 511):
+        assert_half_close(got[r], golden[f"lut512_row{r}"], 1, f"LUT 512 row {r}")
+    # analytic column: roughness 0 => A = 1-(1-NdotV)^5, B = (1-NdotV)^5
+    ndv = (np.arange(512) + 1) / 512
+    B = (1 - ndv) ** 5
+    assert np.abs(got[:, 0, 0].astype(np.float64) - (1 - B)).max() <= 5e-4
+    assert np.abs(got[:, 0, 1].astype(np.float64) - B).max() <= 5e-4
+
+
+def test_brdf_lut_bad_args(ctx):
+    from direct12pbrrenderer_amd.api import PbrError
+    with pytest.raises(PbrError):
+        ctx.brdf_lut(1, out=ctx.empty((4,), torch.float16))
+
+
+# ------------------------------------------------------------------------------------------ cube mips / a4 / a5
+def test_cube_gen_mips_bit_exact(ctx, orc):
+    sky = synth.env_cube(32, 6)
+    want = orc.cube_gen_mips(sky.copy(), 32, 6)
+    d = ctx.upload(sky)
+    ctx.cube_gen_mips(d, 32, 6)
+    assert np.array_equal(d.cpu().numpy(), want)
+
+
+def test_prefilter_env_vs_oracle_and_golden(ctx, orc, golden, ibl):
+    sky, env, _, _ = ibl
+    got = to_np_half(ctx.prefilter_env(ctx.upload(sky), common.SKY_SIZE, common.SKY_MIPS, common.ENV_SIZE, common.ENV_MIPS))
+    assert np.array_equal(env, golden["env16"])
+    g32, w32 = got.astype(np.float32), env.astype(np.float32)
+    ok = (common.half_ulp_diff(got, env) <= 1) | (np.abs(g32 - w32) <= 1e-3 * np.abs(w32))
+    assert ok.all(), f"prefilter: {(~ok).sum()} texels outside 1 ULP / 1e-3"
+    assert np.all(got[:, 3] == 1.0)
+
+
+def test_prefilter_env_larger_cube_one_mip(ctx, orc):
+    # 64^2 source, 32^2 output mip 2 (roughness 0.5): exercises PDF-based LOD selection across mips
+    sky = synth.env_cube(64, 7)
+    orc.cube_gen_mips(sky, 64, 7)
+    got = to_np_half(ctx.prefilter_env(ctx.upload(sky), 64, 7, 128, 5))
+    m = 2
+    want = orc.prefilter_env_mip(sky, 64, 7, 128, 5, m)
+    off = cube_mip_offset(128, m)
+    sub = got[off: off + want.shape[0]]
+    ok = (common.half_ulp_diff(sub, want) <= 1) | (np.abs(sub.astype(np.float32) - want.astype(np.float32)) <= 1e-3 * np.abs(want.astype(np.float32)))
+    assert ok.all()
+
+
+def test_sh9_vs_oracle(ctx, orc, golden, ibl):
+    sky = ibl[0]
+    got = ctx.sh9_project(ctx.upload(sky), common.SKY_SIZE, common.SKY_MIPS).cpu().numpy()
+    want = orc.sh9_project(sky, common.SKY_SIZE)
+    assert np.array_equal(want, golden["sh16"])
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1e-5 * scale
+    # 128^2 cube (98 304 texels -> multi-block reduction)
+    sky2 = synth.env_cube(128, 1)
+    got2 = ctx.sh9_project(ctx.upload(sky2), 128, 1).cpu().numpy()
+    want2 = orc.sh9_project(sky2, 128)
+    assert np.abs(got2 - want2).max() <= 1e-5 * np.abs(want2).max()
+
+
+# ------------------------------------------------------------------------------------------ a13
+def _clusters_from_dev(t):
+    return np.frombuffer(t.cpu().numpy().tobytes(), dtype=CLUSTER_DTYPE).copy()
+
+
+def test_cluster_build_and_cull(ctx, orc, golden, ibl):
+    cam, g, lights, gb, tile = common.shade_scene(64, 64, 256, ibl[3])
+    want = orc.cluster_build(g)
+    d = ctx.alloc_clusters()
+    ctx.cluster_build(g, d)
+    got = _clusters_from_dev(d)
+    for k in ("MinBound", "MaxBound"):
+        assert np.allclose(got[k], want[k], rtol=2e-6, atol=1e-7), k     # powf/tanf are libm-class on both sides
+    assert np.all(got["NumLights"] == 0)
+    # cull on the ORACLE's boxes must give the identical light lists (integer output)
+    d2 = ctx.upload(want)
+    ctx.cluster_cull(g, ctx.upload(lights), len(lights), d2)
+    got2 = _clusters_from_dev(d2)
+    orc.cluster_cull(g, lights, want)
+    assert np.array_equal(got2["NumLights"], want["NumLights"])
+    assert np.array_equal(want["NumLights"], golden["clusters_l256_numlights"])
+    mask = np.arange(32)[None, :] < want["NumLights"][:, None]
+    assert np.array_equal(got2["LightIndex"][mask], want["LightIndex"][mask])
+    assert want["NumLights"].max() == 32 and (want["NumLights"] == 0).any()   # cap and empties both exercised
+    # cull on the GPU-built boxes: ULP-level box differences may flip only borderline lights
+    ctx.cluster_cull(g, ctx.upload(lights), len(lights), d)
+    got3 = _clusters_from_dev(d)
+    assert (got3["NumLights"] != want["NumLights"]).mean() <= 0.002
+
+
+def test_cluster_cull_edge_cases(ctx, orc, ibl):
+    from direct12pbrrenderer_amd.api import PbrError
+    cam, g, lights, gb, tile = common.shade_scene(64, 64, 1, ibl[3])
+    d = ctx.alloc_clusters()
+    ctx.cluster_build(g, d)
+    ctx.cluster_cull(g, None, 0, d)                       # zero lights is legal
+    assert np.all(_clusters_from_dev(d)["NumLights"] == 0)
+    with pytest.raises(PbrError):
+        ctx.cluster_cull(g, ctx.upload(lights), 1025, d)  # > MaxSceneLights (DeferredPipeline.cpp:222)
+    # 1024 lights, the reference's maximum
+    many = synth.lights_in_view_box(1024, cam)
+    want = orc.cluster_build(g)
+    d2 = ctx.upload(want)
+    ctx.cluster_cull(g, ctx.upload(many), 1024, d2)
+    orc.cluster_cull(g, many, want)
+    got = _clusters_from_dev(d2)
+    assert np.array_equal(got["NumLights"], want["NumLights"])
+    mask = np.arange(32)[None, :] < want["NumLights"][:, None]
+    assert np.array_equal(got["LightIndex"][mask], want["LightIndex"][mask])
+
+
+# ------------------------------------------------------------------------------------------ a8-a12
+def _shade_on_gpu(ctx, g, tile, gb, lut, env, env_size, env_mips, clusters_np, lights, prefill=None):
+    h, w = gb["A"].shape
+    gbd = {k: ctx.upload(v) for k, v in gb.items()}
+    hdr = ctx.zeros((h, w, 4), torch.float16) if prefill is None else dev_half(ctx, prefill)
+    ctx.deferred_shade(g, tile, gbd, w, dev_half(ctx, lut), lut.shape[0], dev_half(ctx, env), env_size, env_mips,
+                       ctx.upload(clusters_np), ctx.upload(lights) if len(lights) else None, len(lights), hdr, w)
+    return to_np_half(hdr)
+
+
+def _check_shade(got, want, want_f32, stencil, what):
+    on = stencil > 0
+    scale = np.abs(want_f32[on][:, :3]).max()
+    err = np.abs(got.astype(np.float32) - want.astype(np.float32))[on][:, :3]
+    # fp16 storage of the largest value costs up to scale * 2^-11; the 1e-4 L-inf bound is on top of it
+    assert err.max() <= 1e-4 * scale + scale * 2.0 ** -11, f"{what}: L-inf {err.max()} vs scale {scale}"
+    assert_half_close(got[on], want[on], 2, what, frac_over=1e-3, hard_ulp=64)
+    assert np.all(got[on][:, 3] == 1.0)
+
+
+@pytest.mark.parametrize("n_lights", [0, 1, 256])
+def test_deferred_shade_64_vs_oracle_and_golden(ctx, orc, golden, ibl, n_lights):
+    sky, env, lut, sh = ibl
+    cam, g, lights, gb, tile = common.shade_scene(64, 64, n_lights, sh)
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    assert np.array_equal(want, golden[f"shade64_l{n_lights}"])
+    sentinel = np.full((64, 64, 4), 7.0, dtype=np.float16)
+    got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, prefill=sentinel)
+    _check_shade(got, want, want_f32, gb["stencil"], f"shade {n_lights} lights")
+    assert np.all(got[gb["stencil"] == 0] == 7.0)      # stencil == 0 pixels are left untouched
+
+
+def test_deferred_shade_ragged_tile_of_a_larger_frame(ctx, orc, ibl):
+    # 200 x 37 tile at (328, 91) of a 640 x 360 frame: width not a multiple of 64/256, rows not of 8,
+    # global-pixel uv / camera ray / ClusterIndex, pitch > width
+    sky, env, lut, sh = ibl
+    cam, g, lights, gb, tile = common.shade_scene(200, 37, 256, sh, full=(640, 360), x0=328, y0=91)
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+    _check_shade(got, want, want_f32, gb["stencil"], "ragged tile")
+    # the same region shaded as part of the whole frame agrees with the tile
+    cam2, g2, lights2, gbf, tilef = common.shade_scene(640, 360, 256, sh)
+    full = _shade_on_gpu(ctx, g2, tilef, gbf, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights2)
+    assert np.array_equal(full[91:91 + 37, 328:328 + 200], got)
+
+
+# ------------------------------------------------------------------------------------------ a14-a15
+def _levels(flat, w, h):
+    return [flat[bloom_level_offset(w, h, l): bloom_level_offset(w, h, l + 1)].reshape(h >> l, w >> l, 4) for l in range(5)]
+
+
+def test_bloom_stages_bit_exact(ctx, orc):
+    img = synth.hdr_noise_image(300, 170)       # odd half sizes: 150x85 -> 75x42 -> 37x21 -> 18x10
+    d = dev_half(ctx, img)
+    pre = ctx.zeros((85, 150, 4), torch.float16)
+    ctx.bloom_prefilter(d, 300, 170, 300, pre)
+    want_pre = orc.bloom_prefilter(img)
+    assert np.array_equal(to_np_half(pre).view(np.uint16), want_pre.view(np.uint16))
+    out = ctx.zeros((42, 75, 4), torch.float16)
+    ctx.blur_h(pre, 150, 85, out, 75, 42)       # 2x downsample H
+    want_h = orc.blur_h(want_pre, 75, 42)
+    assert np.array_equal(to_np_half(out).view(np.uint16), want_h.view(np.uint16))
+    out2 = ctx.zeros((42, 75, 4), torch.float16)
+    ctx.blur_v(out, 75, 42, out2, 75, 42)
+    want_v = orc.blur_v(want_h, 75, 42)
+    assert np.array_equal(to_np_half(out2).view(np.uint16), want_v.view(np.uint16))
+    up = ctx.zeros((85, 150, 4), torch.float16)
+    ctx.bloom_upsample_add(pre, 150, 85, out2, 75, 42, up)
+    want_up = orc.bloom_upsample_add(want_pre, want_v)
+    assert np.array_equal(to_np_half(up).view(np.uint16), want_up.view(np.uint16))
+    hdr = dev_half(ctx, img)
+    big = dev_half(ctx, synth.hdr_noise_image(300, 170, seed=77))
+    ctx.bloom_merge(hdr, 300, big, 300, 170)
+    want_m = orc.bloom_merge(img.copy(), synth.hdr_noise_image(300, 170, seed=77))
+    assert np.array_equal(to_np_half(hdr).view(np.uint16), want_m.view(np.uint16))
+
+
+def test_blur_group_edges_wide_and_tall(ctx, orc):
+    # > 256 texels in x and y: exercises the 256-group halo protocol of blur.hlsli:24-89 on both axes
+    img = synth.hdr_noise_image(600, 530, seed=5)
+    d = dev_half(ctx, img)
+    o = ctx.zeros((530, 600, 4), torch.float16)
+    ctx.blur_h(d, 600, 530, o, 600, 530)
+    assert np.array_equal(to_np_half(o).view(np.uint16), orc.blur_h(img, 600, 530).view(np.uint16))
+    ctx.blur_v(d, 600, 530, o, 600, 530)
+    assert np.array_equal(to_np_half(o).view(np.uint16), orc.blur_v(img, 600, 530).view(np.uint16))
+
+
+def test_bloom_chain_vs_golden_every_mip(ctx, orc, golden):
+    img = synth.hdr_noise_image(128, 72)
+    hdr = dev_half(ctx, img)
+    a, b = ctx.alloc_bloom_chain(128, 72), ctx.alloc_bloom_chain(128, 72)
+    ctx.bloom(hdr, 128, 72, 128, a, b)
+    ga, gb_ = to_np_half(a), to_np_half(b)
+    for l in range(5):
+        la, lb = _levels(ga, 128, 72)[l], _levels(gb_, 128, 72)[l]
+        wa, wb = _levels(golden["bloom_chain_a"], 128, 72)[l], _levels(golden["bloom_chain_b"], 128, 72)[l]
+        assert np.array_equal(la.view(np.uint16), wa.view(np.uint16)), f"chain A level {l}"
+        assert np.array_equal(lb.view(np.uint16), wb.view(np.uint16)), f"chain B level {l}"
+    assert np.array_equal(to_np_half(hdr).view(np.uint16), golden["bloom_hdr"].view(np.uint16))
+
+
+def test_bloom_too_small_is_rejected(ctx):
+    from direct12pbrrenderer_amd.api import PbrError
+    hdr = ctx.zeros((8, 8, 4), torch.float16)
+    with pytest.raises(PbrError):
+        ctx.bloom(hdr, 8, 8, 8, ctx.alloc_bloom_chain(8, 8), ctx.alloc_bloom_chain(8, 8))
+
+
+# ------------------------------------------------------------------------------------------ a16-a18
+def test_histogram_average_tonemap_vs_golden(ctx, orc, golden):
+    hdr_np = golden["bloom_hdr"]
+    hdr = dev_half(ctx, hdr_np)
+    hist = ctx.zeros((256,), torch.int32)
+    ctx.lum_histogram(hdr, 128, 72, 128, hist)
+    got_hist = hist.cpu().numpy().view(np.uint32)
+    assert got_hist.sum() == 128 * 72
+    assert np.abs(got_hist.astype(np.int64) - golden["hist"].astype(np.int64)).sum() <= 2   # boundary flips
+    # average on the oracle's histogram: exact
+    hist2 = ctx.upload(golden["hist"])
+    avg = ctx.upload(np.array([0.18], dtype=np.float32))
+    ctx.lum_average(hist2, 128 * 72, 1.0 / 60.0, avg)
+    assert avg.cpu().numpy()[0] == pytest.approx(float(golden["avg"]), rel=2e-6)
+    assert np.all(hist2.cpu().numpy() == 0)                         # cleared for the next frame
+    ldr = ctx.zeros((72, 128), torch.int32)
+    ctx.tonemap(hdr, 128, 72, 128, ctx.upload(np.array([golden["avg"]], dtype=np.float32)), ldr, 128)
+    got = ldr.cpu().numpy().view(np.uint32)
+    want = golden["ldr"]
+    for k in range(4):
+        dch = np.abs(((got >> (8 * k)) & 255).astype(np.int32) - ((want >> (8 * k)) & 255).astype(np.int32))
+        assert dch.max() <= 1, f"channel {k}"
+    assert np.all(got >> 24 == 255)
+
+
+def test_histogram_ragged_and_accumulating(ctx, orc):
+    img = synth.hdr_noise_image(333, 77, seed=9)                    # odd width: scalar path
+    img[5, 5, :3] = 0.0                                             # a black pixel -> bin 0
+    hist = ctx.zeros((256,), torch.int32)
+    d = dev_half(ctx, img)
+    ctx.lum_histogram(d, 333, 77, 333, hist)
+    ctx.lum_histogram(d, 333, 77, 333, hist)                        # the pass ADDS (InterlockedAdd)
+    want = orc.lum_histogram(img) * 2
+    got = hist.cpu().numpy().view(np.uint32)
+    assert got.sum() == want.sum() and got[0] == want[0] >= 2
+    assert np.abs(got.astype(np.int64) - want.astype(np.int64)).sum() <= 4
+    # interior view of a wider buffer (pitch > w, pointer offset)
+    wide = np.zeros((77, 400, 4), dtype=np.float16)
+    wide[:, 40:40 + 332] = img[:, :332]
+    dw = dev_half(ctx, wide)
+    hist.zero_()
+    ctx.lum_histogram(dw.data_ptr() + 8 * 40, 332, 77, 400, hist)
+    want2 = orc.lum_histogram(np.ascontiguousarray(img[:, :332]))
+    assert np.abs(hist.cpu().numpy().view(np.uint32).astype(np.int64) - want2.astype(np.int64)).sum() <= 2
+
+
+def test_average_truncation_overflow_and_black_frame(ctx, orc):
+    def run(hist_np, count, dt, prev):
+        h = ctx.upload(hist_np)
+        a = ctx.upload(np.array([prev], dtype=np.float32))
+        ctx.lum_average(h, count, dt, a)
+        return a.cpu().numpy()[0]
+    h = np.zeros(256, dtype=np.uint32)
+    h[10], h[11] = 1, 3                                              # Q13 truncation
+    assert run(h, 4, 1e9, 0.0) == np.float32(orc.lum_average(h.copy(), 4, 1e9, 0.0))
+    h = np.zeros(256, dtype=np.uint32)
+    h[255] = 20_000_000                                              # Q15 uint32 wrap
+    assert run(h, 20_000_000, 1.0 / 60.0, 0.5) == pytest.approx(orc.lum_average(h.copy(), 20_000_000, 1.0 / 60.0, 0.5), rel=2e-6)
+    h = np.zeros(256, dtype=np.uint32)
+    h[0] = 100                                                       # Q14 all-black frame: 0/0
+    got, want = run(h, 100, 1.0 / 60.0, 0.25), orc.lum_average(h.copy(), 100, 1.0 / 60.0, 0.25)
+    assert (np.isnan(got) and np.isnan(want)) or got == pytest.approx(want, rel=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ whole frame
+def test_frame_1080p_region_properties_and_oracle_sample(ctx, orc, ibl):
+    """cfg2-sized frame (1920x1080, 1 light): full-size run checked through size-independent
+    properties plus an oracle comparison on a 96-row band."""
+    from direct12pbrrenderer_amd.pipeline import DeferredFrame, TileSpec
+    sky, env, lut, sh = ibl
+    W, H = 1920, 1080
+    cam, g, lights, gb, tile = common.shade_scene(W, H, 1, sh, rough_min=48, coverage_mask=False)
+    spec = TileSpec(0, 0, W, H, W, H, 0)
+    fr = DeferredFrame(ctx, spec, g, lights, dev_half(ctx, lut), lut.shape[0], dev_half(ctx, env), common.ENV_SIZE, common.ENV_MIPS)
+    fr.upload_gbuffer(gb)
+    fr.set_prev_luminance(0.18)
+    fr.clustered()
+    fr.shade()
+    shaded = to_np_half(fr.hdr).copy()
+    assert np.isfinite(shaded.astype(np.float32)).all()
+    # oracle on a band of rows (global-pixel math makes a band == the same rows of the frame)
+    y0, rows = 500, 96
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    band = {k: np.ascontiguousarray(v[y0:y0 + rows]) for k, v in gb.items()}
+    want, want_f32 = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "1080p band")
+    fr.bloom()
+    fr.histogram()
+    hist = fr.hist.cpu().numpy().view(np.uint32).copy()
+    assert hist.sum() == W * H                                       # checksum of the histogram
+    fr.average()
+    fr.tonemap()
+    ldr = fr.ldr_numpy()
+    assert np.all(ldr >> 24 == 255)
+    # tone-map is monotone in the exposed value: brighter HDR red never maps to a darker byte
+    hdr_after = to_np_half(fr.hdr).astype(np.float32)
+    r = hdr_after[..., 0].ravel()
+    order = np.argsort(r, kind="stable")
+    assert np.all(np.diff((ldr.ravel()[order] & 255).astype(np.int32)) >= 0)
+    # bloom only adds light (weights and inputs are non-negative)
+    assert np.all(hdr_after[..., :3] >= shaded.astype(np.float32)[..., :3] - 1e-3)
