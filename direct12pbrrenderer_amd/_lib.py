@@ -23,6 +23,7 @@ SIGNATURES = {
     "pbr_ctx_create": (_int, [_int, C.POINTER(_vp)]),
     "pbr_ctx_destroy": (None, [_vp]),
     "pbr_ctx_set_stream": (_int, [_vp, _vp]),
+    "pbr_ctx_use_own_stream": (_int, [_vp]),
     "pbr_last_error": (C.c_char_p, [_vp]),
     "pbr_sync": (_int, [_vp]),
     "pbr_brdf_lut": (_int, [_vp, _u32, _vp]),

@@ -55,7 +55,13 @@ void pbr_ctx_destroy(pbr_ctx* ctx) {
 
 pbr_status pbr_ctx_set_stream(pbr_ctx* ctx, void* hip_stream) {
     if (!ctx) return PBR_ERR_INVALID;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;   // NULL is HIP's default (null) stream, a legal target
+    return PBR_OK;
+}
+
+pbr_status pbr_ctx_use_own_stream(pbr_ctx* ctx) {
+    if (!ctx) return PBR_ERR_INVALID;
+    ctx->stream = ctx->own_stream;
     return PBR_OK;
 }
 

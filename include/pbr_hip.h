@@ -135,8 +135,11 @@ size_t pbr_bloom_level_offset(uint32_t w, uint32_t h, uint32_t level);
 /* ---- context ------------------------------------------------------------------------------ */
 pbr_status  pbr_ctx_create(int hip_device, pbr_ctx** out);
 void        pbr_ctx_destroy(pbr_ctx* ctx);
-/* use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
+/* enqueue on an existing hipStream_t (e.g. torch's current stream).  NULL selects HIP's default
+ * (null) stream.  A new context starts on a private non-blocking stream. */
 pbr_status  pbr_ctx_set_stream(pbr_ctx* ctx, void* hip_stream);
+/* go back to the context's private stream */
+pbr_status  pbr_ctx_use_own_stream(pbr_ctx* ctx);
 const char* pbr_last_error(const pbr_ctx* ctx);
 pbr_status  pbr_sync(pbr_ctx* ctx);
 const char* pbr_version(void);
