@@ -82,6 +82,9 @@ def tile_for_rank(rank, world, tile_w, tile_h, apron=DEFAULT_APRON):
     """Weak scaling: every rank owns one tile_w x tile_h tile of a (cols*tile_w) x (rows*tile_h) frame."""
     cols, rows = grid_for_world(world)
     cx, cy = rank % cols, rank // cols
+    if world > 1 and (tile_w % 16 or tile_h % 16 or apron % 16):
+        # every bloom mip of the extended tile must sit on the full frame's texel grid (2^(BLOOM_MIPS-1) = 16)
+        raise ValueError("tile size and apron must be multiples of 16 for multi-GPU tiling")
     return TileSpec(cx * tile_w, cy * tile_h, tile_w, tile_h, cols * tile_w, rows * tile_h, apron if world > 1 else 0)
 
 

@@ -1,0 +1,117 @@
+"""Host logic and the C-ABI surface — no GPU needed (no compute call is made)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from direct12pbrrenderer_amd import _lib, scene, structs, synth
+from direct12pbrrenderer_amd.pipeline import TileSpec, grid_for_world, tile_for_rank
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "pbr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pbr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 28 and "pbr_deferred_shade" in names and "pbr_allreduce_hist" in names
+    lib = _lib.load()
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/pbr_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.pbr_version().decode().startswith("pbr_hip")
+
+
+def test_layout_helpers_match_python_mirrors():
+    lib = _lib.load()
+    for size, mips in ((512, 5), (16, 5), (8, 4), (1, 1)):
+        assert lib.pbr_cube_texels(size, mips) == structs.cube_texels(size, mips)
+        for m in range(mips):
+            assert lib.pbr_cube_mip_offset(size, m) == structs.cube_mip_offset(size, m)
+    assert structs.cube_texels(512, 5) == 2_095_104
+    for w, h in ((3840, 2160), (1920, 1080), (128, 72), (300, 170)):
+        assert lib.pbr_bloom_chain_texels(w, h) == structs.bloom_chain_texels(w, h)
+        for l in range(5):
+            assert lib.pbr_bloom_level_offset(w, h, l) == structs.bloom_level_offset(w, h, l)
+
+
+def test_struct_sizes_match_reference_layouts():
+    assert C.sizeof(structs.Global) == 412 and C.sizeof(structs.ShPack) == 112
+    assert structs.LIGHT_DTYPE.itemsize == 44 and structs.CLUSTER_DTYPE.itemsize == 156
+    assert C.sizeof(structs.Tile) == 24
+    assert structs.NUM_CLUSTERS == 3072
+
+
+def test_null_context_is_rejected_without_touching_a_gpu():
+    lib = _lib.load()
+    assert lib.pbr_sync(None) == -1
+    assert lib.pbr_brdf_lut(None, 512, None) == -1
+    assert lib.pbr_allreduce_hist(None, None) == -1
+    assert lib.pbr_last_error(None) == b"null context"
+
+
+def test_camera_matches_reference_defaults():
+    cam = scene.Camera.reference_default(1440, 960)             # App.h:77-78, App.cpp:99-101
+    assert np.allclose(cam.translation(), [0, 3, 10])
+    W = cam.world_matrix()
+    assert np.allclose(W[:3, :3], np.diag([-1, 1, -1]), atol=1e-6)   # yaw PI: looks down -z
+    V = cam.local_space_matrix()
+    assert np.allclose(V @ W, np.eye(4), atol=1e-5)
+    P = cam.projection_matrix()                                  # MathLib.cpp:35-68
+    t = np.tan(0.333 * np.pi / 2)
+    assert P[0, 0] == pytest.approx(1 / (1.5 * t), rel=1e-5) and P[1, 1] == pytest.approx(1 / t, rel=1e-5)
+    assert P[2, 2] == pytest.approx(1000 / 999.9, rel=1e-6) and P[2, 3] == pytest.approx(-100 / 999.9, rel=1e-5) and P[3, 2] == 1
+    g = scene.make_global(cam, 1440, 960, delta_time=1 / 60)
+    assert g.Ratio == pytest.approx(1.5) and g.Near == pytest.approx(0.1) and g.Far == 1000.0
+    assert list(g.Resolution) == [1440.0, 960.0]
+    assert np.allclose(np.array(g.InvProjection[:]).reshape(4, 4) @ P, np.eye(4), atol=1e-3)
+
+
+def test_attenuation_presets_are_a_step_function():
+    # Scene.cpp:132-165 (quirk Q18): radius 2 picks the 7.0 preset's coefficients
+    assert scene.attenuation_coefficients(2.0) == (2.0, 1.0, 0.7, 1.8)
+    assert scene.attenuation_coefficients(0.05)[1:] == (1.0, 45.0, 7500.0)
+    assert scene.attenuation_coefficients(7.0)[1:] == (1.0, 0.7, 1.8)
+    assert scene.attenuation_coefficients(1.0)[1:] == (1.0, 4.5, 75.0)
+    assert scene.attenuation_coefficients(500.0) == (600.0, 1.0, 0.007, 0.0002)   # falls through to the last preset
+    l = synth.reference_scene_light()
+    assert l["C1"][0] == np.float32(0.7) and l["C2"][0] == np.float32(1.8) and l["Intensity"][0] == 10.0
+
+
+def test_synthetic_tile_equals_region_of_full_frame():
+    full = synth.gbuffer_tile(0, 0, 96, 64, 96, 64, coverage_mask=True)
+    sub = synth.gbuffer_tile(32, 16, 40, 20, 96, 64, coverage_mask=True)
+    for k in full:
+        assert np.array_equal(full[k][16:36, 32:72], sub[k]), k
+    assert 0.02 < (full["stencil"] == 0).mean() < 0.3
+    assert full["depth"].min() > 0.89 and full["depth"].max() < 1.0
+    rough = full["C"] & 255
+    assert rough.min() >= 48 and (synth.gbuffer_tile(0, 0, 64, 64, 64, 64, rough_min=0)["C"] & 255).min() < 8
+
+
+def test_tile_specs_cover_the_frame_once():
+    for world in (1, 2, 4, 8):
+        cols, rows = grid_for_world(world)
+        cover = np.zeros((rows * 48, cols * 64), dtype=np.int32)
+        for r in range(world):
+            s = tile_for_rank(r, world, 64, 48, apron=16)
+            cover[s.y0:s.y0 + s.h, s.x0:s.x0 + s.w] += 1
+            assert (s.full_w, s.full_h) == (cols * 64, rows * 48)
+            assert 0 <= s.ex0 <= s.x0 and s.ex1 <= s.full_w and s.ix == s.x0 - s.ex0
+            assert (s.apron == 0) == (world == 1)
+            assert s.ex0 % 16 == 0 and s.ey0 % 16 == 0      # extended origin stays on the coarsest mip grid
+        assert np.all(cover == 1)
+    with pytest.raises(ValueError):
+        grid_for_world(6)
+    with pytest.raises(ValueError):
+        tile_for_rank(0, 2, 64, 40, apron=16)
+    s = TileSpec(0, 0, 64, 40, 128, 40, 16)
+    assert (s.ew, s.eh) == (80, 40)
