@@ -29,6 +29,7 @@ SIGNATURES = {
     "pbr_brdf_lut": (_int, [_vp, _u32, _vp]),
     "pbr_cube_gen_mips": (_int, [_vp, _vp, _u32, _u32]),
     "pbr_prefilter_env": (_int, [_vp, C.POINTER(CubeF32), _u32, _u32, _vp]),
+    "pbr_prefilter_env_mip": (_int, [_vp, C.POINTER(CubeF32), _u32, _u32, _f32, _vp]),
     "pbr_sh9_project": (_int, [_vp, C.POINTER(CubeF32), _vp]),
     "pbr_cluster_build": (_int, [_vp, C.POINTER(Global), _vp]),
     "pbr_cluster_cull": (_int, [_vp, C.POINTER(Global), _vp, _int, _vp]),

@@ -249,18 +249,27 @@ pbr_status pbr_cube_gen_mips(pbr_ctx* ctx, float* cube, uint32_t size, uint32_t 
     return PBR_OK;
 }
 
+pbr_status pbr_prefilter_env_mip(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t size, uint32_t mip_level,
+                                 float roughness, pbr_half* out_mip) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, sky && sky->data && out_mip, "pbr_prefilter_env_mip: null pointer");
+    PBR_REQUIRE(ctx, sky->size >= 1 && sky->mips >= 1 && (sky->size >> (sky->mips - 1)) >= 1, "pbr_prefilter_env_mip: bad sky cube");
+    PBR_REQUIRE(ctx, size >= 1 && size <= 8192 && mip_level < 16 && (size >> mip_level) >= 1, "pbr_prefilter_env_mip: bad output size/mip");
+    PBR_REQUIRE(ctx, roughness >= 0.0f && roughness <= 1.0f, "pbr_prefilter_env_mip: roughness outside [0,1]");
+    const uint32_t s = size >> mip_level;
+    const size_t n = (size_t)6 * s * s;
+    hipLaunchKernelGGL(k_prefilter_env, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       sky->data, sky->size, sky->mips, size, s, roughness, out_mip);
+    return launched(ctx, "k_prefilter_env");
+}
+
 pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t size, uint32_t mips, pbr_half* out) {
     if (!ctx) return PBR_ERR_INVALID;
-    PBR_REQUIRE(ctx, sky && sky->data && out, "pbr_prefilter_env: null pointer");
-    PBR_REQUIRE(ctx, sky->size >= 1 && sky->mips >= 1 && (sky->size >> (sky->mips - 1)) >= 1, "pbr_prefilter_env: bad sky cube");
-    PBR_REQUIRE(ctx, size >= 1 && size <= 8192 && mips >= 1 && (size >> (mips - 1)) >= 1, "pbr_prefilter_env: bad output size/mips");
+    PBR_REQUIRE(ctx, out != nullptr, "pbr_prefilter_env: null pointer");
+    PBR_REQUIRE(ctx, size >= 1 && mips >= 1 && mips <= 16 && (size >> (mips - 1)) >= 1, "pbr_prefilter_env: bad output size/mips");
     for (uint32_t m = 0; m < mips; m++) {
-        uint32_t s = size >> m;
-        size_t n = (size_t)6 * s * s;
-        float roughness = mips > 1 ? (float)m / (float)(mips - 1) : 0.0f;   // DeferredPipeline.cpp:99
-        hipLaunchKernelGGL(k_prefilter_env, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           sky->data, sky->size, sky->mips, size, s, roughness, out + 4 * cube_mip_offset(size, m));
-        pbr_status r = launched(ctx, "k_prefilter_env");
+        const float roughness = mips > 1 ? (float)m / (float)(mips - 1) : 0.0f;   // DeferredPipeline.cpp:99
+        pbr_status r = pbr_prefilter_env_mip(ctx, sky, size, m, roughness, out + 4 * cube_mip_offset(size, m));
         if (r) return r;
     }
     return PBR_OK;

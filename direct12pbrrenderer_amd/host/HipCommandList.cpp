@@ -1,0 +1,250 @@
+// HipCommandList.cpp — ShadingState binding checks + the shader-file -> C-ABI dispatch table.
+#include "HipCommandList.h"
+
+#include "ShaderConstants.h"
+
+namespace MRendererHip {
+
+// ---------------------------------------------------------------------------------------------
+// "Reflection": the resource names each shader file declares (what DXC reflection reports to
+// ShadingState::FindShaderAttribute, Engine/Source/Renderer/Pipeline/IPipeline.cpp:188-199).
+// Files are the reference's DeferredRendering/Shader/*.hlsl; the kernels are in csrc/*.hip.
+static const std::vector<ShaderReflection>& Reflections() {
+    static const std::vector<ShaderReflection> table = {
+        {"precompute_brdf.hlsl", true, {}, {"PrecomputeBRDF"}, {}, {}, sizeof(PrecomputeBRDFConstant)},
+        {"env_map_gen.hlsl", true, {"SkyBox"}, {"PrefilterEnvMap"}, {}, {}, sizeof(PreFilterEnvMapConstant)},
+        {"clustered_compute.hlsl", true, {}, {}, {}, {"Clusters"}, sizeof(ClusteredShaderConstant)},
+        {"clustered_culling.hlsl", true, {}, {}, {}, {"Clusters", "PointLights"}, sizeof(ClusteredShaderConstant)},
+        {"deferred_shading.hlsl", false,
+         {"GBufferA", "GBufferB", "GBufferC", "DepthStencil", "PrecomputeBRDF", "PrefilterEnvMap"}, {}, {"Clusters", "PointLights"}, {}, 0},
+        {"bloom_prefilter.hlsl", true, {"InputTexture"}, {"OutputTexture"}, {}, {}, sizeof(BloomPrefilterConstant)},
+        {"blur_horizontal.hlsl", true, {"InputTexture"}, {"OutputTexture"}, {}, {}, sizeof(BlurConstant)},
+        {"blur_vertical.hlsl", true, {"InputTexture"}, {"OutputTexture"}, {}, {}, sizeof(BlurConstant)},
+        {"bloom_upsample_add.hlsl", true, {"UpperLevel", "LowerLevel"}, {"OutputTexture"}, {}, {}, sizeof(BlurConstant)},
+        {"bloom_merge.hlsl", true, {"InputTexture"}, {"OutputTexture"}, {}, {}, 0},
+        {"hdr_luminance_histogram.hlsl", true, {"LuminanceTexture"}, {}, {}, {"LuminanceHistogram"}, sizeof(LuminanceHistogramConstant)},
+        {"hdr_average_histogram.hlsl", true, {}, {}, {}, {"LuminanceHistogram", "AverageLuminance"}, sizeof(AverageLuminanceConstant)},
+        {"hdr_tone_mapping.hlsl", false, {"LuminanceTexture"}, {}, {}, {"AverageLuminance"}, 0},
+        // raster shaders of the reference: out of scope; known so that SetShader succeeds
+        {"gbuffer.hlsl", false, {}, {}, {}, {}, 0},
+        {"skybox.hlsl", false, {"SkyBox"}, {}, {}, {}, 0},
+    };
+    return table;
+}
+
+const ShaderReflection* FindShader(std::string_view file) {
+    for (const auto& r : Reflections())
+        if (r.File == file) return &r;
+    return nullptr;
+}
+
+// --------------------------------------------------------------------------------------------- ShadingState
+void ShadingState::SetShader(std::string_view shader_file_path, bool is_compute) {
+    mShader = FindShader(shader_file_path);
+    if (!mShader) throw HipException("ShadingState::SetShader: no HIP kernel for shader file " + std::string(shader_file_path));
+    if (mShader->IsCompute != is_compute) throw HipException("ShadingState::SetShader: compute/graphics mismatch for " + std::string(shader_file_path));
+    mIsCompute = is_compute;
+    ClearResourceBinding();
+}
+
+bool ShadingState::Known(const std::vector<std::string_view>& names, std::string_view semantic_name, const char* kind) const {
+    if (mShader && std::find(names.begin(), names.end(), semantic_name) != names.end()) return true;
+    // the reference logs and returns false when the name is not in the shader's reflection data
+    std::fprintf(stderr, "[ShadingState] %s: no %s named '%.*s'\n", std::string(File()).c_str(), kind, (int)semantic_name.size(), semantic_name.data());
+    return false;
+}
+
+bool ShadingState::SetTexture(std::string_view name, DeviceTexture* texture) {
+    if (!Known(mShader ? mShader->Textures : std::vector<std::string_view>{}, name, "texture")) return false;
+    if (mTextures.size() >= MaxShaderResourceViews && !mTextures.count(std::string(name))) return false;
+    mTextures[std::string(name)] = TextureBinding{texture, -1};
+    return true;
+}
+bool ShadingState::SetTexture(std::string_view name, DeviceTexture2D* texture, uint32 mip_slice) {
+    if (!Known(mShader ? mShader->Textures : std::vector<std::string_view>{}, name, "texture")) return false;
+    if (texture && mip_slice >= texture->MipLevels()) throw HipException("ShadingState::SetTexture: mip slice out of range");
+    mTextures[std::string(name)] = TextureBinding{texture, (int32)mip_slice};
+    return true;
+}
+bool ShadingState::SetRWTexture(std::string_view name, DeviceTexture2D* texture) {
+    if (!Known(mShader ? mShader->RWTextures : std::vector<std::string_view>{}, name, "RW texture")) return false;
+    mRWTextures[std::string(name)] = TextureBinding{texture, 0};
+    return true;
+}
+bool ShadingState::SetRWTexture(std::string_view name, DeviceTexture2D* texture, uint32 mip_slice) {
+    if (!Known(mShader ? mShader->RWTextures : std::vector<std::string_view>{}, name, "RW texture")) return false;
+    if (texture && mip_slice >= texture->MipLevels()) throw HipException("ShadingState::SetRWTexture: mip slice out of range");
+    mRWTextures[std::string(name)] = TextureBinding{texture, (int32)mip_slice};
+    return true;
+}
+bool ShadingState::SetRWTextureArray(std::string_view name, DeviceTexture2DArray* texture) {
+    if (!Known(mShader ? mShader->RWTextures : std::vector<std::string_view>{}, name, "RW texture array")) return false;
+    mRWTextures[std::string(name)] = TextureBinding{texture, -1};
+    return true;
+}
+bool ShadingState::SetStructuredBuffer(std::string_view name, DeviceStructuredBuffer* buffer) {
+    if (!Known(mShader ? mShader->StructuredBuffers : std::vector<std::string_view>{}, name, "structured buffer")) return false;
+    mBuffers[std::string(name)] = buffer;
+    return true;
+}
+bool ShadingState::SetRWStructuredBuffer(std::string_view name, DeviceStructuredBuffer* buffer) {
+    if (!Known(mShader ? mShader->RWStructuredBuffers : std::vector<std::string_view>{}, name, "RW structured buffer")) return false;
+    mBuffers[std::string(name)] = buffer;
+    return true;
+}
+void ShadingState::ClearResourceBinding() {
+    mTextures.clear();
+    mRWTextures.clear();
+    mBuffers.clear();
+}
+const TextureBinding& ShadingState::Texture(std::string_view name) const {
+    auto it = mTextures.find(std::string(name));
+    if (it == mTextures.end() || !it->second.Texture) throw HipException(std::string(File()) + ": texture '" + std::string(name) + "' is not bound");
+    return it->second;
+}
+const TextureBinding& ShadingState::RWTexture(std::string_view name) const {
+    auto it = mRWTextures.find(std::string(name));
+    if (it == mRWTextures.end() || !it->second.Texture) throw HipException(std::string(File()) + ": RW texture '" + std::string(name) + "' is not bound");
+    return it->second;
+}
+DeviceStructuredBuffer* ShadingState::Buffer(std::string_view name) const {
+    auto it = mBuffers.find(std::string(name));
+    if (it == mBuffers.end() || !it->second) throw HipException(std::string(File()) + ": buffer '" + std::string(name) + "' is not bound");
+    return it->second;
+}
+
+// --------------------------------------------------------------------------------------------- HipCommandList
+HipCommandList::HipCommandList(int hip_device) {
+    pbr_status st = pbr_ctx_create(hip_device, &mCtx);
+    if (st != PBR_OK) throw HipException("pbr_ctx_create failed (status " + std::to_string(st) + ")");
+}
+HipCommandList::~HipCommandList() { pbr_ctx_destroy(mCtx); }
+
+void HipCommandList::Check(pbr_status st, const char* what) {
+    if (st != PBR_OK) throw HipException(std::string(what) + ": " + pbr_last_error(mCtx));
+}
+void HipCommandList::EndFrame() { Check(pbr_sync(mCtx), "pbr_sync"); }
+
+namespace {
+struct Mip {
+    pbr_half* ptr;
+    uint32 w, h;
+};
+Mip MipOf(const TextureBinding& b) {
+    auto* t = dynamic_cast<DeviceTexture2D*>(b.Texture);
+    if (!t) throw HipException("expected a 2D texture binding");
+    uint32 m = b.MipSlice < 0 ? 0 : (uint32)b.MipSlice;
+    return Mip{(pbr_half*)t->MipPtr(m), t->Width() >> m, t->Height() >> m};
+}
+uint32 Groups(uint32 size, uint32 group) { return (size + group - 1) / group; }
+void ExpectGroups(std::string_view file, uint32 gx, uint32 gy, uint32 gz, uint32 ex, uint32 ey, uint32 ez) {
+    if (gx != ex || gy != ey || gz != ez)
+        throw HipException(std::string(file) + ": dispatch shape (" + std::to_string(gx) + "," + std::to_string(gy) + "," + std::to_string(gz) +
+                           ") does not cover the bound output (" + std::to_string(ex) + "," + std::to_string(ey) + "," + std::to_string(ez) + ")");
+}
+}  // namespace
+
+void HipCommandList::Dispatch(ShadingState* s, uint32 gx, uint32 gy, uint32 gz) {
+    if (!s || !s->GetShader() || !s->IsCompute()) throw HipException("Dispatch: shading state has no compute shader");
+    const std::string_view f = s->File();
+    mDispatchCount++;
+    if (f == "precompute_brdf.hlsl") {
+        const auto& c = s->Constants<PrecomputeBRDFConstant>();
+        auto* out = dynamic_cast<DeviceTexture2D*>(s->RWTexture("PrecomputeBRDF").Texture);
+        if (!out || out->Width() != c.TextureResolution || out->Height() != c.TextureResolution) throw HipException("precompute_brdf: LUT size != TextureResolution");
+        ExpectGroups(f, gx, gy, gz, Groups(c.TextureResolution, 8), Groups(c.TextureResolution, 8), 1);
+        Check(pbr_brdf_lut(mCtx, c.TextureResolution, (pbr_half*)out->DevicePtr()), "pbr_brdf_lut");
+    } else if (f == "env_map_gen.hlsl") {
+        const auto& c = s->Constants<PreFilterEnvMapConstant>();
+        auto* sky = dynamic_cast<DeviceTexture2DArray*>(s->Texture("SkyBox").Texture);
+        auto* out = dynamic_cast<DeviceTexture2DArray*>(s->RWTexture("PrefilterEnvMap").Texture);
+        if (!sky || !out || out->Size() != c.EnvMapSize || c.MipLevel >= out->MipLevels()) throw HipException("env_map_gen: bad bindings");
+        const uint32 ms = c.EnvMapSize >> c.MipLevel;
+        ExpectGroups(f, gx, gy, gz, Groups(ms, 8), Groups(ms, 8), 6);   // z = NumCubeMapFaces (quirk Q7: only 6 of the 30 z-threads are useful)
+        pbr_cube_f32 cube{(const float*)sky->DevicePtr(), sky->Size(), sky->MipLevels()};
+        pbr_half* dst = (pbr_half*)out->DevicePtr() + 4 * pbr_cube_mip_offset(out->Size(), c.MipLevel);
+        Check(pbr_prefilter_env_mip(mCtx, &cube, c.EnvMapSize, c.MipLevel, c.Roughness, dst), "pbr_prefilter_env_mip");
+    } else if (f == "clustered_compute.hlsl") {
+        ExpectGroups(f, gx, gy, gz, 1, 1, 1);
+        Check(pbr_cluster_build(mCtx, &mGlobal, (pbr_cluster*)s->Buffer("Clusters")->DevicePtr()), "pbr_cluster_build");
+    } else if (f == "clustered_culling.hlsl") {
+        ExpectGroups(f, gx, gy, gz, 1, 1, 1);
+        const auto& c = s->Constants<ClusteredShaderConstant>();
+        mNumLights = c.NumLight;
+        Check(pbr_cluster_cull(mCtx, &mGlobal, (const pbr_light*)s->Buffer("PointLights")->DevicePtr(), c.NumLight,
+                               (pbr_cluster*)s->Buffer("Clusters")->DevicePtr()), "pbr_cluster_cull");
+    } else if (f == "bloom_prefilter.hlsl") {
+        const auto& c = s->Constants<BloomPrefilterConstant>();
+        Mip in = MipOf(s->Texture("InputTexture")), out = MipOf(s->RWTexture("OutputTexture"));
+        // the reference sizes this grid by the FULL resolution (quirk Q9); the kernel covers the half-res output
+        ExpectGroups(f, gx, gy, gz, Groups(in.w, 16), Groups(in.h, 16), 1);
+        if (out.w != (in.w >> 1) || out.h != (in.h >> 1)) throw HipException("bloom_prefilter: output is not the half-res mip");
+        Check(pbr_bloom_prefilter(mCtx, in.ptr, in.w, in.h, in.w, out.ptr, c.Threshold, c.Knee), "pbr_bloom_prefilter");
+    } else if (f == "blur_horizontal.hlsl" || f == "blur_vertical.hlsl") {
+        Mip in = MipOf(s->Texture("InputTexture")), out = MipOf(s->RWTexture("OutputTexture"));
+        (void)s->Constants<BlurConstant>();   // TexelSize = 1/output size; recomputed identically inside the C ABI
+        if (f == "blur_horizontal.hlsl") {
+            ExpectGroups(f, gx, gy, gz, Groups(out.w, 256), out.h, 1);
+            Check(pbr_blur_h(mCtx, in.ptr, in.w, in.h, out.ptr, out.w, out.h), "pbr_blur_h");
+        } else {
+            ExpectGroups(f, gx, gy, gz, out.w, Groups(out.h, 256), 1);
+            Check(pbr_blur_v(mCtx, in.ptr, in.w, in.h, out.ptr, out.w, out.h), "pbr_blur_v");
+        }
+    } else if (f == "bloom_upsample_add.hlsl") {
+        Mip up = MipOf(s->Texture("UpperLevel")), lo = MipOf(s->Texture("LowerLevel")), out = MipOf(s->RWTexture("OutputTexture"));
+        ExpectGroups(f, gx, gy, gz, Groups(out.w, 256), out.h, 1);
+        if (out.w != up.w || out.h != up.h) throw HipException("bloom_upsample_add: output size != upper level");
+        Check(pbr_bloom_upsample_add(mCtx, up.ptr, up.w, up.h, lo.ptr, lo.w, lo.h, out.ptr), "pbr_bloom_upsample_add");
+    } else if (f == "bloom_merge.hlsl") {
+        Mip in = MipOf(s->Texture("InputTexture")), out = MipOf(s->RWTexture("OutputTexture"));
+        ExpectGroups(f, gx, gy, gz, Groups(out.w, 16), Groups(out.h, 16), 1);
+        Check(pbr_bloom_merge(mCtx, out.ptr, out.w, in.ptr, out.w, out.h), "pbr_bloom_merge");
+    } else if (f == "hdr_luminance_histogram.hlsl") {
+        const auto& c = s->Constants<LuminanceHistogramConstant>();
+        Mip in = MipOf(s->Texture("LuminanceTexture"));
+        ExpectGroups(f, gx, gy, gz, Groups(c.TextureWidth, 16), Groups(c.TextureHeight, 16), 1);
+        Check(pbr_lum_histogram(mCtx, in.ptr, c.TextureWidth, c.TextureHeight, in.w, c.MinLogLuminance, c.InvLogLuminanceRange,
+                                (uint32_t*)s->Buffer("LuminanceHistogram")->DevicePtr()), "pbr_lum_histogram");
+    } else if (f == "hdr_average_histogram.hlsl") {
+        const auto& c = s->Constants<AverageLuminanceConstant>();
+        ExpectGroups(f, gx, gy, gz, 1, 1, 1);
+        uint32_t* hist = (uint32_t*)s->Buffer("LuminanceHistogram")->DevicePtr();
+        // new step: with several GPUs the tile histograms are summed first; no-op on one GPU
+        Check(pbr_allreduce_hist(mCtx, hist), "pbr_allreduce_hist");
+        Check(pbr_lum_average(mCtx, hist, c.PixelCount, c.MinLogLuminance, c.LogLuminanceRange, mGlobal.DeltaTime,
+                              (float*)s->Buffer("AverageLuminance")->DevicePtr()), "pbr_lum_average");
+    } else {
+        throw HipException("Dispatch: " + std::string(f) + " is not a compute kernel of this build");
+    }
+}
+
+void HipCommandList::DrawScreen(ShadingState* s) {
+    if (!s || !s->GetShader() || s->IsCompute()) throw HipException("DrawScreen: shading state has no pixel shader");
+    const std::string_view f = s->File();
+    mDispatchCount++;
+    if (!mRenderTarget) throw HipException("DrawScreen: no render target bound (FrameGraph::PreparePass)");
+    if (f == "deferred_shading.hlsl") {
+        auto tex = [&](const char* n) { return dynamic_cast<DeviceTexture2D*>(s->Texture(n).Texture); };
+        DeviceTexture2D *a = tex("GBufferA"), *b = tex("GBufferB"), *c = tex("GBufferC"), *ds = tex("DepthStencil"), *lut = tex("PrecomputeBRDF");
+        auto* env = dynamic_cast<DeviceTexture2DArray*>(s->Texture("PrefilterEnvMap").Texture);
+        if (!a || !b || !c || !ds || !lut || !env) throw HipException("deferred_shading: bad texture bindings");
+        const uint32 w = mRenderTarget->Width(), h = mRenderTarget->Height();
+        pbr_gbuffer gb{(const uint32_t*)a->DevicePtr(), (const uint32_t*)b->DevicePtr(), (const uint32_t*)c->DevicePtr(),
+                       ds->DepthPlane(), ds->StencilPlane(), w};
+        pbr_tile tile = mTile.w ? mTile : pbr_tile{0, 0, w, h, w, h};
+        // stencil ref 0, compare LESS: shade where 0 < stencil (DeferredPipeline.h:176-181, .cpp:203)
+        if (mStencilRef != 0) throw HipException("deferred_shading: only stencil ref 0 is supported");
+        Check(pbr_deferred_shade(mCtx, &mGlobal, &tile, &gb, (const pbr_half*)lut->DevicePtr(), lut->Width(),
+                                 (const pbr_half*)env->DevicePtr(), env->Size(), env->MipLevels(),
+                                 (const pbr_cluster*)s->Buffer("Clusters")->DevicePtr(), (const pbr_light*)s->Buffer("PointLights")->DevicePtr(),
+                                 mNumLights, (pbr_half*)mRenderTarget->DevicePtr(), w), "pbr_deferred_shade");
+    } else if (f == "hdr_tone_mapping.hlsl") {
+        Mip in = MipOf(s->Texture("LuminanceTexture"));
+        Check(pbr_tonemap(mCtx, in.ptr, in.w, in.h, in.w, (const float*)s->Buffer("AverageLuminance")->DevicePtr(),
+                          (uint32_t*)mRenderTarget->DevicePtr(), mRenderTarget->Width()), "pbr_tonemap");
+    } else {
+        throw HipException("DrawScreen: " + std::string(f) + " is not a full-screen kernel of this build");
+    }
+}
+
+}  // namespace MRendererHip

@@ -1,0 +1,58 @@
+// HipCommandList.h — the dispatch seam.  Stands where D3D12CommandList stands in the reference
+// (Engine/Include/Renderer/Device/Direct12/D3D12CommandList.h:83 DrawScreen, :103 Dispatch;
+// .cpp:80-97, :116-133): a pass hands over a ShadingState (shader file + named bindings + POD
+// constants) and a dispatch shape; here that becomes ONE call into the C ABI of
+// include/pbr_hip.h on the context's HIP stream.  Work is recorded serially by one thread and
+// executes in order on one stream, which gives the ordering the reference gets from its single
+// DIRECT queue (it issues no UAV barriers between dependent dispatches).
+#pragma once
+#include "IPipeline.h"
+
+namespace MRendererHip {
+
+class HipCommandList {
+public:
+    explicit HipCommandList(int hip_device);
+    ~HipCommandList();
+    HipCommandList(const HipCommandList&) = delete;
+    HipCommandList& operator=(const HipCommandList&) = delete;
+
+    void BeginFrame() { mDispatchCount = 0; }
+    void EndFrame();   // D3D12Device::EndFrame blocks on the fence every frame (D3D12Device.cpp:993-1003)
+
+    // global constants (b2), RenderScheduler.cpp:22-41
+    void SetGlobalConstant(const ConstantBufferGlobal& g) { mGlobal = g; }
+    const ConstantBufferGlobal& GlobalConstant() const { return mGlobal; }
+
+    void SetStencilRef(uint32 ref) { mStencilRef = ref; }
+    // bound by FrameGraph::PreparePass for a GraphicsPass (Engine/Source/Renderer/FrameGraph.cpp:94-141)
+    void SetRenderTarget(DeviceTexture2D* rt) { mRenderTarget = rt; }
+    // multi-GPU: the region of the full frame this device renders; default = whole target
+    void SetTile(const pbr_tile& tile) { mTile = tile; }
+
+    // compute dispatch of `state`'s shader; (x,y,z) are thread-GROUP counts exactly as the reference passes them
+    void Dispatch(ShadingState* state, uint32 thread_group_count_x, uint32 thread_group_count_y, uint32 thread_group_count_z);
+    // full-screen triangle with `state`'s pixel shader
+    void DrawScreen(ShadingState* state);
+    void Present(DeviceTexture2D* tex) { mPresented = tex; }
+
+    pbr_ctx* Context() const { return mCtx; }
+    uint32 DispatchCount() const { return mDispatchCount; }
+    DeviceTexture2D* Presented() const { return mPresented; }
+    // the light count the last clustered_culling dispatch was given (the HIP shade stages exactly that many records)
+    int32 NumLights() const { return mNumLights; }
+
+private:
+    void Check(pbr_status st, const char* what);
+
+    pbr_ctx* mCtx = nullptr;
+    ConstantBufferGlobal mGlobal{};
+    uint32 mStencilRef = 0;
+    uint32 mDispatchCount = 0;
+    int32 mNumLights = 0;
+    DeviceTexture2D* mPresented = nullptr;
+    DeviceTexture2D* mRenderTarget = nullptr;
+    pbr_tile mTile{};
+};
+
+}  // namespace MRendererHip

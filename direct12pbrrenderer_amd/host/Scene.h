@@ -1,0 +1,129 @@
+// Scene.h — the slice of Scene / Camera / RenderScheduler the shading path consumes.
+//
+// Camera        <- Engine/Include/Renderer/Camera.h:9-50, Engine/Source/Renderer/Camera.cpp:5-12,
+//                  MathLib.cpp:35-68 (ProjectionMatrix1), MathLib.h:656-671 (FromEulerAngle), :786-811 (QuickInverse)
+// SceneLight    <- Engine/Include/Renderer/Scene.h:115-184, Engine/Source/Renderer/Scene.cpp:122-165
+// Scene         <- light list + sky box (cube + SH pack); meshes/materials are out of scope, the
+//                  G-buffer a frame starts from is supplied as planes (synthetic or captured)
+// RenderScheduler <- Engine/Source/Renderer/RenderScheduler.cpp:16-47
+#pragma once
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "HipCommandList.h"
+
+namespace MRendererHip {
+
+struct Vector3 { float x, y, z; };
+
+struct Matrix4x4 {
+    float m[16];   // row-major, M*v
+    static Matrix4x4 Identity() {
+        Matrix4x4 r{};
+        r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f;
+        return r;
+    }
+    float& At(int r, int c) { return m[r * 4 + c]; }
+    float At(int r, int c) const { return m[r * 4 + c]; }
+};
+
+Matrix4x4 ProjectionMatrix1(float fov, float ratio, float near_z, float far_z);
+Matrix4x4 QuickInverse(const Matrix4x4& m);
+Matrix4x4 Inverse(const Matrix4x4& m);
+
+class Camera {
+public:
+    Camera(float fov, uint32 width, uint32 height, float near_plane, float far_plane)
+        : mFov(fov), mRatio((float)width / (float)height), mNear(near_plane), mFar(far_plane),
+          mRoll(0), mYaw(0), mPitch(0), mViewSpaceTransform(Matrix4x4::Identity()) {}
+    void Move(const Vector3& d) {
+        mViewSpaceTransform.m[3] += d.x;
+        mViewSpaceTransform.m[7] += d.y;
+        mViewSpaceTransform.m[11] += d.z;
+    }
+    void Rotate(float roll, float yaw, float pitch);
+    Matrix4x4 GetWorldMatrix() const { return mViewSpaceTransform; }
+    Matrix4x4 GetLocalSpaceMatrix() const { return QuickInverse(mViewSpaceTransform); }
+    Matrix4x4 GetProjectionMatrix() const { return ProjectionMatrix1(mFov, mRatio, mNear, mFar); }
+    Vector3 GetTranslation() const { return Vector3{mViewSpaceTransform.m[3], mViewSpaceTransform.m[7], mViewSpaceTransform.m[11]}; }
+    float Near() const { return mNear; }
+    float Far() const { return mFar; }
+    float Fov() const { return mFov; }
+    float Ratio() const { return mRatio; }
+protected:
+    float mFov, mRatio, mNear, mFar, mRoll, mYaw, mPitch;
+    Matrix4x4 mViewSpaceTransform;
+};
+
+struct PointLightAttenuation { float Radius, ConstantCoefficent, LinearCoefficent, QuadraticCoefficent; };
+
+class SceneLight {
+public:
+    SceneLight(const Vector3& pos, const Vector3& color, float radius, float intensity)
+        : mTranslation(pos), mColor(color), mRadius(radius), mIntensity(intensity), mAttenuation(CaclAttenuationCoefficients(radius)) {}
+    Vector3 GetTranslation() const { return mTranslation; }
+    const Vector3& GetColor() const { return mColor; }
+    float GetRadius() const { return mRadius; }
+    float GetIntensity() const { return mIntensity; }
+    const PointLightAttenuation& GetAttenuationCoefficients() const { return mAttenuation; }
+    static PointLightAttenuation CaclAttenuationCoefficients(float radius);   // Scene.cpp:132-165 (step function, quirk Q18)
+protected:
+    Vector3 mTranslation, mColor;
+    float mRadius, mIntensity;
+    PointLightAttenuation mAttenuation;
+};
+
+// CubeMapResource stand-in: fp32 RGBA cube with mips + the SH pack computed at import time
+// (BasicStorage.cpp:201-209 -> SHBaker; here pbr_sh9_project on the GPU).
+struct SkyBox {
+    std::shared_ptr<DeviceTexture2DArray> Cube;
+    pbr_sh_pack SH{};
+    DeviceTexture2DArray* Resource() const { return Cube.get(); }
+    const pbr_sh_pack& GetSHCoefficients() const { return SH; }
+};
+
+// host copy of the G-buffer a frame starts from (the raster GBufferPass is out of scope)
+struct GBufferSource {
+    uint32 Width = 0, Height = 0;
+    std::vector<uint32_t> A, B, C;
+    std::vector<float> Depth;
+    std::vector<uint8_t> Stencil;
+};
+
+class Scene {
+public:
+    void AddLight(const SceneLight& l) { mLights.push_back(l); }
+    void ClearLights() { mLights.clear(); }
+    uint32 GetLightCount() const { return (uint32)mLights.size(); }
+    // Scene::CullLight(volume, fn): octree frustum cull in the reference (Scene.h:229-237).  The
+    // lights of the synthetic scenes are generated inside the frustum, so every light is visited.
+    template <class Fn>
+    void CullLight(Fn&& fn) { for (auto& l : mLights) fn(&l); }
+    void SetSkyBox(std::shared_ptr<SkyBox> s) { mSkyBox = std::move(s); }
+    SkyBox* GetSkyBox() const { return mSkyBox.get(); }
+    GBufferSource& GBuffer() { return mGBuffer; }
+private:
+    std::vector<SceneLight> mLights;
+    std::shared_ptr<SkyBox> mSkyBox;
+    GBufferSource mGBuffer;
+};
+
+class FrameGraph;
+class IRenderPipeline;
+
+class RenderScheduler {
+public:
+    RenderScheduler(IRenderPipeline* pipeline, int hip_device, uint32 width, uint32 height);
+    ~RenderScheduler();
+    // fills ConstantBufferGlobal, then FrameGraph::Execute (RenderScheduler.cpp:16-47)
+    HipCommandList* ExecutePipeline(Scene* scene, Camera* camera, float delta_time, float total_time);
+    FrameGraph* GetFrameGraph() const { return mFrameGraph.get(); }
+    HipCommandList* CommandList() const { return mCommandList.get(); }
+private:
+    std::unique_ptr<HipCommandList> mCommandList;
+    std::unique_ptr<FrameGraph> mFrameGraph;
+    uint32 mWidth, mHeight;
+};
+
+}  // namespace MRendererHip

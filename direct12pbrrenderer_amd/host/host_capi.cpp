@@ -1,0 +1,177 @@
+// host_capi.cpp — C embedding of the pass graph (see pbr_host.h).
+#include "pbr_host.h"
+
+#include <cstdio>
+#include <string>
+
+#include "DeferredPipeline.h"
+
+using namespace MRendererHip;
+
+struct pbrh_renderer {
+    std::unique_ptr<DeferredRenderPipeline> pipeline;
+    std::unique_ptr<RenderScheduler> scheduler;
+    std::unique_ptr<Scene> scene;
+    std::unique_ptr<Camera> camera;
+    uint32 width = 0, height = 0;
+    float time = 0.0f;
+    std::string err;
+};
+
+template <class Fn>
+static int guarded(pbrh_renderer* r, Fn&& fn) {
+    try {
+        fn();
+        return 0;
+    } catch (const std::exception& e) {
+        if (r) r->err = e.what();
+        return -1;
+    }
+}
+
+extern "C" {
+
+pbrh_renderer* pbrh_create(int device, uint32_t width, uint32_t height, uint32_t env_size, uint32_t lut_res, char* err, size_t err_len) {
+    auto* r = new pbrh_renderer();
+    try {
+        FGResourceDescriptionTable::Instance()->Reset();   // one pipeline per process in the reference; allow re-creation here
+        r->width = width;
+        r->height = height;
+        r->pipeline = std::make_unique<DeferredRenderPipeline>(RenderSize{width, height}, env_size, lut_res);
+        r->scheduler = std::make_unique<RenderScheduler>(r->pipeline.get(), device, width, height);
+        r->scene = std::make_unique<Scene>();
+        // App.cpp:99-101
+        r->camera = std::make_unique<Camera>(0.333f * 3.14159265359f, width, height, 0.1f, 1000.0f);
+        r->camera->Move(Vector3{0, 3, 10});
+        r->camera->Rotate(0, 3.14159265359f, 0);
+        return r;
+    } catch (const std::exception& e) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", e.what());
+        delete r;
+        return nullptr;
+    }
+}
+
+void pbrh_destroy(pbrh_renderer* r) { delete r; }
+const char* pbrh_last_error(const pbrh_renderer* r) { return r ? r->err.c_str() : "null renderer"; }
+
+int pbrh_set_skybox(pbrh_renderer* r, const float* cube, uint32_t size) {
+    return guarded(r, [&] {
+        uint32 mips = 1;
+        while ((size >> mips) >= 1) mips++;
+        auto sky = std::make_shared<SkyBox>();
+        sky->Cube = std::make_shared<DeviceTexture2DArray>(size, mips, ETextureFormat_R32G32B32A32_FLOAT);
+        ThrowIfFailed(hipMemcpy(sky->Cube->DevicePtr(), cube, (size_t)6 * size * size * 16, hipMemcpyHostToDevice), "upload sky");
+        pbr_ctx* ctx = r->scheduler->CommandList()->Context();
+        if (pbr_cube_gen_mips(ctx, (float*)sky->Cube->DevicePtr(), size, mips) != PBR_OK) throw HipException(pbr_last_error(ctx));
+        DeviceStructuredBuffer pack(112, 4);
+        pbr_cube_f32 c{(const float*)sky->Cube->DevicePtr(), size, mips};
+        if (pbr_sh9_project(ctx, &c, (float*)pack.DevicePtr()) != PBR_OK) throw HipException(pbr_last_error(ctx));
+        if (pbr_sync(ctx) != PBR_OK) throw HipException(pbr_last_error(ctx));
+        ThrowIfFailed(hipMemcpy(&sky->SH, pack.DevicePtr(), 112, hipMemcpyDeviceToHost), "read SH");
+        r->scene->SetSkyBox(sky);
+        r->pipeline->mPrefilterEnvMapPass->Invalidate();
+    });
+}
+
+int pbrh_set_lights(pbrh_renderer* r, const float* l, int n) {
+    return guarded(r, [&] {
+        r->scene->ClearLights();
+        for (int i = 0; i < n; i++, l += 8) r->scene->AddLight(SceneLight(Vector3{l[0], l[1], l[2]}, Vector3{l[3], l[4], l[5]}, l[6], l[7]));
+    });
+}
+
+int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, const uint32_t* C, const float* depth, const uint8_t* stencil) {
+    return guarded(r, [&] {
+        GBufferSource& g = r->scene->GBuffer();
+        const size_t n = (size_t)r->width * r->height;
+        g.Width = r->width;
+        g.Height = r->height;
+        g.A.assign(A, A + n);
+        g.B.assign(B, B + n);
+        g.C.assign(C, C + n);
+        g.Depth.assign(depth, depth + n);
+        g.Stencil.assign(stencil, stencil + n);
+    });
+}
+
+int pbrh_set_initial_luminance(pbrh_renderer* r, float v) {
+    return guarded(r, [&] { r->pipeline->mAutoExposurePass->SetInitialLuminance(v); });
+}
+
+int pbrh_render(pbrh_renderer* r, float dt) {
+    return guarded(r, [&] {
+        r->time += dt;
+        r->scheduler->ExecutePipeline(r->scene.get(), r->camera.get(), dt, r->time);
+    });
+}
+
+int pbrh_execution_order(pbrh_renderer* r, char* buf, size_t len) {
+    return guarded(r, [&] {
+        std::string s;
+        for (IRenderPass* p : r->scheduler->GetFrameGraph()->ExecutionOrder()) {
+            if (!s.empty()) s += ">";
+            s += p->Name();
+        }
+        std::snprintf(buf, len, "%s", s.c_str());
+    });
+}
+
+int pbrh_dispatch_count(const pbrh_renderer* r) { return r ? (int)r->scheduler->CommandList()->DispatchCount() : -1; }
+
+long pbrh_read(pbrh_renderer* r, const char* name, void* dst, size_t dst_bytes) {
+    long n = -1;
+    int st = guarded(r, [&] {
+        IDeviceResource* res = r->scheduler->GetFrameGraph()->FindResource(FGResourceIDs::Instance()->NameToID(name));
+        size_t bytes = std::min(dst_bytes, res->Bytes());
+        ThrowIfFailed(hipMemcpy(dst, res->DevicePtr(), bytes, hipMemcpyDeviceToHost), "read back");
+        n = (long)bytes;
+    });
+    return st ? -1 : n;
+}
+
+int pbrh_get_global(const pbrh_renderer* r, void* dst) {
+    if (!r || !dst) return -1;
+    std::memcpy(dst, &r->scheduler->CommandList()->GlobalConstant(), sizeof(pbr_global));
+    return 0;
+}
+
+int pbrh_dry_run_execution_order(uint32_t width, uint32_t height, char* buf, size_t len) {
+    try {
+        DeviceMemory::DryRun() = true;
+        FGResourceDescriptionTable::Instance()->Reset();
+        DeferredRenderPipeline pipeline(RenderSize{width, height});
+        FrameGraph graph(&pipeline);
+        graph.Setup();
+        graph.Compile();
+        std::string s;
+        for (IRenderPass* p : graph.ExecutionOrder()) {
+            if (!s.empty()) s += ">";
+            s += p->Name();
+        }
+        std::snprintf(buf, len, "%s", s.c_str());
+        DeviceMemory::DryRun() = false;
+        return 0;
+    } catch (const std::exception& e) {
+        DeviceMemory::DryRun() = false;
+        std::snprintf(buf, len, "error: %s", e.what());
+        return -1;
+    }
+}
+
+int pbrh_probe_binding(const char* shader_file, int is_compute, const char* name, int kind) {
+    try {
+        ShadingState s;
+        s.SetShader(shader_file, is_compute != 0);
+        switch (kind) {
+            case 0: return s.SetTexture(name, (DeviceTexture*)nullptr) ? 1 : 0;
+            case 1: return s.SetRWTexture(name, (DeviceTexture2D*)nullptr) ? 1 : 0;
+            case 2: return s.SetStructuredBuffer(name, nullptr) ? 1 : 0;
+            default: return s.SetRWStructuredBuffer(name, nullptr) ? 1 : 0;
+        }
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+}  // extern "C"

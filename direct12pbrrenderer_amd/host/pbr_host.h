@@ -1,0 +1,39 @@
+/* pbr_host.h — C entry points of libpbr_host.so: a small embedding of the C++ pass graph
+ * (DeferredRenderPipeline + FrameGraph + RenderScheduler over the HIP kernels) so that tests
+ * and tools can drive whole frames through the reference-shaped pass API. */
+#ifndef PBR_HOST_H
+#define PBR_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct pbrh_renderer pbrh_renderer;
+
+pbrh_renderer* pbrh_create(int hip_device, uint32_t width, uint32_t height, uint32_t env_size, uint32_t lut_res,
+                           char* err, size_t err_len);
+void pbrh_destroy(pbrh_renderer* r);
+const char* pbrh_last_error(const pbrh_renderer* r);
+/* fp32 RGBA cube mip 0 (host, 6*size*size*4 floats): uploaded, box mips + SH9 computed on the GPU */
+int pbrh_set_skybox(pbrh_renderer* r, const float* cube_mip0, uint32_t size);
+/* n lights: position[3], color[3], radius, intensity (8 floats each) */
+int pbrh_set_lights(pbrh_renderer* r, const float* lights, int n);
+int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, const uint32_t* C, const float* depth, const uint8_t* stencil);
+int pbrh_set_initial_luminance(pbrh_renderer* r, float v);
+/* one frame through RenderScheduler::ExecutePipeline; blocks until the GPU is done */
+int pbrh_render(pbrh_renderer* r, float delta_time);
+/* "PreFilterEnvMap>PrecomputeBRDF>..." */
+int pbrh_execution_order(pbrh_renderer* r, char* buf, size_t len);
+int pbrh_dispatch_count(const pbrh_renderer* r);
+/* copy a frame-graph resource (by its FGResourceIDs name) to host memory; returns bytes copied or <0 */
+long pbrh_read(pbrh_renderer* r, const char* resource_name, void* dst, size_t dst_bytes);
+/* the global constants the last frame used (412 bytes) */
+int pbrh_get_global(const pbrh_renderer* r, void* dst_412_bytes);
+/* builds DeferredRenderPipeline + FrameGraph without touching a GPU and returns the sorted pass order */
+int pbrh_dry_run_execution_order(uint32_t width, uint32_t height, char* buf, size_t len);
+/* ShadingState contract probes (no GPU work): 1 = the call returned true */
+int pbrh_probe_binding(const char* shader_file, int is_compute, const char* semantic_name, int kind);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -158,6 +158,10 @@ pbr_status pbr_cube_gen_mips(pbr_ctx* ctx, float* cube_data, uint32_t size, uint
  * out: half4 cube chain, layout as pbr_cube_f32 with edge `size`. */
 pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t size, uint32_t mips,
                              pbr_half* out_rgba);
+/* ONE dispatch of env_map_gen.hlsl: cbuffer {Roughness, MipLevel, PrefilterEnvMapTextureSize}
+ * (DeferredPipeline.h:46-51).  out_mip_rgba: the 6 x (size>>mip_level)^2 half4 texels of that mip. */
+pbr_status pbr_prefilter_env_mip(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t size, uint32_t mip_level,
+                                 float roughness, pbr_half* out_mip_rgba);
 
 /* SHBaker::ProjectEnvironmentMap + PackCubeMapSHCoefficient (Engine/Source/Utils/SH.cpp:87-153,
  * 201-222) as a deterministic solid-angle quadrature over every mip-0 texel.

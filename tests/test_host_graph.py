@@ -1,0 +1,149 @@
+"""The C++ host pass graph (direct12pbrrenderer_amd/host): IRenderPass / ShadingState / FrameGraph
+look-alikes of Engine/ that dispatch the HIP kernels through the C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import common
+from direct12pbrrenderer_amd import synth
+from direct12pbrrenderer_amd.structs import Global, bloom_chain_texels
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_LIB = os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_host.so")
+
+# the order FGExecutionParser::Parse (FrameGraph.cpp:191-250) derives
+REFERENCE_ORDER = "PreFilterEnvMap>PrecomputeBRDF>Clustered>GBuffer>Skybox>DeferredShading>Bloom>AutoExposure>ToneMapping>Present"
+
+
+@pytest.fixture(scope="module")
+def host():
+    assert os.path.exists(HOST_LIB), "build with make -C direct12pbrrenderer_amd/host"
+    L = C.CDLL(HOST_LIB)
+    L.pbrh_create.restype = C.c_void_p
+    L.pbrh_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.pbrh_destroy.argtypes = [C.c_void_p]
+    L.pbrh_last_error.restype = C.c_char_p
+    L.pbrh_last_error.argtypes = [C.c_void_p]
+    L.pbrh_set_skybox.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.pbrh_set_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.pbrh_set_gbuffer.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.pbrh_set_initial_luminance.argtypes = [C.c_void_p, C.c_float]
+    L.pbrh_render.argtypes = [C.c_void_p, C.c_float]
+    L.pbrh_execution_order.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.pbrh_dispatch_count.argtypes = [C.c_void_p]
+    L.pbrh_read.restype = C.c_long
+    L.pbrh_read.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    L.pbrh_get_global.argtypes = [C.c_void_p, C.c_void_p]
+    L.pbrh_probe_binding.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.pbrh_dry_run_execution_order.argtypes = [C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+    return L
+
+
+def test_execution_order_matches_reference_graph(host):
+    buf = C.create_string_buffer(512)
+    for w, h in ((1440, 960), (3840, 2160), (7680, 4320)):
+        assert host.pbrh_dry_run_execution_order(w, h, buf, 512) == 0, buf.value
+        assert buf.value.decode() == REFERENCE_ORDER
+    # BloomPass asserts BloomStep < max mip levels (DeferredPipeline.cpp:343): 8x8 cannot hold 5 mips
+    assert host.pbrh_dry_run_execution_order(8, 8, buf, 512) == -1 and b"too small" in buf.value
+    # TextureFormatKey stores 16-bit extents (quirk Q24)
+    assert host.pbrh_dry_run_execution_order(70000, 64, buf, 512) == -1 and b"65535" in buf.value
+
+
+def test_shading_state_binding_contract(host):
+    # known name -> true; unknown name -> false + log (IPipeline.cpp:188-199); unknown shader file -> throws
+    T, RWT, SB, RWSB = 0, 1, 2, 3
+    assert host.pbrh_probe_binding(b"deferred_shading.hlsl", 0, b"GBufferA", T) == 1
+    assert host.pbrh_probe_binding(b"deferred_shading.hlsl", 0, b"Clusters", SB) == 1
+    assert host.pbrh_probe_binding(b"deferred_shading.hlsl", 0, b"GBufferZ", T) == 0
+    assert host.pbrh_probe_binding(b"deferred_shading.hlsl", 0, b"GBufferA", RWT) == 0      # SRV, not UAV
+    assert host.pbrh_probe_binding(b"bloom_upsample_add.hlsl", 1, b"LowerLevel", T) == 1
+    assert host.pbrh_probe_binding(b"hdr_average_histogram.hlsl", 1, b"AverageLuminance", RWSB) == 1
+    assert host.pbrh_probe_binding(b"clustered_culling.hlsl", 1, b"PointLights", RWSB) == 1
+    assert host.pbrh_probe_binding(b"no_such_shader.hlsl", 1, b"x", T) == -1
+    assert host.pbrh_probe_binding(b"blur_vertical.hlsl", 0, b"InputTexture", T) == -1        # compute shader bound as graphics
+
+
+@pytest.mark.gpu
+def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
+    """Two frames through RenderScheduler/FrameGraph vs the same passes issued from Python
+    (bit-identical: both are the same C-ABI calls) and vs the oracle (parity tolerances)."""
+    import torch
+    from direct12pbrrenderer_amd import scene
+    from direct12pbrrenderer_amd.pipeline import DeferredFrame, TileSpec
+    W, H, ENV, LUT = 320, 192, 32, 64
+    err = C.create_string_buffer(256)
+    r = host.pbrh_create(0, W, H, ENV, LUT, err, 256)
+    assert r, err.value
+    try:
+        sky_np = synth.env_cube(ENV)
+        n0 = 4 * 6 * ENV * ENV
+        assert host.pbrh_set_skybox(r, sky_np[:n0].ctypes.data, ENV) == 0, host.pbrh_last_error(r)
+        cam = scene.Camera.reference_default(W, H)
+        lights = synth.lights_in_view_box(256, cam)
+        packed = np.concatenate([lights["Position"], lights["Color"], np.full((256, 1), 2.0, np.float32), lights["Intensity"][:, None]], axis=1).astype(np.float32)
+        assert host.pbrh_set_lights(r, np.ascontiguousarray(packed).ctypes.data, 256) == 0
+        gb = synth.gbuffer_tile(0, 0, W, H, W, H, coverage_mask=True)
+        assert host.pbrh_set_gbuffer(r, *[np.ascontiguousarray(gb[k]).ctypes.data for k in ("A", "B", "C", "depth", "stencil")]) == 0
+        assert host.pbrh_set_initial_luminance(r, 0.18) == 0
+        assert host.pbrh_render(r, 1.0 / 60.0) == 0, host.pbrh_last_error(r)
+        assert host.pbrh_dispatch_count(r) == 5 + 1 + 2 + 1 + 16 + 2 + 1      # first frame incl. one-shot IBL
+        buf = C.create_string_buffer(512)
+        assert host.pbrh_execution_order(r, buf, 512) == 0 and buf.value.decode() == REFERENCE_ORDER
+
+        def read(name, shape, dtype):
+            a = np.zeros(shape, dtype=dtype)
+            n = host.pbrh_read(r, name.encode(), a.ctypes.data, a.nbytes)
+            assert n == a.nbytes, (name, n, host.pbrh_last_error(r))
+            return a
+        hdr1 = read("DeferredShadingRT", (H, W, 4), np.float16)
+        ldr1 = read("ToneMappedTexture", (H, W), np.uint32)
+        avg1 = read("AverageLuminance", (1,), np.float32)[0]
+        g_host = Global()
+        assert host.pbrh_get_global(r, C.byref(g_host)) == 0
+
+        # --- the same frame issued from Python through the same C ABI
+        sky_mips = int(np.log2(ENV)) + 1
+        sky = ctx.upload(sky_np)
+        ctx.cube_gen_mips(sky, ENV, sky_mips)
+        lut = ctx.brdf_lut(LUT)
+        env = ctx.prefilter_env(sky, ENV, sky_mips, ENV, 5)
+        sh = ctx.sh9_project(sky, ENV, sky_mips).cpu().numpy()
+        g = scene.make_global(cam, W, H, sh_pack=sh, delta_time=1.0 / 60.0, time=1.0 / 60.0)
+        for f in ("InvView", "View", "Projection", "CameraPos"):      # C++ Camera == Python Camera
+            assert np.allclose(np.array(getattr(g_host, f)[:]), np.array(getattr(g, f)[:]), rtol=1e-6, atol=1e-7), f
+        assert bytes(g_host.SkyBoxSH) == bytes(g.SkyBoxSH)
+        fr = DeferredFrame(ctx, TileSpec(0, 0, W, H, W, H, 0), g_host, lights, lut, LUT, env, ENV, 5)
+        fr.upload_gbuffer(gb)
+        fr.set_prev_luminance(0.18)
+        fr.render()
+        hdr_py = fr.hdr.cpu().view(torch.int16).numpy().view(np.float16)
+        on = gb["stencil"] > 0
+        assert np.array_equal(hdr1[on].view(np.uint16), hdr_py[on].view(np.uint16))
+        assert np.array_equal(ldr1[on], fr.ldr_numpy()[on])
+        assert avg1 == fr.avg.cpu().numpy()[0]
+
+        # --- second frame: one-shot passes latched (mReady), 22 dispatches, exposure keeps adapting
+        assert host.pbrh_render(r, 1.0 / 60.0) == 0
+        assert host.pbrh_dispatch_count(r) == 22
+        avg2 = read("AverageLuminance", (1,), np.float32)[0]
+        fr.render()
+        assert avg2 == fr.avg.cpu().numpy()[0] and avg2 != avg1
+
+        # --- oracle parity of the first frame's HDR (shade + bloom), IBL inputs taken from the GPU
+        lut_np = lut.cpu().view(torch.int16).numpy().view(np.float16)
+        env_np = env.cpu().view(torch.int16).numpy().view(np.float16)
+        cl = orc.cluster_build(g_host)
+        orc.cluster_cull(g_host, lights, cl)
+        from direct12pbrrenderer_amd.structs import Tile
+        want, _ = orc.deferred_shade(g_host, Tile(0, 0, W, H, W, H), gb, lut_np, env_np, ENV, 5, cl, lights)
+        orc.bloom(want)
+        scale = np.abs(want.astype(np.float32)[on][:, :3]).max()
+        d = common.half_ulp_diff(hdr1[on][:, :3], want[on][:, :3])
+        assert (d > 2).mean() <= 2e-3 and d.max() <= 64, (d.max(), (d > 2).mean())
+        assert np.abs(hdr1.astype(np.float32) - want.astype(np.float32))[on][:, :3].max() <= 5e-3 * scale
+        assert bloom_chain_texels(W, H) == 320 * 192 + 160 * 96 + 80 * 48 + 40 * 24 + 20 * 12
+    finally:
+        host.pbrh_destroy(r)
