@@ -142,7 +142,7 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
         orc.bloom(want)
         scale = np.abs(want.astype(np.float32)[on][:, :3]).max()
         d = common.half_ulp_diff(hdr1[on][:, :3], want[on][:, :3])
-        assert (d > 2).mean() <= 2e-3 and d.max() <= 64, (d.max(), (d > 2).mean())
+        assert (d > 2).mean() <= 1e-3, (d.max(), (d > 2).mean())   # rare slice/threshold flips move a single pixel
         assert np.abs(hdr1.astype(np.float32) - want.astype(np.float32))[on][:, :3].max() <= 5e-3 * scale
         assert bloom_chain_texels(W, H) == 320 * 192 + 160 * 96 + 80 * 48 + 40 * 24 + 20 * 12
     finally:
