@@ -9,7 +9,7 @@ import os
 from .structs import CubeF32, GBuffer, Global, Tile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbr_hip.so")
+LIB_PATH = os.environ.get("PBR_HIP_LIB", os.path.join(_HERE, "libpbr_hip.so"))   # override = experiments only
 
 _u32, _f32, _int, _vp, _sz = C.c_uint32, C.c_float, C.c_int, C.c_void_p, C.c_size_t
 
@@ -18,6 +18,8 @@ SIGNATURES = {
     "pbr_version": (C.c_char_p, []),
     "pbr_cube_texels": (_sz, [_u32, _u32]),
     "pbr_cube_mip_offset": (_sz, [_u32, _u32]),
+    "pbr_env_padded_texels": (_sz, [_u32, _u32]),
+    "pbr_env_padded_mip_offset": (_sz, [_u32, _u32]),
     "pbr_bloom_chain_texels": (_sz, [_u32, _u32]),
     "pbr_bloom_level_offset": (_sz, [_u32, _u32, _u32]),
     "pbr_ctx_create": (_int, [_int, C.POINTER(_vp)]),
@@ -30,6 +32,7 @@ SIGNATURES = {
     "pbr_cube_gen_mips": (_int, [_vp, _vp, _u32, _u32]),
     "pbr_prefilter_env": (_int, [_vp, C.POINTER(CubeF32), _u32, _u32, _vp]),
     "pbr_prefilter_env_mip": (_int, [_vp, C.POINTER(CubeF32), _u32, _u32, _f32, _vp]),
+    "pbr_env_pad": (_int, [_vp, _vp, _u32, _u32, _vp]),
     "pbr_sh9_project": (_int, [_vp, C.POINTER(CubeF32), _vp]),
     "pbr_cluster_build": (_int, [_vp, C.POINTER(Global), _vp]),
     "pbr_cluster_cull": (_int, [_vp, C.POINTER(Global), _vp, _int, _vp]),

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from .structs import (BLOOM_KNEE, BLOOM_THRESHOLD, CLUSTER_DTYPE, ENV_MIPS, HISTOGRAM_BINS,
                       INV_LOG_LUMINANCE_RANGE, LIGHT_DTYPE, LOG_LUMINANCE_RANGE, MIN_LOG_LUMINANCE,
-                      NUM_CLUSTERS, CubeF32, GBuffer, Global, Tile, bloom_chain_texels, cube_texels)
+                      NUM_CLUSTERS, CubeF32, GBuffer, Global, Tile, bloom_chain_texels, cube_texels, env_padded_texels)
 
 
 class PbrError(RuntimeError):
@@ -104,6 +104,12 @@ class PbrContext:
         self._check(self.lib.pbr_prefilter_env(self.h, C.byref(c), size, mips, _ptr(out)))
         return out
 
+    def env_pad(self, env, size, mips=ENV_MIPS, out=None):
+        """Padded copy of a prefiltered env chain — the layout deferred_shade samples (one-shot)."""
+        out = out if out is not None else self.empty((env_padded_texels(size, mips), 4), torch.float16)
+        self._check(self.lib.pbr_env_pad(self.h, _ptr(env), size, mips, _ptr(out)))
+        return out
+
     def sh9_project(self, sky, sky_size, sky_mips=1, out=None):
         out = out if out is not None else self.empty((28,), torch.float32)
         c = CubeF32(sky.data_ptr(), sky_size, sky_mips)
@@ -122,7 +128,7 @@ class PbrContext:
 
     def deferred_shade(self, g: Global, tile: Tile, gb, pitch, lut, lut_res, env, env_size, env_mips,
                        clusters, lights, num_lights, hdr, hdr_pitch):
-        """gb: dict with device tensors A,B,C,depth,stencil."""
+        """gb: dict with device tensors A,B,C,depth,stencil; env: the PADDED chain from env_pad()."""
         s = GBuffer(gb["A"].data_ptr(), gb["B"].data_ptr(), gb["C"].data_ptr(), gb["depth"].data_ptr(),
                     gb["stencil"].data_ptr(), pitch)
         self._check(self.lib.pbr_deferred_shade(self.h, C.byref(g), C.byref(tile), C.byref(s), _ptr(lut), lut_res,

@@ -10,6 +10,8 @@ const char* pbr_version(void) { return "pbr_hip 0.1 (gfx950)"; }
 
 size_t pbr_cube_texels(uint32_t size, uint32_t mips) { return pbr::cube_mip_offset(size, mips); }
 size_t pbr_cube_mip_offset(uint32_t size, uint32_t mip) { return pbr::cube_mip_offset(size, mip); }
+size_t pbr_env_padded_mip_offset(uint32_t size, uint32_t mip) { return pbr::env_padded_mip_offset(size, mip); }
+size_t pbr_env_padded_texels(uint32_t size, uint32_t mips) { return pbr::env_padded_mip_offset(size, mips); }
 size_t pbr_bloom_level_offset(uint32_t w, uint32_t h, uint32_t level) {
     size_t off = 0;
     for (uint32_t l = 0; l < level; l++) off += (size_t)(w >> l) * (h >> l);

@@ -122,6 +122,12 @@ __host__ __device__ __forceinline__ size_t cube_mip_offset(uint32_t size, uint32
     return off;
 }
 
+__host__ __device__ __forceinline__ size_t env_padded_mip_offset(uint32_t size, uint32_t mip) {
+    size_t off = 0;
+    for (uint32_t m = 0; m < mip; m++) { size_t s = (size >> m) + 2; off += 6 * s * s; }
+    return off;
+}
+
 // Seamless edge rule (same definition as the oracle): a tap outside the face is re-projected
 // onto the neighbouring face through the direction of its texel centre; a tap that leaves the
 // face in both axes is clamped in y first.

@@ -1,11 +1,18 @@
 // shade.hip — deferred Cook-Torrance shade of a G-buffer tile (deferred_shading.hlsl:91-192).
 //
 // Replaces the stencil-masked full-screen draw of DeferredShadingPass::Execute
-// (DeferredPipeline.cpp:187-206).  One lane per pixel, a wave = 64 consecutive pixels of a row,
-// so every G-buffer plane is read as one 256-byte (RGBA8 / depth) or 64-byte (stencil)
-// coalesced segment per wave and the half4 output is one 512-byte store.  The light table is
-// staged into LDS once per block (48-byte records, float4-aligned) so the per-light fetch in
-// the divergent cluster loop is three ds_read_b128 instead of eleven scattered global loads.
+// (DeferredPipeline.cpp:187-206).  MI355X mapping:
+//  * one lane per pixel, a wave = 64 consecutive pixels of a row: every G-buffer plane is read as
+//    one 256-byte (RGBA8 / depth) or 64-byte (stencil) coalesced segment per wave, the half4 output
+//    is one 512-byte store; a block walks SHADE_ROWS rows after staging its tables once;
+//  * the light table is staged in LDS (48-byte records, three ds_read_b128-class reads per light);
+//  * the light lists of the clusters the block can touch are staged in LDS as u16 indices, so the
+//    divergent per-lane list walk is an LDS read, not a global gather (blocks that span too many
+//    cluster tiles — tiny render targets — fall back to the global list);
+//  * IBL gathers (prefiltered env + LUT) are issued BEFORE the light loop and filtered after it,
+//    so their L2/MALL latency hides under ~2 000 VALU instructions; the env chain is sampled from
+//    its padded layout (pbr_env_pad): no seam branches, each bilinear row is one 16-byte load;
+//  * with 256 lights the kernel is FP32-VALU-bound (~60 VALU per pixel-light), not HBM-bound.
 #include "pbr_internal.hpp"
 #include "pbr_device.hpp"
 
@@ -15,7 +22,9 @@ struct ShadeParams {
     pbr_sh_pack sh;
     float InvView[9];      // 3x3 part, row-major
     float CameraPos[3];
-    float Near, Far, Fov, Ratio;
+    float Near, Far;
+    float near_width, near_height;   // 2 Near tan(Fov/2) [* Ratio]  (vs_main :94-95), host libm
+    float log_far_near;              // log(Far/Near) of ClusterIndex (clustered.hlsli:53), host libm
     uint32_t x0, y0, w, h, full_w, full_h;
     const uint32_t* A;
     const uint32_t* B;
@@ -25,7 +34,7 @@ struct ShadeParams {
     uint32_t pitch;
     const pbr_half* lut;
     uint32_t lut_res;
-    const pbr_half* env;
+    const pbr_half* env;   // padded layout
     uint32_t env_size, env_mips;
     const pbr_cluster* clusters;
     const pbr_light* lights;
@@ -47,16 +56,49 @@ __device__ __forceinline__ V3 decode_octahedron(float u, float v) {
     return d;
 }
 
-// LDS light record: 12 floats
-struct LightLds { float4 pos_int; float4 col_c0; float4 c1c2; };
+// ------------------------------------------------------------------------------------------------
+// Padded env chain: face f of mip m is (s+2) x (s+2); padded texel (xp,yp) holds the texel the
+// seamless-cube rule selects for tap (xp-1, yp-1) — interior texels are themselves.
+__global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ src, pbr_half* __restrict__ dst, int s) {
+    const int sp = s + 2;
+    const size_t n = (size_t)6 * sp * sp;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int xp = (int)(t % sp), yp = (int)((t / sp) % sp);
+    uint32_t face = (uint32_t)(t / ((size_t)sp * sp));
+    int x = xp - 1, y = yp - 1;
+    const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
+    if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
+        if (xo & yo) y = clampi(y, 0, s - 1);
+        const float uu = 2.0f * ((float)x + 0.5f) / (float)s - 1.0f;
+        const float vv = 2.0f * ((float)y + 0.5f) / (float)s - 1.0f;
+        float u2, v2;
+        cube_face_uv(cube_dir_raw(face, uu, vv), face, u2, v2);
+        x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
+        y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
+    }
+    reinterpret_cast<H4*>(dst)[t] = reinterpret_cast<const H4*>(src)[((size_t)face * s + y) * s + x];
+}
+
+// LDS light record (48 B, float4-aligned)
+struct LightLds {
+    float4 pos_c0;   // position.xyz, C0
+    float4 col_c1;   // color.rgb * intensity, C1
+    float4 c2;       // C2, -, -, -
+};
 
 constexpr int SHADE_BLOCK = 256;
+constexpr int SHADE_ROWS = 8;          // rows of 256 pixels one block walks after staging its tables
+constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per block
+// staged list: count, pad, 32 u16 indices = 34 halfwords (68 B) per cluster
+constexpr int LIST_STRIDE_U16 = 34;
 
-// rows of 256 pixels one block walks after staging the light table once
-constexpr int SHADE_ROWS = 8;
+struct alignas(8) H4x2 { H4 a, b; };   // two x-adjacent half4 texels (16 bytes, 8-byte aligned)
+struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-byte aligned)
 
-__device__ __forceinline__ void shade_pixel(const ShadeParams& p, const LightLds* llds, int n_lights,
-                                            uint32_t px, uint32_t py) {
+template <bool STAGED_LISTS>
+__device__ __forceinline__ void shade_pixel(const ShadeParams& p, const LightLds* llds, const uint16_t* lists,
+                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, uint32_t px, uint32_t py) {
     const size_t gi = (size_t)py * p.pitch + px;
     if (p.stencil[gi] == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
 
@@ -67,20 +109,17 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const LightLds
     const float u = ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
     const float v = ((float)(p.y0 + py) + 0.5f) / (float)p.full_h;
     const float ndc_x = 2.0f * u - 1.0f, ndc_y = 1.0f - 2.0f * v;
-    const float near_height = 2.0f * p.Near * tanf(p.Fov / 2.0f);
-    const float near_width = near_height * p.Ratio;
-    const V3 cvv = v3(ndc_x * 0.5f * near_width, ndc_y * 0.5f * near_height, p.Near);
+    const V3 cvv = v3(ndc_x * 0.5f * p.near_width, ndc_y * 0.5f * p.near_height, p.Near);
     const V3 camera_vec = v3(p.InvView[0] * cvv.x + p.InvView[1] * cvv.y + p.InvView[2] * cvv.z,
                              p.InvView[3] * cvv.x + p.InvView[4] * cvv.y + p.InvView[5] * cvv.z,
                              p.InvView[6] * cvv.x + p.InvView[7] * cvv.y + p.InvView[8] * cvv.z);
 
-    const float inv255 = 1.0f / 255.0f;
-    const V3 albedo = v3((float)(a & 255u) / 255.0f, (float)((a >> 8) & 255u) / 255.0f, (float)((a >> 16) & 255u) / 255.0f);
-    const float emission = (float)(a >> 24) / 255.0f;
-    const float roughness = (float)(c & 255u) / 255.0f;
-    const float metallic = (float)((c >> 8) & 255u) / 255.0f;
-    (void)inv255;
-    const V3 n = normalize3(decode_octahedron((float)(b & 255u) / 255.0f, (float)((b >> 8) & 255u) / 255.0f));
+    const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
+    const V3 albedo = v3((float)(a & 255u) * inv255, (float)((a >> 8) & 255u) * inv255, (float)((a >> 16) & 255u) * inv255);
+    const float emission = (float)(a >> 24) * inv255;
+    const float roughness = (float)(c & 255u) * inv255;
+    const float metallic = (float)((c >> 8) & 255u) * inv255;
+    const V3 n = normalize3(decode_octahedron((float)(b & 255u) * inv255, (float)((b >> 8) & 255u) * inv255));
 
     // ViewSpaceDepth :74-77, ReconstructWorldPosition :79-83
     const float z_vs = p.Near * p.Far / (p.Far - depth_ndc * (p.Far - p.Near));
@@ -88,6 +127,63 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const LightLds
     const float zs = z_vs / p.Near;
     const V3 pos = v3(cam.x + camera_vec.x * zs, cam.y + camera_vec.y * zs, cam.z + camera_vec.z * zs);
     const V3 view = normalize3(cam - pos);
+
+    const V3 F0 = v3(0.04f + metallic * (albedo.x - 0.04f), 0.04f + metallic * (albedo.y - 0.04f), 0.04f + metallic * (albedo.z - 0.04f));
+    const float NdV = dot3(n, view);
+    const float NdotV = fmaxf(NdV, 0.0f);
+
+    // ---- EnvironmentSpecular :56-70, part 1: addresses + loads (filtered after the light loop)
+    H4x2 e00, e01, e10, e11;   // mip l0 rows y0,y1 ; mip l1 rows y0,y1
+    H2x2 lt0, lt1;
+    float env_f, e0fx, e0fy, e1fx, e1fy, lfx, lfy;
+    bool lsel0, lsel1;
+    {
+        const V3 R = normalize3(n * (2.0f * NdV) - view);
+        float lod = roughness * (float)PBR_ENV_MIPS;   // Q4: roughness*5 on a 5-mip chain
+        lod = fminf(fmaxf(lod, 0.0f), (float)(p.env_mips - 1));
+        const float fl = floorf(lod);
+        const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1, p.env_mips - 1);
+        env_f = lod - fl;
+        uint32_t face;
+        float cu, cv;
+        cube_face_uv(R, face, cu, cv);
+        {
+            const int s = (int)(p.env_size >> l0), sp = s + 2;
+            const BilinearCoord cx = bilinear_coord(cu, s), cy = bilinear_coord(cv, s);
+            const H4* m = reinterpret_cast<const H4*>(p.env) + env_padded_mip_offset(p.env_size, l0);
+            const size_t o = ((size_t)face * sp + (size_t)(cy.i0 + 1)) * sp + (size_t)(cx.i0 + 1);
+            e00 = *reinterpret_cast<const H4x2*>(m + o);
+            e01 = *reinterpret_cast<const H4x2*>(m + o + sp);
+            e0fx = cx.f; e0fy = cy.f;
+        }
+        {
+            const int s = (int)(p.env_size >> l1), sp = s + 2;
+            const BilinearCoord cx = bilinear_coord(cu, s), cy = bilinear_coord(cv, s);
+            const H4* m = reinterpret_cast<const H4*>(p.env) + env_padded_mip_offset(p.env_size, l1);
+            const size_t o = ((size_t)face * sp + (size_t)(cy.i0 + 1)) * sp + (size_t)(cx.i0 + 1);
+            e10 = *reinterpret_cast<const H4x2*>(m + o);
+            e11 = *reinterpret_cast<const H4x2*>(m + o + sp);
+            e1fx = cx.f; e1fy = cy.f;
+        }
+        // LUT bilinear with clamp addressing (Q5): one 8-byte pair per row; at the borders both taps
+        // are the same texel, picked out of the pair that stays inside the row
+        const int lr = (int)p.lut_res;
+        const BilinearCoord cx = bilinear_coord(roughness, lr), cy = bilinear_coord(NdotV, lr);
+        const int x0 = clampi(cx.i0, 0, lr - 1), x1 = clampi(cx.i1, 0, lr - 1);
+        const int y0 = clampi(cy.i0, 0, lr - 1), y1 = clampi(cy.i1, 0, lr - 1);
+        const int xb = lr > 1 ? min(x0, lr - 2) : 0;
+        lsel0 = x0 != xb;   // tap0 is the pair's second texel
+        lsel1 = x1 != xb;
+        const H2* lut = reinterpret_cast<const H2*>(p.lut);
+        if (lr > 1) {
+            lt0 = *reinterpret_cast<const H2x2*>(lut + (size_t)y0 * lr + xb);
+            lt1 = *reinterpret_cast<const H2x2*>(lut + (size_t)y1 * lr + xb);
+        } else {
+            lt0.a = lt0.b = lut[0];
+            lt1 = lt0;
+        }
+        lfx = cx.f; lfy = cy.f;
+    }
 
     // ---- EnvironmentDiffuse :23-54
     V3 out;
@@ -105,84 +201,106 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const LightLds
         out = v3(albedo.x * kd * ir, albedo.y * kd * ig, albedo.z * kd * ib);
     }
 
-    // ---- EnvironmentSpecular :56-70
-    const V3 F0 = v3(0.04f + metallic * (albedo.x - 0.04f), 0.04f + metallic * (albedo.y - 0.04f), 0.04f + metallic * (albedo.z - 0.04f));
-    const float NdV = dot3(n, view);
-    const float NdotV = fmaxf(NdV, 0.0f);
-    {
-        const V3 R = normalize3(n * (2.0f * NdV) - view);
-        const F4 envc = cube_trilinear<CubeTexelF16>(p.env, p.env_size, p.env_mips, R, roughness * (float)PBR_ENV_MIPS);   // Q4
-        const int lr = (int)p.lut_res;
-        const BilinearCoord cx = bilinear_coord(roughness, lr), cy = bilinear_coord(NdotV, lr);   // Q5
-        const int x0 = clampi(cx.i0, 0, lr - 1), x1 = clampi(cx.i1, 0, lr - 1);
-        const int y0 = clampi(cy.i0, 0, lr - 1), y1 = clampi(cy.i1, 0, lr - 1);
-        const H2* lut = reinterpret_cast<const H2*>(p.lut);
-        const H2 l00 = lut[(size_t)y0 * lr + x0], l10 = lut[(size_t)y0 * lr + x1];
-        const H2 l01 = lut[(size_t)y1 * lr + x0], l11 = lut[(size_t)y1 * lr + x1];
-        const float wx0 = 1.0f - cx.f, wy0 = 1.0f - cy.f;
-        const float la = ((float)l00.x * wx0 + (float)l10.x * cx.f) * wy0 + ((float)l01.x * wx0 + (float)l11.x * cx.f) * cy.f;
-        const float lb = ((float)l00.y * wx0 + (float)l10.y * cx.f) * wy0 + ((float)l01.y * wx0 + (float)l11.y * cx.f) * cy.f;
-        out.x += envc.x * (F0.x * la + lb);
-        out.y += envc.y * (F0.y * la + lb);
-        out.z += envc.z * (F0.z * la + lb);
-    }
+    // ---- clustered point lights :159-186.  ClusterIndex(uv, z), clustered.hlsli:45-60;
+    // logf (not the fast intrinsic): the result is truncated to the slice index.
+    int sx = (int)floorf(u * (float)PBR_CLUSTER_X);
+    int sy = (int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y);
+    const float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
+    int sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
+    sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
+    sy = clampi(sy, 0, PBR_CLUSTER_Y - 1);
+    sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
 
-    // ---- clustered point lights :159-186
-    int ci;
-    {
-        // ClusterIndex(uv, z), clustered.hlsli:45-60.  logf (not the fast intrinsic): the result is truncated.
-        int sx = (int)floorf(u * (float)PBR_CLUSTER_X);
-        int sy = (int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y);
-        float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
-        int sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / logf(p.Far / p.Near));
-        sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
-        sy = clampi(sy, 0, PBR_CLUSTER_Y - 1);
-        sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
-        ci = sz + sx * PBR_CLUSTER_Z + sy * PBR_CLUSTER_X * PBR_CLUSTER_Z;
-    }
-    const pbr_cluster* cl = p.clusters + ci;
-    const int nl = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-
-    // loop invariants of brdf() (brdf.hlsli:47-67)
+    // Per-pixel invariants of brdf() (brdf.hlsli:47-67).  With Kd = (1-F)(1-m), F = F0 + (1-F0) f5:
+    //   Kd*albedo/pi = [(1-F0)(1-m) albedo/pi] * (1 - f5)                      -> Kdiff * (1 - f5)
+    //   F*D*G/max(4 NdotL NdotV,1e-4) = F * [a^4/pi * gV] * NdotL / (T * A * B)  with
+    //   T = max(t^2, 1e-6/pi), A = NdotL(1-k)+k (>= 1/8, the shader's max(.,1e-6) never binds), B = max(4 NdotL NdotV, 1e-4)
+    // so one v_rcp serves D, G and the 4 NdotL NdotV denominator, and one serves the attenuation.
     const float ra = roughness * roughness;
     const float a4 = ra * ra;
     const float a4m1 = a4 - 1.0f;
-    const float k = (roughness + 1.0f) * (roughness + 1.0f) / 8.0f;
+    const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
     const float one_k = 1.0f - k;
     const float gv = NdotV / fmaxf(NdotV * one_k + k, EPSILON_F);
+    const float spec_pix = a4 * INV_PI_F * gv;
+    const float ndv4 = 4.0f * NdotV;
     const float one_m = 1.0f - metallic;
     const V3 omF0 = v3(1.0f - F0.x, 1.0f - F0.y, 1.0f - F0.z);
+    const V3 Kdiff = v3(omF0.x * one_m * albedo.x * INV_PI_F, omF0.y * one_m * albedo.y * INV_PI_F, omF0.z * one_m * albedo.z * INV_PI_F);
+    const float t_floor = EPSILON_F * INV_PI_F;
     V3 pl = v3(0.0f, 0.0f, 0.0f);
-    for (int i = 0; i < nl; i++) {
-        const int li = min(max(cl->LightIndex[i], 0), n_lights - 1);   // never index past the staged table
+
+    auto light = [&](int li) {
+        li = min(li, n_lights - 1);   // never index past the staged table
         const LightLds& r = llds[li];
-        const float4 q0 = r.pos_int, q1 = r.col_c0, q2 = r.c1c2;
-        const V3 lp = v3(q0.x, q0.y, q0.z), lc = v3(q1.x, q1.y, q1.z);
-        const float intensity = q0.w, c0 = q1.w, c1 = q2.x, c2 = q2.y;
-        V3 dir = lp - pos;
+        const float4 q0 = r.pos_c0, q1 = r.col_c1;
+        const float c2 = r.c2.x;
+        const V3 dir = v3(q0.x - pos.x, q0.y - pos.y, q0.z - pos.z);
         const float d2 = dot3(dir, dir);
         const float invd = rsq(d2);
         const float dist = d2 * invd;
-        dir = dir * invd;
-        const float NdotL = fmaxf(dot3(n, dir), 0.0f);
-        const V3 H = normalize3(dir + view);
-        const float NdotH = fmaxf(dot3(n, H), 0.0f);
-        // fresnel on NdotL (Q3)
-        const float fm = fmaxf(1.0f - NdotL, EPSILON_F);
+        const float NdL = dot3(n, dir) * invd;
+        const float NdotL = fmaxf(NdL, 0.0f);
+        const float LdV = dot3(dir, view) * invd;
+        // |L + V|^2 = 2 + 2 L.V ; N.H = (N.L + N.V) / |L + V|
+        const float NdotH = fmaxf((NdL + NdV) * rsq(fmaxf(2.0f + 2.0f * LdV, 1e-12f)), 0.0f);
+        const float t = (NdotH * NdotH) * a4m1 + 1.0f;
+        const float T = fmaxf(t * t, t_floor);
+        const float A = NdotL * one_k + k;
+        const float B = fmaxf(ndv4 * NdotL, 0.0001f);
+        const float spec = spec_pix * NdotL * rcp(T * A * B);
+        const float Q = fmaxf(q0.w + q1.w * dist + c2 * d2, EPSILON_F);
+        const float X = NdotL * rcp(Q);   // attenuation * NdotL
+        const float fm = fmaxf(1.0f - NdotL, EPSILON_F);   // fresnel on NdotL (Q3)
         const float fm2 = fm * fm;
         const float f5 = fm2 * fm2 * fm;
-        const V3 F = v3(F0.x + omF0.x * f5, F0.y + omF0.y * f5, F0.z + omF0.z * f5);
-        const float t = (NdotH * NdotH) * a4m1 + 1.0f;
-        const float D = a4 * rcp(fmaxf(PI_F * t * t, EPSILON_F));
-        const float gl = NdotL * rcp(fmaxf(NdotL * one_k + k, EPSILON_F));
-        const float G = gv * gl;
-        const float spec = D * G * rcp(fmaxf(4.0f * NdotL * NdotV, 0.0001f));
-        const float att = rcp(fmaxf(c0 + c1 * dist + c2 * dist * dist, EPSILON_F));
-        const float scale = intensity * att * NdotL;
-        const float kdx = (1.0f - F.x) * one_m, kdy = (1.0f - F.y) * one_m, kdz = (1.0f - F.z) * one_m;
-        pl.x += (kdx * albedo.x * INV_PI_F + F.x * spec) * lc.x * scale;
-        pl.y += (kdy * albedo.y * INV_PI_F + F.y * spec) * lc.y * scale;
-        pl.z += (kdz * albedo.z * INV_PI_F + F.z * spec) * lc.z * scale;
+        const float omf5 = 1.0f - f5;
+        const float Fx = F0.x + omF0.x * f5, Fy = F0.y + omF0.y * f5, Fz = F0.z + omF0.z * f5;
+        pl.x += (Kdiff.x * omf5 + Fx * spec) * (q1.x * X);
+        pl.y += (Kdiff.y * omf5 + Fy * spec) * (q1.y * X);
+        pl.z += (Kdiff.z * omf5 + Fz * spec) * (q1.z * X);
+    };
+
+    if (n_lights > 0) {
+        if (STAGED_LISTS) {
+            const uint16_t* my = lists + (((sy - tile_y0) * tiles_x + (sx - tile_x0)) * PBR_CLUSTER_Z + sz) * LIST_STRIDE_U16;
+            const int nl = my[0];
+            // two lights per trip: both index reads and both record reads are in flight together
+            int i = 0;
+            for (; i + 1 < nl; i += 2) {
+                const uint32_t pair = *reinterpret_cast<const uint32_t*>(my + 2 + i);   // i even -> 4-byte aligned
+                light((int)(pair & 0xFFFFu));
+                light((int)(pair >> 16));
+            }
+            if (i < nl) light((int)my[2 + i]);
+        } else {
+            const pbr_cluster* cl = p.clusters + (sz + sx * PBR_CLUSTER_Z + sy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+            const int nl = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
+            for (int i = 0; i < nl; i++) light(max(cl->LightIndex[i], 0));
+        }
+    }
+
+    // ---- EnvironmentSpecular part 2: filter the taps fetched above
+    {
+        auto bil = [](const H4x2& r0, const H4x2& r1, float fx, float fy) {
+            const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+            const float tr = (float)r0.a.x * wx0 + (float)r0.b.x * fx, br = (float)r1.a.x * wx0 + (float)r1.b.x * fx;
+            const float tg = (float)r0.a.y * wx0 + (float)r0.b.y * fx, bg = (float)r1.a.y * wx0 + (float)r1.b.y * fx;
+            const float tb = (float)r0.a.z * wx0 + (float)r0.b.z * fx, bb = (float)r1.a.z * wx0 + (float)r1.b.z * fx;
+            return v3(tr * wy0 + br * fy, tg * wy0 + bg * fy, tb * wy0 + bb * fy);
+        };
+        const V3 ea = bil(e00, e01, e0fx, e0fy);
+        const V3 eb = bil(e10, e11, e1fx, e1fy);
+        const float w0 = 1.0f - env_f;
+        const V3 envc = v3(ea.x * w0 + eb.x * env_f, ea.y * w0 + eb.y * env_f, ea.z * w0 + eb.z * env_f);
+        const H2 l00 = lsel0 ? lt0.b : lt0.a, l10 = lsel1 ? lt0.b : lt0.a;
+        const H2 l01 = lsel0 ? lt1.b : lt1.a, l11 = lsel1 ? lt1.b : lt1.a;
+        const float wx0 = 1.0f - lfx, wy0 = 1.0f - lfy;
+        const float la = ((float)l00.x * wx0 + (float)l10.x * lfx) * wy0 + ((float)l01.x * wx0 + (float)l11.x * lfx) * lfy;
+        const float lb = ((float)l00.y * wx0 + (float)l10.y * lfx) * wy0 + ((float)l01.y * wx0 + (float)l11.y * lfx) * lfy;
+        out.x += envc.x * (F0.x * la + lb);
+        out.y += envc.y * (F0.y * la + lb);
+        out.z += envc.z * (F0.z * la + lb);
     }
     out = out + pl;
     // emission (Q1: the directional light of :144-156 is computed by the reference but never added)
@@ -190,27 +308,71 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const LightLds
     store_h4(p.hdr + 4 * ((size_t)py * p.hdr_pitch + px), f4(out.x, out.y, out.z, 1.0f));
 }
 
-// grid (ceil(w/256), ceil(h/SHADE_ROWS)), block 256, dynamic LDS = n_lights * 48 B
-__global__ __launch_bounds__(SHADE_BLOCK) void k_deferred_shade(ShadeParams p, int n_lights) {
+// grid (ceil(w/256), ceil(h/SHADE_ROWS)), block 256.
+// dynamic LDS: n_lights * 48 B light records, then (STAGED_LISTS) max_clusters * 68 B of light lists.
+template <bool STAGED_LISTS>
+__global__ __launch_bounds__(SHADE_BLOCK) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters) {
     extern __shared__ float4 lds_raw[];
     LightLds* llds = reinterpret_cast<LightLds*>(lds_raw);
+    uint16_t* lists = reinterpret_cast<uint16_t*>(llds + n_lights);
     for (int i = threadIdx.x; i < n_lights; i += SHADE_BLOCK) {
         const pbr_light l = p.lights[i];
         LightLds r;
-        r.pos_int = make_float4(l.Position[0], l.Position[1], l.Position[2], l.Intensity);
-        r.col_c0 = make_float4(l.Color[0], l.Color[1], l.Color[2], l.C0);
-        r.c1c2 = make_float4(l.C1, l.C2, 0.0f, 0.0f);
+        r.pos_c0 = make_float4(l.Position[0], l.Position[1], l.Position[2], l.C0);
+        r.col_c1 = make_float4(l.Color[0] * l.Intensity, l.Color[1] * l.Intensity, l.Color[2] * l.Intensity, l.C1);
+        r.c2 = make_float4(l.C2, 0.0f, 0.0f, 0.0f);
         llds[i] = r;
     }
-    __syncthreads();
-    const uint32_t px = blockIdx.x * SHADE_BLOCK + threadIdx.x;
-    if (px >= p.w) return;
+    const uint32_t bx0 = blockIdx.x * SHADE_BLOCK;
     const uint32_t y_begin = blockIdx.y * SHADE_ROWS;
     const uint32_t y_end = min(y_begin + SHADE_ROWS, p.h);
-    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel(p, llds, n_lights, px, py);
+    int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
+    if (STAGED_LISTS) {
+        // cluster (x,y) tiles the block's pixel rectangle can fall into — same arithmetic as the per-pixel
+        // ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners bound it
+        const uint32_t bx1 = min(bx0 + SHADE_BLOCK, p.w) - 1;
+        auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
+        auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
+        tile_x0 = tx(bx0);
+        const int tile_x1 = tx(bx1);
+        const int ty_a = ty(y_begin), ty_b = ty(y_end - 1);
+        tile_y0 = min(ty_a, ty_b);
+        const int tile_y1 = max(ty_a, ty_b);
+        tiles_x = tile_x1 - tile_x0 + 1;
+        const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
+        for (int e = threadIdx.x; e < n_cl * LIST_STRIDE_U16; e += SHADE_BLOCK) {
+            const int c = e / LIST_STRIDE_U16, j = e % LIST_STRIDE_U16;
+            const int z = c % PBR_CLUSTER_Z, t = c / PBR_CLUSTER_Z;
+            const int cx = tile_x0 + t % tiles_x, cy = tile_y0 + t / tiles_x;
+            const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+            int val = 0;
+            if (j == 0) val = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
+            else if (j >= 2) val = min(max(cl->LightIndex[j - 2], 0), PBR_MAX_SCENE_LIGHTS - 1);
+            lists[e] = (uint16_t)val;
+        }
+    }
+    __syncthreads();
+    const uint32_t px = bx0 + threadIdx.x;
+    if (px >= p.w) return;
+    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS>(p, llds, lists, tile_x0, tile_y0, tiles_x, n_lights, px, py);
 }
 
 extern "C" {
+
+pbr_status pbr_env_pad(pbr_ctx* ctx, const pbr_half* env, uint32_t size, uint32_t mips, pbr_half* out_padded) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, env && out_padded, "pbr_env_pad: null pointer");
+    PBR_REQUIRE(ctx, size >= 1 && size <= 8192 && mips >= 1 && mips <= 16 && (size >> (mips - 1)) >= 1, "pbr_env_pad: bad size/mips");
+    for (uint32_t m = 0; m < mips; m++) {
+        const int s = (int)(size >> m);
+        const size_t n = (size_t)6 * (s + 2) * (s + 2);
+        hipLaunchKernelGGL(k_env_pad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           env + 4 * cube_mip_offset(size, m), out_padded + 4 * env_padded_mip_offset(size, m), s);
+        pbr_status r = launched(ctx, "k_env_pad");
+        if (r) return r;
+    }
+    return PBR_OK;
+}
 
 pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
                               const pbr_half* lut, uint32_t lut_res,
@@ -223,22 +385,34 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
     PBR_REQUIRE(ctx, tile->w >= 1 && tile->h >= 1 && tile->w <= 65535 && tile->h <= 65535, "pbr_deferred_shade: bad tile size");
     PBR_REQUIRE(ctx, tile->x0 + tile->w <= tile->full_w && tile->y0 + tile->h <= tile->full_h, "pbr_deferred_shade: tile outside frame");
     PBR_REQUIRE(ctx, gb->pitch >= tile->w && hdr_pitch >= tile->w, "pbr_deferred_shade: pitch < width");
-    PBR_REQUIRE(ctx, lut_res >= 1 && env_size >= 1 && env_mips >= 1 && (env_size >> (env_mips - 1)) >= 1, "pbr_deferred_shade: bad LUT/env size");
+    PBR_REQUIRE(ctx, lut_res >= 1 && env_size >= 1 && env_mips >= 1 && env_mips <= 16 && (env_size >> (env_mips - 1)) >= 1, "pbr_deferred_shade: bad LUT/env size");
+    PBR_REQUIRE(ctx, ((uintptr_t)env & 7u) == 0 && ((uintptr_t)lut & 3u) == 0, "pbr_deferred_shade: env must be 8-byte and lut 4-byte aligned");
     PBR_REQUIRE(ctx, g->Near > 0.0f && g->Far > g->Near, "pbr_deferred_shade: need 0 < Near < Far");
+    PBR_REQUIRE(ctx, num_lights >= 0 && num_lights <= PBR_MAX_SCENE_LIGHTS, "pbr_deferred_shade: light count out of [0, 1024]");
+    PBR_REQUIRE(ctx, num_lights == 0 || lights != nullptr, "pbr_deferred_shade: null lights");
     ShadeParams p;
     p.sh = g->SkyBoxSH;
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) p.InvView[r * 3 + c] = g->InvView[r * 4 + c];
     for (int i = 0; i < 3; i++) p.CameraPos[i] = g->CameraPos[i];
-    p.Near = g->Near; p.Far = g->Far; p.Fov = g->Fov; p.Ratio = g->Ratio;
+    p.Near = g->Near; p.Far = g->Far;
+    p.near_height = 2.0f * g->Near * tanf(g->Fov / 2.0f);
+    p.near_width = p.near_height * g->Ratio;
+    p.log_far_near = logf(g->Far / g->Near);
     p.x0 = tile->x0; p.y0 = tile->y0; p.w = tile->w; p.h = tile->h; p.full_w = tile->full_w; p.full_h = tile->full_h;
     p.A = gb->A; p.B = gb->B; p.C = gb->C; p.depth = gb->depth; p.stencil = gb->stencil; p.pitch = gb->pitch;
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
     p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch;
-    PBR_REQUIRE(ctx, num_lights >= 0 && num_lights <= PBR_MAX_SCENE_LIGHTS, "pbr_deferred_shade: light count out of [0, 1024]");
-    PBR_REQUIRE(ctx, num_lights == 0 || lights != nullptr, "pbr_deferred_shade: null lights");
     dim3 grid((tile->w + SHADE_BLOCK - 1) / SHADE_BLOCK, (tile->h + SHADE_ROWS - 1) / SHADE_ROWS);
-    hipLaunchKernelGGL(k_deferred_shade, grid, dim3(SHADE_BLOCK), (size_t)num_lights * sizeof(LightLds), ctx->stream, p, num_lights);
+    // A block covers 256 x 8 pixels.  It can stage its cluster lists when that rectangle spans at most
+    // MAX_STAGED_TILES cluster tiles: a tile is full_w/24 x full_h/16 pixels, +1 per axis for straddling.
+    const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
+    const uint32_t span_y = (uint32_t)((uint64_t)(SHADE_ROWS - 1) * PBR_CLUSTER_Y / tile->full_h) + 2;
+    const bool staged = num_lights > 0 && span_x * span_y <= (uint32_t)MAX_STAGED_TILES;
+    const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
+    const size_t lds = (size_t)num_lights * sizeof(LightLds) + (size_t)max_clusters * LIST_STRIDE_U16 * sizeof(uint16_t);
+    if (staged) hipLaunchKernelGGL(k_deferred_shade<true>, grid, dim3(SHADE_BLOCK), lds, ctx->stream, p, num_lights, max_clusters);
+    else hipLaunchKernelGGL(k_deferred_shade<false>, grid, dim3(SHADE_BLOCK), lds, ctx->stream, p, num_lights, 0);
     return launched(ctx, "k_deferred_shade");
 }
 

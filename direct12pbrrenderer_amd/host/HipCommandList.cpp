@@ -164,6 +164,7 @@ void HipCommandList::Dispatch(ShadingState* s, uint32 gx, uint32 gy, uint32 gz) 
         pbr_cube_f32 cube{(const float*)sky->DevicePtr(), sky->Size(), sky->MipLevels()};
         pbr_half* dst = (pbr_half*)out->DevicePtr() + 4 * pbr_cube_mip_offset(out->Size(), c.MipLevel);
         Check(pbr_prefilter_env_mip(mCtx, &cube, c.EnvMapSize, c.MipLevel, c.Roughness, dst), "pbr_prefilter_env_mip");
+        mPaddedEnv.erase(out);   // the padded copy the shade samples is stale now
     } else if (f == "clustered_compute.hlsl") {
         ExpectGroups(f, gx, gy, gz, 1, 1, 1);
         Check(pbr_cluster_build(mCtx, &mGlobal, (pbr_cluster*)s->Buffer("Clusters")->DevicePtr()), "pbr_cluster_build");
@@ -232,10 +233,16 @@ void HipCommandList::DrawScreen(ShadingState* s) {
         pbr_gbuffer gb{(const uint32_t*)a->DevicePtr(), (const uint32_t*)b->DevicePtr(), (const uint32_t*)c->DevicePtr(),
                        ds->DepthPlane(), ds->StencilPlane(), w};
         pbr_tile tile = mTile.w ? mTile : pbr_tile{0, 0, w, h, w, h};
+        // the shade samples the padded layout of the env chain (seamless-cube addressing resolved once)
+        auto& padded = mPaddedEnv[env];
+        if (!padded) {
+            padded = std::make_unique<DeviceStructuredBuffer>((uint32)(pbr_env_padded_texels(env->Size(), env->MipLevels()) * 8), 8);
+            Check(pbr_env_pad(mCtx, (const pbr_half*)env->DevicePtr(), env->Size(), env->MipLevels(), (pbr_half*)padded->DevicePtr()), "pbr_env_pad");
+        }
         // stencil ref 0, compare LESS: shade where 0 < stencil (DeferredPipeline.h:176-181, .cpp:203)
         if (mStencilRef != 0) throw HipException("deferred_shading: only stencil ref 0 is supported");
         Check(pbr_deferred_shade(mCtx, &mGlobal, &tile, &gb, (const pbr_half*)lut->DevicePtr(), lut->Width(),
-                                 (const pbr_half*)env->DevicePtr(), env->Size(), env->MipLevels(),
+                                 (const pbr_half*)padded->DevicePtr(), env->Size(), env->MipLevels(),
                                  (const pbr_cluster*)s->Buffer("Clusters")->DevicePtr(), (const pbr_light*)s->Buffer("PointLights")->DevicePtr(),
                                  mNumLights, (pbr_half*)mRenderTarget->DevicePtr(), w), "pbr_deferred_shade");
     } else if (f == "hdr_tone_mapping.hlsl") {

@@ -53,6 +53,9 @@ private:
     DeviceTexture2D* mPresented = nullptr;
     DeviceTexture2D* mRenderTarget = nullptr;
     pbr_tile mTile{};
+    // padded copies of prefiltered env chains (pbr_env_pad), keyed by the plain texture; rebuilt after
+    // env_map_gen.hlsl rewrites the texture
+    std::map<const DeviceTexture2DArray*, std::unique_ptr<DeviceStructuredBuffer>> mPaddedEnv;
 };
 
 }  // namespace MRendererHip

@@ -96,7 +96,9 @@ class DeferredFrame:
         self.ctx, self.spec, self.g = ctx, spec, g
         self.n_lights = int(len(lights_np))
         self.lights = ctx.upload(lights_np) if self.n_lights else None
-        self.lut, self.lut_res, self.env, self.env_size, self.env_mips = lut, lut_res, env, env_size, env_mips
+        # env: plain prefiltered chain (pbr_prefilter_env); the shade samples its padded copy (one-shot)
+        self.lut, self.lut_res, self.env_size, self.env_mips = lut, lut_res, env_size, env_mips
+        self.env = ctx.env_pad(env, env_size, env_mips)
         self.allreduce = allreduce
         ew, eh = spec.ew, spec.eh
         self.clusters = ctx.alloc_clusters()

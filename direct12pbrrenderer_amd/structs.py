@@ -94,6 +94,15 @@ def cube_texels(size: int, mips: int) -> int:
     return cube_mip_offset(size, mips)
 
 
+def env_padded_mip_offset(size: int, mip: int) -> int:
+    """Texel offset of mip `mip` in the padded env layout ((s+2)^2 per face, see pbr_env_pad)."""
+    return sum(6 * ((size >> m) + 2) ** 2 for m in range(mip))
+
+
+def env_padded_texels(size: int, mips: int) -> int:
+    return env_padded_mip_offset(size, mips)
+
+
 def bloom_level_offset(w: int, h: int, level: int) -> int:
     return sum((w >> l) * (h >> l) for l in range(level))
 

@@ -128,6 +128,12 @@ typedef struct pbr_cube_f32 {
 size_t pbr_cube_texels(uint32_t size, uint32_t mips);
 /* texel offset of (mip, face 0) */
 size_t pbr_cube_mip_offset(uint32_t size, uint32_t mip);
+/* texels of the PADDED prefiltered-env layout pbr_deferred_shade samples: every face of every mip
+ * carries a 1-texel border ((s+2) x (s+2)) holding the texel the seamless-cube rule selects for an
+ * out-of-face tap, so the per-pixel trilinear fetch is branch-free and each bilinear row is one
+ * contiguous 16-byte pair.  Offset of (mip, face 0) = pbr_env_padded_mip_offset. */
+size_t pbr_env_padded_texels(uint32_t size, uint32_t mips);
+size_t pbr_env_padded_mip_offset(uint32_t size, uint32_t mip);
 /* texels of a PBR_BLOOM_MIPS-level 2D chain of a w x h image (level l is (w>>l) x (h>>l)) */
 size_t pbr_bloom_chain_texels(uint32_t w, uint32_t h);
 size_t pbr_bloom_level_offset(uint32_t w, uint32_t h, uint32_t level);
@@ -163,6 +169,10 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
 pbr_status pbr_prefilter_env_mip(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t size, uint32_t mip_level,
                                  float roughness, pbr_half* out_mip_rgba);
 
+/* Build the padded copy of a prefiltered env chain (one-shot, after pbr_prefilter_env).
+ * env_rgba: plain half4 cube chain (pbr_cube_f32 layout); out_padded: pbr_env_padded_texels half4. */
+pbr_status pbr_env_pad(pbr_ctx* ctx, const pbr_half* env_rgba, uint32_t size, uint32_t mips, pbr_half* out_padded);
+
 /* SHBaker::ProjectEnvironmentMap + PackCubeMapSHCoefficient (Engine/Source/Utils/SH.cpp:87-153,
  * 201-222) as a deterministic solid-angle quadrature over every mip-0 texel.
  * out_pack: DEVICE pointer to 28 floats (pbr_sh_pack). */
@@ -178,14 +188,15 @@ pbr_status pbr_cluster_cull(pbr_ctx* ctx, const pbr_global* g, const pbr_light* 
                             pbr_cluster* clusters);
 
 /* deferred_shading.hlsl:91-192 full-screen pass, stencil-masked (DeferredPipeline.cpp:187-206).
- * gb: HOST struct of device planes.  lut: res x res half2.  env: half4 cube chain.
+ * gb: HOST struct of device planes.  lut: res x res half2.  env_padded: the PADDED half4 cube chain
+ * produced by pbr_env_pad (the fixed-function seamless-cube addressing, done once instead of per tap).
  * lights / num_lights: the PointLights buffer the cluster lists index (num_lights <= 1024; the
  * kernel stages exactly num_lights records into LDS, indices are clamped to that range).
  * hdr: tile-local w x h half4, pitch hdr_pitch pixels; untouched where stencil == 0. */
 pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile,
                               const pbr_gbuffer* gb,
                               const pbr_half* lut, uint32_t lut_res,
-                              const pbr_half* env, uint32_t env_size, uint32_t env_mips,
+                              const pbr_half* env_padded, uint32_t env_size, uint32_t env_mips,
                               const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
                               pbr_half* hdr, uint32_t hdr_pitch);
 

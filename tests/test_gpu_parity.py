@@ -173,7 +173,8 @@ def _shade_on_gpu(ctx, g, tile, gb, lut, env, env_size, env_mips, clusters_np, l
     h, w = gb["A"].shape
     gbd = {k: ctx.upload(v) for k, v in gb.items()}
     hdr = ctx.zeros((h, w, 4), torch.float16) if prefill is None else dev_half(ctx, prefill)
-    ctx.deferred_shade(g, tile, gbd, w, dev_half(ctx, lut), lut.shape[0], dev_half(ctx, env), env_size, env_mips,
+    env_padded = ctx.env_pad(dev_half(ctx, env), env_size, env_mips)
+    ctx.deferred_shade(g, tile, gbd, w, dev_half(ctx, lut), lut.shape[0], env_padded, env_size, env_mips,
                        ctx.upload(clusters_np), ctx.upload(lights) if len(lights) else None, len(lights), hdr, w)
     return to_np_half(hdr)
 
