@@ -80,12 +80,12 @@ __global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ sr
     reinterpret_cast<H4*>(dst)[t] = reinterpret_cast<const H4*>(src)[((size_t)face * s + y) * s + x];
 }
 
-// LDS light record (48 B, float4-aligned)
-struct LightLds {
-    float4 pos_c0;   // position.xyz, C0
-    float4 col_c1;   // color.rgb * intensity, C1
-    float4 c2;       // C2, -, -, -
-};
+// Light table in LDS, structure-of-arrays: 9 planes of LSTRIDE floats
+//   0..2 position, 3..5 color*intensity, 6..8 attenuation C0,C1,C2
+// SoA (not 48-byte records) so that the SAME component of two different lights lands in an adjacent
+// VGPR pair straight from two ds_read_b32 — the operand shape v_pk_*_f32 wants — with no repacking
+// moves; the plane stride is a compile-time constant so the plane offset rides in the DS offset field.
+constexpr int LIGHT_PLANES = 9;
 
 constexpr int SHADE_BLOCK = 256;
 constexpr int SHADE_ROWS = 8;          // rows of 256 pixels one block walks after staging its tables
@@ -93,88 +93,205 @@ constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices m
 // staged list: count, pad, 32 u16 indices = 34 halfwords (68 B) per cluster
 constexpr int LIST_STRIDE_U16 = 34;
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 f2s(float a) { return f2{a, a}; }
+__device__ __forceinline__ f2 max2(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ f2 rsq2(f2 a) { return f2{rsq(a.x), rsq(a.y)}; }
+__device__ __forceinline__ f2 rcp2(f2 a) { return f2{rcp(a.x), rcp(a.y)}; }
+
 struct alignas(8) H4x2 { H4 a, b; };   // two x-adjacent half4 texels (16 bytes, 8-byte aligned)
 struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-byte aligned)
 
-template <bool STAGED_LISTS>
-__device__ __forceinline__ void shade_pixel(const ShadeParams& p, const LightLds* llds, const uint16_t* lists,
+// One pixel.  Register budget is the design constraint: on gfx950 a SIMD issues plain fp32 VALU at
+// ~2.2 cycles/instruction with 8 resident waves but only ~3.5 with 3 (measured, tools/valu_rate.hip;
+// v_pk_*_f32 costs two issue slots, so packing buys nothing).  The pixel is therefore shaded in
+// phases that keep <= 64 VGPRs live (8 waves/SIMD):
+//   1. geometry: position, normal, view vector, roughness terms;
+//   2. light loop: accumulates nine light-colour-weighted sums that do not depend on albedo/F0:
+//        pl_c = Kdiff_c * S1_c + F0_c * spec_pix * S2_c + (1-F0_c) * spec_pix * S3_c
+//        S1_c = sum col_c X (1-f5), S2_c = sum col_c X s, S3_c = sum col_c X s f5,   s = NdotL/(T A B)
+//   3. material: re-reads the A/C planes (L2 hits) and folds the sums;
+//   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
+template <bool STAGED_LISTS, int LSTRIDE>
+__device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint16_t* lists,
                                             int tile_x0, int tile_y0, int tiles_x, int n_lights, uint32_t px, uint32_t py) {
     const size_t gi = (size_t)py * p.pitch + px;
     if (p.stencil[gi] == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
+    const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
 
-    const uint32_t a = p.A[gi], b = p.B[gi], c = p.C[gi];
-    const float depth_ndc = p.depth[gi];
-
-    // uv / camera ray from the GLOBAL pixel (vs_main :91-121, screen triangle D3D12Device.cpp:167-176)
+    // ---- phase 1: geometry (vs_main :91-121, screen triangle D3D12Device.cpp:167-176; uv from the GLOBAL pixel)
     const float u = ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
     const float v = ((float)(p.y0 + py) + 0.5f) / (float)p.full_h;
-    const float ndc_x = 2.0f * u - 1.0f, ndc_y = 1.0f - 2.0f * v;
-    const V3 cvv = v3(ndc_x * 0.5f * p.near_width, ndc_y * 0.5f * p.near_height, p.Near);
-    const V3 camera_vec = v3(p.InvView[0] * cvv.x + p.InvView[1] * cvv.y + p.InvView[2] * cvv.z,
-                             p.InvView[3] * cvv.x + p.InvView[4] * cvv.y + p.InvView[5] * cvv.z,
-                             p.InvView[6] * cvv.x + p.InvView[7] * cvv.y + p.InvView[8] * cvv.z);
-
-    const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
-    const V3 albedo = v3((float)(a & 255u) * inv255, (float)((a >> 8) & 255u) * inv255, (float)((a >> 16) & 255u) * inv255);
-    const float emission = (float)(a >> 24) * inv255;
-    const float roughness = (float)(c & 255u) * inv255;
-    const float metallic = (float)((c >> 8) & 255u) * inv255;
-    const V3 n = normalize3(decode_octahedron((float)(b & 255u) * inv255, (float)((b >> 8) & 255u) * inv255));
-
-    // ViewSpaceDepth :74-77, ReconstructWorldPosition :79-83
-    const float z_vs = p.Near * p.Far / (p.Far - depth_ndc * (p.Far - p.Near));
-    const V3 cam = v3(p.CameraPos[0], p.CameraPos[1], p.CameraPos[2]);
-    const float zs = z_vs / p.Near;
-    const V3 pos = v3(cam.x + camera_vec.x * zs, cam.y + camera_vec.y * zs, cam.z + camera_vec.z * zs);
-    const V3 view = normalize3(cam - pos);
-
-    const V3 F0 = v3(0.04f + metallic * (albedo.x - 0.04f), 0.04f + metallic * (albedo.y - 0.04f), 0.04f + metallic * (albedo.z - 0.04f));
+    V3 pos, view, n;
+    float z_vs, roughness;
+    {
+        const uint32_t b = p.B[gi], c = p.C[gi];
+        const float depth_ndc = p.depth[gi];
+        const float ndc_x = 2.0f * u - 1.0f, ndc_y = 1.0f - 2.0f * v;
+        const V3 cvv = v3(ndc_x * 0.5f * p.near_width, ndc_y * 0.5f * p.near_height, p.Near);
+        const V3 camera_vec = v3(p.InvView[0] * cvv.x + p.InvView[1] * cvv.y + p.InvView[2] * cvv.z,
+                                 p.InvView[3] * cvv.x + p.InvView[4] * cvv.y + p.InvView[5] * cvv.z,
+                                 p.InvView[6] * cvv.x + p.InvView[7] * cvv.y + p.InvView[8] * cvv.z);
+        roughness = (float)(c & 255u) * inv255;
+        n = normalize3(decode_octahedron((float)(b & 255u) * inv255, (float)((b >> 8) & 255u) * inv255));
+        // ViewSpaceDepth :74-77, ReconstructWorldPosition :79-83
+        z_vs = p.Near * p.Far / (p.Far - depth_ndc * (p.Far - p.Near));
+        const V3 cam = v3(p.CameraPos[0], p.CameraPos[1], p.CameraPos[2]);
+        const float zs = z_vs / p.Near;
+        pos = v3(cam.x + camera_vec.x * zs, cam.y + camera_vec.y * zs, cam.z + camera_vec.z * zs);
+        view = normalize3(cam - pos);
+    }
     const float NdV = dot3(n, view);
     const float NdotV = fmaxf(NdV, 0.0f);
 
-    // ---- EnvironmentSpecular :56-70, part 1: addresses + loads (filtered after the light loop)
-    H4x2 e00, e01, e10, e11;   // mip l0 rows y0,y1 ; mip l1 rows y0,y1
-    H2x2 lt0, lt1;
-    float env_f, e0fx, e0fy, e1fx, e1fy, lfx, lfy;
-    bool lsel0, lsel1;
+    // ---- phase 2: clustered point lights :159-186.  ClusterIndex(uv, z), clustered.hlsli:45-60;
+    // logf (not the fast intrinsic): the result is truncated to the slice index.
+    float s1x = 0.0f, s1y = 0.0f, s1z = 0.0f, s2x = 0.0f, s2y = 0.0f, s2z = 0.0f, s3x = 0.0f, s3y = 0.0f, s3z = 0.0f;
+    if (n_lights > 0) {
+        int sx = (int)floorf(u * (float)PBR_CLUSTER_X);
+        int sy = (int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y);
+        const float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
+        int sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
+        sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
+        sy = clampi(sy, 0, PBR_CLUSTER_Y - 1);
+        sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
+        // brdf() (brdf.hlsli:47-67) with D, G and the 4 NdotL NdotV denominator under ONE reciprocal:
+        //   D G / max(4 NdotL NdotV,1e-4) = [a^4/pi * gV] * NdotL / (T * A * B),  T = max(t^2, 1e-6/pi),
+        //   A = NdotL(1-k)+k (>= 1/8: the shader's max(.,1e-6) never binds), B = max(4 NdotL NdotV, 1e-4)
+        const float ra = roughness * roughness;
+        const float a4m1 = ra * ra - 1.0f;
+        const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
+        const float one_k = 1.0f - k;
+        const float ndv4 = 4.0f * NdotV;
+        const float t_floor = EPSILON_F * INV_PI_F;
+        // Two lights per trip in the two halves of packed-fp32 registers (light A | light B): measured on
+        // gfx950 (tools/valu_rate*.hip) a plain fp32 VALU op issues every ~4 cycles per SIMD whatever the
+        // occupancy, v_pk_{fma,mul,add}_f32 every ~5.4 with >= 6 resident waves — 1.5x per flop.  The SoA
+        // light planes put the same component of both lights into an adjacent VGPR pair with no moves.
+        f2 a1x = f2s(0.0f), a1y = f2s(0.0f), a1z = f2s(0.0f), a2x = f2s(0.0f), a2y = f2s(0.0f), a2z = f2s(0.0f), a3x = f2s(0.0f), a3y = f2s(0.0f), a3z = f2s(0.0f);
+        auto light2 = [&](int liA, int liB, float wB) {
+            const float* la = llds + min(liA, n_lights - 1);   // never index past the staged table
+            const float* lb = llds + min(liB, n_lights - 1);
+            auto comp = [&](int c) { return f2{la[c * LSTRIDE], lb[c * LSTRIDE]}; };
+            const f2 dx = comp(0) - f2s(pos.x), dy = comp(1) - f2s(pos.y), dz = comp(2) - f2s(pos.z);
+            const f2 d2 = dx * dx + dy * dy + dz * dz;
+            const f2 invd = rsq2(d2);
+            const f2 dist = d2 * invd;
+            const f2 NdL = (dx * n.x + dy * n.y + dz * n.z) * invd;
+            const f2 NdotL = max2(NdL, f2s(0.0f));
+            const f2 LdV = (dx * view.x + dy * view.y + dz * view.z) * invd;
+            // |L + V|^2 = 2 + 2 L.V ; N.H = (N.L + N.V) / |L + V|
+            const f2 NdotH = max2((NdL + f2s(NdV)) * rsq2(max2(LdV * 2.0f + f2s(2.0f), f2s(1e-12f))), f2s(0.0f));
+            const f2 t = (NdotH * NdotH) * a4m1 + f2s(1.0f);
+            const f2 T = max2(t * t, f2s(t_floor));
+            const f2 A = NdotL * one_k + f2s(k);
+            const f2 B = max2(NdotL * ndv4, f2s(0.0001f));
+            const f2 Q = max2(comp(6) + comp(7) * dist + comp(8) * d2, f2s(EPSILON_F));
+            const f2 X = (NdotL * rcp2(Q)) * f2{1.0f, wB};   // attenuation * NdotL (light B masked off on an odd tail)
+            const f2 fm = max2(f2s(1.0f) - NdotL, f2s(EPSILON_F));   // fresnel on NdotL (Q3)
+            const f2 fm2 = fm * fm;
+            const f2 f5 = fm2 * fm2 * fm;
+            const f2 w2 = X * NdotL * rcp2(T * A * B);   // X * s
+            const f2 w1 = X - X * f5;                    // X * (1 - f5)
+            const f2 w3 = w2 * f5;
+            const f2 cr = comp(3), cg = comp(4), cb = comp(5);
+            a1x += cr * w1; a1y += cg * w1; a1z += cb * w1;
+            a2x += cr * w2; a2y += cg * w2; a2z += cb * w2;
+            a3x += cr * w3; a3y += cg * w3; a3z += cb * w3;
+        };
+        if (STAGED_LISTS) {
+            const uint16_t* my = lists + (((sy - tile_y0) * tiles_x + (sx - tile_x0)) * PBR_CLUSTER_Z + sz) * LIST_STRIDE_U16;
+            const int nl = my[0];
+            int i = 0;
+            for (; i + 1 < nl; i += 2) {   // two indices per LDS read
+                const uint32_t pair = *reinterpret_cast<const uint32_t*>(my + 2 + i);   // i even -> 4-byte aligned
+                light2((int)(pair & 0xFFFFu), (int)(pair >> 16), 1.0f);
+            }
+            if (i < nl) light2((int)my[2 + i], (int)my[2 + i], 0.0f);
+        } else {
+            const pbr_cluster* cl = p.clusters + (sz + sx * PBR_CLUSTER_Z + sy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+            const int nl = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
+            int i = 0;
+            for (; i + 1 < nl; i += 2) light2(max(cl->LightIndex[i], 0), max(cl->LightIndex[i + 1], 0), 1.0f);
+            if (i < nl) light2(max(cl->LightIndex[i], 0), max(cl->LightIndex[i], 0), 0.0f);
+        }
+        s1x = a1x.x + a1x.y; s1y = a1y.x + a1y.y; s1z = a1z.x + a1z.y;
+        s2x = a2x.x + a2x.y; s2y = a2y.x + a2y.y; s2z = a2z.x + a2z.y;
+        s3x = a3x.x + a3x.y; s3y = a3y.x + a3y.y; s3z = a3z.x + a3z.y;
+    }
+
+    // ---- phase 3: material terms (planes A and C re-read: L2 hits, keeps them out of the loop's registers)
+    const uint32_t a = p.A[gi];
+    const float metallic = (float)((p.C[gi] >> 8) & 255u) * inv255;
+    const V3 albedo = v3((float)(a & 255u) * inv255, (float)((a >> 8) & 255u) * inv255, (float)((a >> 16) & 255u) * inv255);
+    const float emission = (float)(a >> 24) * inv255;
+    const V3 F0 = v3(0.04f + metallic * (albedo.x - 0.04f), 0.04f + metallic * (albedo.y - 0.04f), 0.04f + metallic * (albedo.z - 0.04f));
+    V3 out;
+    {
+        const float ra = roughness * roughness;
+        const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
+        const float gv = NdotV / fmaxf(NdotV * (1.0f - k) + k, EPSILON_F);
+        const float spec_pix = ra * ra * INV_PI_F * gv;
+        const float kd = (1.0f - metallic) * INV_PI_F;   // Kd*albedo/pi = (1-F0)(1-m) albedo/pi * (1-f5)
+        out.x = (1.0f - F0.x) * (kd * albedo.x * s1x + spec_pix * s3x) + F0.x * spec_pix * s2x;
+        out.y = (1.0f - F0.y) * (kd * albedo.y * s1y + spec_pix * s3y) + F0.y * spec_pix * s2y;
+        out.z = (1.0f - F0.z) * (kd * albedo.z * s1z + spec_pix * s3z) + F0.z * spec_pix * s2z;
+        // emission (Q1: the directional light of :144-156 is computed by the reference but never added)
+        out = out + albedo * emission;
+
+        // ---- phase 4a: EnvironmentDiffuse :23-54
+        const float bx = n.x * n.y, by = n.y * n.z, bz = n.z * n.z, bw = n.z * n.x;
+        const float cc = n.x * n.x - n.y * n.y;
+        const pbr_sh_pack& s = p.sh;
+        const float ir = (s.sha_r[0] * n.x + s.sha_r[1] * n.y + s.sha_r[2] * n.z + s.sha_r[3]) +
+                         ((s.shb_r[0] * bx + s.shb_r[1] * by + s.shb_r[2] * bz + s.shb_r[3] * bw) + s.shc[0] * cc);
+        const float ig = (s.sha_g[0] * n.x + s.sha_g[1] * n.y + s.sha_g[2] * n.z + s.sha_g[3]) +
+                         ((s.shb_g[0] * bx + s.shb_g[1] * by + s.shb_g[2] * bz + s.shb_g[3] * bw) + s.shc[1] * cc);
+        const float ib = (s.sha_b[0] * n.x + s.sha_b[1] * n.y + s.sha_b[2] * n.z + s.sha_b[3]) +
+                         ((s.shb_b[0] * bx + s.shb_b[1] * by + s.shb_b[2] * bz + s.shb_b[3] * bw) + s.shc[2] * cc);
+        out.x += albedo.x * kd * ir;
+        out.y += albedo.y * kd * ig;
+        out.z += albedo.z * kd * ib;
+    }
+
+    // ---- phase 4b: EnvironmentSpecular :56-70 — padded env chain: each bilinear row is one 16-byte pair
+#ifndef PBR_EXP_NOIBL
     {
         const V3 R = normalize3(n * (2.0f * NdV) - view);
         float lod = roughness * (float)PBR_ENV_MIPS;   // Q4: roughness*5 on a 5-mip chain
         lod = fminf(fmaxf(lod, 0.0f), (float)(p.env_mips - 1));
         const float fl = floorf(lod);
         const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1, p.env_mips - 1);
-        env_f = lod - fl;
+        const float env_f = lod - fl;
         uint32_t face;
         float cu, cv;
         cube_face_uv(R, face, cu, cv);
-        {
-            const int s = (int)(p.env_size >> l0), sp = s + 2;
+        auto fetch = [&](uint32_t l) {
+            const int s = (int)(p.env_size >> l), sp = s + 2;
             const BilinearCoord cx = bilinear_coord(cu, s), cy = bilinear_coord(cv, s);
-            const H4* m = reinterpret_cast<const H4*>(p.env) + env_padded_mip_offset(p.env_size, l0);
+            const H4* m = reinterpret_cast<const H4*>(p.env) + env_padded_mip_offset(p.env_size, l);
             const size_t o = ((size_t)face * sp + (size_t)(cy.i0 + 1)) * sp + (size_t)(cx.i0 + 1);
-            e00 = *reinterpret_cast<const H4x2*>(m + o);
-            e01 = *reinterpret_cast<const H4x2*>(m + o + sp);
-            e0fx = cx.f; e0fy = cy.f;
-        }
-        {
-            const int s = (int)(p.env_size >> l1), sp = s + 2;
-            const BilinearCoord cx = bilinear_coord(cu, s), cy = bilinear_coord(cv, s);
-            const H4* m = reinterpret_cast<const H4*>(p.env) + env_padded_mip_offset(p.env_size, l1);
-            const size_t o = ((size_t)face * sp + (size_t)(cy.i0 + 1)) * sp + (size_t)(cx.i0 + 1);
-            e10 = *reinterpret_cast<const H4x2*>(m + o);
-            e11 = *reinterpret_cast<const H4x2*>(m + o + sp);
-            e1fx = cx.f; e1fy = cy.f;
-        }
-        // LUT bilinear with clamp addressing (Q5): one 8-byte pair per row; at the borders both taps
-        // are the same texel, picked out of the pair that stays inside the row
+            const H4x2 r0 = *reinterpret_cast<const H4x2*>(m + o);
+            const H4x2 r1 = *reinterpret_cast<const H4x2*>(m + o + sp);
+            const float wx0 = 1.0f - cx.f, wy0 = 1.0f - cy.f;
+            const float tr = (float)r0.a.x * wx0 + (float)r0.b.x * cx.f, br = (float)r1.a.x * wx0 + (float)r1.b.x * cx.f;
+            const float tg = (float)r0.a.y * wx0 + (float)r0.b.y * cx.f, bg = (float)r1.a.y * wx0 + (float)r1.b.y * cx.f;
+            const float tb = (float)r0.a.z * wx0 + (float)r0.b.z * cx.f, bb = (float)r1.a.z * wx0 + (float)r1.b.z * cx.f;
+            return v3(tr * wy0 + br * cy.f, tg * wy0 + bg * cy.f, tb * wy0 + bb * cy.f);
+        };
+        const V3 ea = fetch(l0);
+        const V3 eb = fetch(l1);
+        const float w0 = 1.0f - env_f;
+        const V3 envc = v3(ea.x * w0 + eb.x * env_f, ea.y * w0 + eb.y * env_f, ea.z * w0 + eb.z * env_f);
+        // LUT bilinear with clamp addressing (Q5): one 8-byte pair per row; at the borders both taps are
+        // the same texel, picked out of the pair that stays inside the row
         const int lr = (int)p.lut_res;
         const BilinearCoord cx = bilinear_coord(roughness, lr), cy = bilinear_coord(NdotV, lr);
         const int x0 = clampi(cx.i0, 0, lr - 1), x1 = clampi(cx.i1, 0, lr - 1);
         const int y0 = clampi(cy.i0, 0, lr - 1), y1 = clampi(cy.i1, 0, lr - 1);
         const int xb = lr > 1 ? min(x0, lr - 2) : 0;
-        lsel0 = x0 != xb;   // tap0 is the pair's second texel
-        lsel1 = x1 != xb;
         const H2* lut = reinterpret_cast<const H2*>(p.lut);
+        H2x2 lt0, lt1;
         if (lr > 1) {
             lt0 = *reinterpret_cast<const H2x2*>(lut + (size_t)y0 * lr + xb);
             lt1 = *reinterpret_cast<const H2x2*>(lut + (size_t)y1 * lr + xb);
@@ -182,146 +299,40 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const LightLds
             lt0.a = lt0.b = lut[0];
             lt1 = lt0;
         }
-        lfx = cx.f; lfy = cy.f;
-    }
-
-    // ---- EnvironmentDiffuse :23-54
-    V3 out;
-    {
-        const float bx = n.x * n.y, by = n.y * n.z, bz = n.z * n.z, bw = n.z * n.x;
-        const float cc = n.x * n.x - n.y * n.y;
-        const pbr_sh_pack& s = p.sh;
-        float ir = (s.sha_r[0] * n.x + s.sha_r[1] * n.y + s.sha_r[2] * n.z + s.sha_r[3]) +
-                   ((s.shb_r[0] * bx + s.shb_r[1] * by + s.shb_r[2] * bz + s.shb_r[3] * bw) + s.shc[0] * cc);
-        float ig = (s.sha_g[0] * n.x + s.sha_g[1] * n.y + s.sha_g[2] * n.z + s.sha_g[3]) +
-                   ((s.shb_g[0] * bx + s.shb_g[1] * by + s.shb_g[2] * bz + s.shb_g[3] * bw) + s.shc[1] * cc);
-        float ib = (s.sha_b[0] * n.x + s.sha_b[1] * n.y + s.sha_b[2] * n.z + s.sha_b[3]) +
-                   ((s.shb_b[0] * bx + s.shb_b[1] * by + s.shb_b[2] * bz + s.shb_b[3] * bw) + s.shc[2] * cc);
-        const float kd = (1.0f - metallic) * INV_PI_F;
-        out = v3(albedo.x * kd * ir, albedo.y * kd * ig, albedo.z * kd * ib);
-    }
-
-    // ---- clustered point lights :159-186.  ClusterIndex(uv, z), clustered.hlsli:45-60;
-    // logf (not the fast intrinsic): the result is truncated to the slice index.
-    int sx = (int)floorf(u * (float)PBR_CLUSTER_X);
-    int sy = (int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y);
-    const float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
-    int sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
-    sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
-    sy = clampi(sy, 0, PBR_CLUSTER_Y - 1);
-    sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
-
-    // Per-pixel invariants of brdf() (brdf.hlsli:47-67).  With Kd = (1-F)(1-m), F = F0 + (1-F0) f5:
-    //   Kd*albedo/pi = [(1-F0)(1-m) albedo/pi] * (1 - f5)                      -> Kdiff * (1 - f5)
-    //   F*D*G/max(4 NdotL NdotV,1e-4) = F * [a^4/pi * gV] * NdotL / (T * A * B)  with
-    //   T = max(t^2, 1e-6/pi), A = NdotL(1-k)+k (>= 1/8, the shader's max(.,1e-6) never binds), B = max(4 NdotL NdotV, 1e-4)
-    // so one v_rcp serves D, G and the 4 NdotL NdotV denominator, and one serves the attenuation.
-    const float ra = roughness * roughness;
-    const float a4 = ra * ra;
-    const float a4m1 = a4 - 1.0f;
-    const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
-    const float one_k = 1.0f - k;
-    const float gv = NdotV / fmaxf(NdotV * one_k + k, EPSILON_F);
-    const float spec_pix = a4 * INV_PI_F * gv;
-    const float ndv4 = 4.0f * NdotV;
-    const float one_m = 1.0f - metallic;
-    const V3 omF0 = v3(1.0f - F0.x, 1.0f - F0.y, 1.0f - F0.z);
-    const V3 Kdiff = v3(omF0.x * one_m * albedo.x * INV_PI_F, omF0.y * one_m * albedo.y * INV_PI_F, omF0.z * one_m * albedo.z * INV_PI_F);
-    const float t_floor = EPSILON_F * INV_PI_F;
-    V3 pl = v3(0.0f, 0.0f, 0.0f);
-
-    auto light = [&](int li) {
-        li = min(li, n_lights - 1);   // never index past the staged table
-        const LightLds& r = llds[li];
-        const float4 q0 = r.pos_c0, q1 = r.col_c1;
-        const float c2 = r.c2.x;
-        const V3 dir = v3(q0.x - pos.x, q0.y - pos.y, q0.z - pos.z);
-        const float d2 = dot3(dir, dir);
-        const float invd = rsq(d2);
-        const float dist = d2 * invd;
-        const float NdL = dot3(n, dir) * invd;
-        const float NdotL = fmaxf(NdL, 0.0f);
-        const float LdV = dot3(dir, view) * invd;
-        // |L + V|^2 = 2 + 2 L.V ; N.H = (N.L + N.V) / |L + V|
-        const float NdotH = fmaxf((NdL + NdV) * rsq(fmaxf(2.0f + 2.0f * LdV, 1e-12f)), 0.0f);
-        const float t = (NdotH * NdotH) * a4m1 + 1.0f;
-        const float T = fmaxf(t * t, t_floor);
-        const float A = NdotL * one_k + k;
-        const float B = fmaxf(ndv4 * NdotL, 0.0001f);
-        const float spec = spec_pix * NdotL * rcp(T * A * B);
-        const float Q = fmaxf(q0.w + q1.w * dist + c2 * d2, EPSILON_F);
-        const float X = NdotL * rcp(Q);   // attenuation * NdotL
-        const float fm = fmaxf(1.0f - NdotL, EPSILON_F);   // fresnel on NdotL (Q3)
-        const float fm2 = fm * fm;
-        const float f5 = fm2 * fm2 * fm;
-        const float omf5 = 1.0f - f5;
-        const float Fx = F0.x + omF0.x * f5, Fy = F0.y + omF0.y * f5, Fz = F0.z + omF0.z * f5;
-        pl.x += (Kdiff.x * omf5 + Fx * spec) * (q1.x * X);
-        pl.y += (Kdiff.y * omf5 + Fy * spec) * (q1.y * X);
-        pl.z += (Kdiff.z * omf5 + Fz * spec) * (q1.z * X);
-    };
-
-    if (n_lights > 0) {
-        if (STAGED_LISTS) {
-            const uint16_t* my = lists + (((sy - tile_y0) * tiles_x + (sx - tile_x0)) * PBR_CLUSTER_Z + sz) * LIST_STRIDE_U16;
-            const int nl = my[0];
-            // two lights per trip: both index reads and both record reads are in flight together
-            int i = 0;
-            for (; i + 1 < nl; i += 2) {
-                const uint32_t pair = *reinterpret_cast<const uint32_t*>(my + 2 + i);   // i even -> 4-byte aligned
-                light((int)(pair & 0xFFFFu));
-                light((int)(pair >> 16));
-            }
-            if (i < nl) light((int)my[2 + i]);
-        } else {
-            const pbr_cluster* cl = p.clusters + (sz + sx * PBR_CLUSTER_Z + sy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
-            const int nl = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
-            for (int i = 0; i < nl; i++) light(max(cl->LightIndex[i], 0));
-        }
-    }
-
-    // ---- EnvironmentSpecular part 2: filter the taps fetched above
-    {
-        auto bil = [](const H4x2& r0, const H4x2& r1, float fx, float fy) {
-            const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-            const float tr = (float)r0.a.x * wx0 + (float)r0.b.x * fx, br = (float)r1.a.x * wx0 + (float)r1.b.x * fx;
-            const float tg = (float)r0.a.y * wx0 + (float)r0.b.y * fx, bg = (float)r1.a.y * wx0 + (float)r1.b.y * fx;
-            const float tb = (float)r0.a.z * wx0 + (float)r0.b.z * fx, bb = (float)r1.a.z * wx0 + (float)r1.b.z * fx;
-            return v3(tr * wy0 + br * fy, tg * wy0 + bg * fy, tb * wy0 + bb * fy);
-        };
-        const V3 ea = bil(e00, e01, e0fx, e0fy);
-        const V3 eb = bil(e10, e11, e1fx, e1fy);
-        const float w0 = 1.0f - env_f;
-        const V3 envc = v3(ea.x * w0 + eb.x * env_f, ea.y * w0 + eb.y * env_f, ea.z * w0 + eb.z * env_f);
-        const H2 l00 = lsel0 ? lt0.b : lt0.a, l10 = lsel1 ? lt0.b : lt0.a;
-        const H2 l01 = lsel0 ? lt1.b : lt1.a, l11 = lsel1 ? lt1.b : lt1.a;
-        const float wx0 = 1.0f - lfx, wy0 = 1.0f - lfy;
-        const float la = ((float)l00.x * wx0 + (float)l10.x * lfx) * wy0 + ((float)l01.x * wx0 + (float)l11.x * lfx) * lfy;
-        const float lb = ((float)l00.y * wx0 + (float)l10.y * lfx) * wy0 + ((float)l01.y * wx0 + (float)l11.y * lfx) * lfy;
+        const H2 l00 = x0 != xb ? lt0.b : lt0.a, l10 = x1 != xb ? lt0.b : lt0.a;
+        const H2 l01 = x0 != xb ? lt1.b : lt1.a, l11 = x1 != xb ? lt1.b : lt1.a;
+        const float wx0 = 1.0f - cx.f, wy0 = 1.0f - cy.f;
+        const float la = ((float)l00.x * wx0 + (float)l10.x * cx.f) * wy0 + ((float)l01.x * wx0 + (float)l11.x * cx.f) * cy.f;
+        const float lb = ((float)l00.y * wx0 + (float)l10.y * cx.f) * wy0 + ((float)l01.y * wx0 + (float)l11.y * cx.f) * cy.f;
         out.x += envc.x * (F0.x * la + lb);
         out.y += envc.y * (F0.y * la + lb);
         out.z += envc.z * (F0.z * la + lb);
     }
-    out = out + pl;
-    // emission (Q1: the directional light of :144-156 is computed by the reference but never added)
-    out = out + albedo * emission;
+#endif
     store_h4(p.hdr + 4 * ((size_t)py * p.hdr_pitch + px), f4(out.x, out.y, out.z, 1.0f));
 }
 
 // grid (ceil(w/256), ceil(h/SHADE_ROWS)), block 256.
-// dynamic LDS: n_lights * 48 B light records, then (STAGED_LISTS) max_clusters * 68 B of light lists.
-template <bool STAGED_LISTS>
-__global__ __launch_bounds__(SHADE_BLOCK) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters) {
+// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 68 B of light lists.
+template <bool STAGED_LISTS, int LSTRIDE>
+#ifndef SHADE_MIN_WAVES
+#define SHADE_MIN_WAVES 5   // 96 VGPRs, no spills: best of 4..8 measured (tools_probe_shade.py)
+#endif
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters) {
     extern __shared__ float4 lds_raw[];
-    LightLds* llds = reinterpret_cast<LightLds*>(lds_raw);
-    uint16_t* lists = reinterpret_cast<uint16_t*>(llds + n_lights);
+    float* llds = reinterpret_cast<float*>(lds_raw);
+    uint16_t* lists = reinterpret_cast<uint16_t*>(llds + LIGHT_PLANES * LSTRIDE);
     for (int i = threadIdx.x; i < n_lights; i += SHADE_BLOCK) {
         const pbr_light l = p.lights[i];
-        LightLds r;
-        r.pos_c0 = make_float4(l.Position[0], l.Position[1], l.Position[2], l.C0);
-        r.col_c1 = make_float4(l.Color[0] * l.Intensity, l.Color[1] * l.Intensity, l.Color[2] * l.Intensity, l.C1);
-        r.c2 = make_float4(l.C2, 0.0f, 0.0f, 0.0f);
-        llds[i] = r;
+        llds[0 * LSTRIDE + i] = l.Position[0];
+        llds[1 * LSTRIDE + i] = l.Position[1];
+        llds[2 * LSTRIDE + i] = l.Position[2];
+        llds[3 * LSTRIDE + i] = l.Color[0] * l.Intensity;
+        llds[4 * LSTRIDE + i] = l.Color[1] * l.Intensity;
+        llds[5 * LSTRIDE + i] = l.Color[2] * l.Intensity;
+        llds[6 * LSTRIDE + i] = l.C0;
+        llds[7 * LSTRIDE + i] = l.C1;
+        llds[8 * LSTRIDE + i] = l.C2;
     }
     const uint32_t bx0 = blockIdx.x * SHADE_BLOCK;
     const uint32_t y_begin = blockIdx.y * SHADE_ROWS;
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_deferred_shade(ShadeParams p, i
     __syncthreads();
     const uint32_t px = bx0 + threadIdx.x;
     if (px >= p.w) return;
-    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS>(p, llds, lists, tile_x0, tile_y0, tiles_x, n_lights, px, py);
+    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE>(p, llds, lists, tile_x0, tile_y0, tiles_x, n_lights, px, py);
 }
 
 extern "C" {
@@ -410,9 +421,13 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
     const uint32_t span_y = (uint32_t)((uint64_t)(SHADE_ROWS - 1) * PBR_CLUSTER_Y / tile->full_h) + 2;
     const bool staged = num_lights > 0 && span_x * span_y <= (uint32_t)MAX_STAGED_TILES;
     const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
-    const size_t lds = (size_t)num_lights * sizeof(LightLds) + (size_t)max_clusters * LIST_STRIDE_U16 * sizeof(uint16_t);
-    if (staged) hipLaunchKernelGGL(k_deferred_shade<true>, grid, dim3(SHADE_BLOCK), lds, ctx->stream, p, num_lights, max_clusters);
-    else hipLaunchKernelGGL(k_deferred_shade<false>, grid, dim3(SHADE_BLOCK), lds, ctx->stream, p, num_lights, 0);
+    const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
+    const size_t lds = (size_t)LIGHT_PLANES * lstride * sizeof(float) + (size_t)max_clusters * LIST_STRIDE_U16 * sizeof(uint16_t);
+    const dim3 blk(SHADE_BLOCK);
+    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters);
+    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters);
+    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257>), grid, blk, lds, ctx->stream, p, num_lights, 0);
+    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1>), grid, blk, lds, ctx->stream, p, num_lights, 0);
     return launched(ctx, "k_deferred_shade");
 }
 
