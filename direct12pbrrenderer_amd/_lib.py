@@ -44,6 +44,7 @@ SIGNATURES = {
     "pbr_bloom_upsample_add": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp]),
     "pbr_bloom_merge": (_int, [_vp, _vp, _u32, _vp, _u32, _u32]),
     "pbr_bloom": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32]),
+    "pbr_bloom_histogram": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, C.POINTER(_u32 * 4), _f32, _f32, _vp]),
     "pbr_lum_histogram": (_int, [_vp, _vp, _u32, _u32, _u32, _f32, _f32, _vp]),
     "pbr_lum_average": (_int, [_vp, _vp, _u32, _f32, _f32, _f32, _vp]),
     "pbr_tonemap": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _u32]),

@@ -156,6 +156,13 @@ class PbrContext:
     def bloom(self, hdr, w, h, pitch, chain_a, chain_b, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE):
         self._check(self.lib.pbr_bloom(self.h, _ptr(hdr), w, h, pitch, _ptr(chain_a), _ptr(chain_b), threshold, knee))
 
+    def bloom_histogram(self, hdr, w, h, pitch, chain_a, chain_b, rect, hist, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE,
+                        min_log=MIN_LOG_LUMINANCE, inv_range=INV_LOG_LUMINANCE_RANGE):
+        """bloom + luminance histogram of rect=(x,y,w,h) in one pass (adds into hist)."""
+        r = (C.c_uint32 * 4)(*[int(v) for v in rect])
+        self._check(self.lib.pbr_bloom_histogram(self.h, _ptr(hdr), w, h, pitch, _ptr(chain_a), _ptr(chain_b), threshold, knee,
+                                                 C.byref(r), min_log, inv_range, _ptr(hist)))
+
     def lum_histogram(self, hdr, w, h, pitch, hist, min_log=MIN_LOG_LUMINANCE, inv_range=INV_LOG_LUMINANCE_RANGE):
         self._check(self.lib.pbr_lum_histogram(self.h, _ptr(hdr), w, h, pitch, min_log, inv_range, _ptr(hist)))
 

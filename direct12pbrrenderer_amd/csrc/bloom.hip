@@ -128,6 +128,77 @@ __global__ __launch_bounds__(256) void k_blur_v(const pbr_half* __restrict__ in,
     }
 }
 
+// ---------------------------------------------------------------- final three dispatches fused
+// A0 = V(B0) (blur_vertical.hlsl), S += A0 (bloom_merge.hlsl) and — optionally — the luminance
+// histogram of the merged pixel (hdr_luminance_histogram.hlsl:23-59), in one pass over the frame:
+// A0 is never written to HBM (nobody reads it afterwards) and the histogram pass no longer re-reads
+// the HDR buffer.  Every intermediate is rounded exactly where the separate dispatches round
+// (A0 to fp16, then the fp16 sum), so the HDR result is bit-identical to the unfused chain.
+// Persistent blocks walk 64x16 tiles so the per-wave LDS histograms are flushed once per block.
+__device__ __forceinline__ uint32_t luminance_bin_exact(float r, float g, float b, float min_log, float inv_range) {
+    const float lum = (r * 0.2126f + g * 0.7152f) + b * 0.0722f;
+    if (lum < EPSILON_F) return 0u;
+    const float l = saturatef((log2f(lum) - min_log) * inv_range);
+    return (uint32_t)floorf(l * 254.0f + 1.0f);
+}
+
+template <bool HIST>
+__global__ __launch_bounds__(256) void k_blur_v_merge(const pbr_half* __restrict__ in, int w, int h, float tx, float ty,
+                                                       pbr_half* __restrict__ hdr, int pitch, int tiles_x, int tiles_y,
+                                                       int hx0, int hy0, int hx1, int hy1, float min_log, float inv_range,
+                                                       uint32_t* __restrict__ hist) {
+    __shared__ float4 smp[VT_R + 8][VT_W];
+    __shared__ uint32_t sh_hist[HIST ? 4 : 1][HIST ? PBR_HISTOGRAM_BINS : 1];
+    const int tid = threadIdx.y * VT_W + threadIdx.x;
+    if (HIST) {
+        for (int i = tid; i < 4 * PBR_HISTOGRAM_BINS; i += 256) (&sh_hist[0][0])[i] = 0u;
+    }
+    const int n_tiles = tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int x = (tile % tiles_x) * VT_W + threadIdx.x;
+        const int y0 = (tile / tiles_x) * VT_R;
+        const bool top_edge = (y0 & 255) == 0;
+        const bool bot_edge = ((y0 + VT_R) & 255) == 0;
+        const float uvx = ((float)x + 0.5f) * tx;
+        __syncthreads();   // previous tile's reads of smp are done (and the histogram clear on the first trip)
+        for (int r = threadIdx.y; r < VT_R + 8; r += 4) {
+            const int j = y0 - 4 + r;
+            float vy;
+            if (r < 4 && top_edge) vy = fmaxf(((float)(j + 4) + 0.5f) * ty - 4.0f * ty, 0.0f);
+            else if (r >= VT_R + 4 && bot_edge) vy = fminf(((float)(j - 4) + 0.5f) * ty + 4.0f * ty, 1.0f);
+            else vy = ((float)j + 0.5f) * ty;
+            smp[r][threadIdx.x] = to4(sample_2d_h4(in, w, h, w, uvx, vy));
+        }
+        __syncthreads();
+        if (x < w) {
+            for (int r = threadIdx.y; r < VT_R; r += 4) {
+                const int y = y0 + r;
+                if (y >= h) break;
+                F4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                for (int i = 0; i < 9; i++) v = v + from4(smp[r + i][threadIdx.x]) * c_gauss[i];
+                // A0 texel as the separate pass would have stored it
+                H4 a0;
+                a0.x = (h16)v.x; a0.y = (h16)v.y; a0.z = (h16)v.z; a0.w = (h16)v.w;
+                pbr_half* px = hdr + 4 * ((size_t)y * pitch + x);
+                const F4 s = load_h4(px);
+                H4 o;
+                o.x = (h16)(s.x + (float)a0.x); o.y = (h16)(s.y + (float)a0.y); o.z = (h16)(s.z + (float)a0.z); o.w = (h16)(s.w + (float)a0.w);
+                *reinterpret_cast<H4*>(px) = o;
+                if (HIST) {
+                    if (x >= hx0 && x < hx1 && y >= hy0 && y < hy1)
+                        atomicAdd(&sh_hist[threadIdx.y][luminance_bin_exact((float)o.x, (float)o.y, (float)o.z, min_log, inv_range)], 1u);
+                }
+            }
+        }
+    }
+    if (HIST) {
+        __syncthreads();
+        const uint32_t s = (sh_hist[0][tid] + sh_hist[1][tid]) + (sh_hist[2][tid] + sh_hist[3][tid]);
+        if (s) atomicAdd(&hist[tid], s);
+    }
+}
+
 // ---------------------------------------------------------------- bloom_merge.hlsl:7-11
 __global__ __launch_bounds__(256) void k_bloom_merge(pbr_half* __restrict__ hdr, int pitch, const pbr_half* __restrict__ in, int w, int h) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -191,13 +262,28 @@ pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pb
     return launched(ctx, "k_bloom_merge");
 }
 
-// BloomPass::Execute (DeferredPipeline.cpp:400-570; schedule comment :379-399)
-pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
-                     pbr_half* A, pbr_half* B, float threshold, float knee) {
-    if (!ctx) return PBR_ERR_INVALID;
+static pbr_status bloom_final(pbr_ctx* ctx, const pbr_half* b0, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                              const uint32_t* hist_rect, float min_log, float inv_range, uint32_t* hist256) {
+    const float tx = 1.0f / (float)w, ty = 1.0f / (float)h;
+    const int tiles_x = (int)((w + VT_W - 1) / VT_W), tiles_y = (int)((h + VT_R - 1) / VT_R);
+    int blocks = tiles_x * tiles_y;
+    if (blocks > 2048) blocks = 2048;
+    if (hist256) {
+        hipLaunchKernelGGL(k_blur_v_merge<true>, dim3(blocks), dim3(VT_W, 4), 0, ctx->stream, b0, (int)w, (int)h, tx, ty, hdr, (int)pitch, tiles_x, tiles_y,
+                           (int)hist_rect[0], (int)hist_rect[1], (int)(hist_rect[0] + hist_rect[2]), (int)(hist_rect[1] + hist_rect[3]), min_log, inv_range, hist256);
+    } else {
+        hipLaunchKernelGGL(k_blur_v_merge<false>, dim3(blocks), dim3(VT_W, 4), 0, ctx->stream, b0, (int)w, (int)h, tx, ty, hdr, (int)pitch, tiles_x, tiles_y,
+                           0, 0, 0, 0, 0.0f, 0.0f, (uint32_t*)nullptr);
+    }
+    return launched(ctx, "k_blur_v_merge");
+}
+
+static pbr_status bloom_impl(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch, pbr_half* A, pbr_half* B,
+                             float threshold, float knee, const uint32_t* hist_rect, float min_log, float inv_range, uint32_t* hist256) {
     PBR_REQUIRE(ctx, hdr && A && B, "pbr_bloom: null pointer");
     // BloomStep < CalculateMaxMipLevels (DeferredPipeline.cpp:343): every level must be >= 1 texel
     PBR_REQUIRE(ctx, (w >> (PBR_BLOOM_MIPS - 1)) >= 1 && (h >> (PBR_BLOOM_MIPS - 1)) >= 1, "pbr_bloom: image too small for 5 mips");
+    PBR_REQUIRE(ctx, w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom: bad size");
     auto a = [&](uint32_t l) { return A + 4 * pbr_bloom_level_offset(w, h, l); };
     auto b = [&](uint32_t l) { return B + 4 * pbr_bloom_level_offset(w, h, l); };
     auto W = [&](uint32_t l) { return w >> l; };
@@ -215,8 +301,26 @@ pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32
         if ((r = pbr_blur_v(ctx, b(up), W(up), H(up), a(up), W(up), H(up)))) return r;
     }
     if ((r = pbr_blur_h(ctx, a(1), W(1), H(1), b(0), w, h))) return r;
-    if ((r = pbr_blur_v(ctx, b(0), w, h, a(0), w, h))) return r;
-    return pbr_bloom_merge(ctx, hdr, pitch, a(0), w, h);
+    // A0 = V(B0); S += A0 [; histogram(S)] in one pass — chain A level 0 is not materialised
+    return bloom_final(ctx, b(0), hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
+}
+
+// BloomPass::Execute (DeferredPipeline.cpp:400-570; schedule comment :379-399)
+pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                     pbr_half* A, pbr_half* B, float threshold, float knee) {
+    if (!ctx) return PBR_ERR_INVALID;
+    return bloom_impl(ctx, hdr, w, h, pitch, A, B, threshold, knee, nullptr, 0.0f, 0.0f, nullptr);
+}
+
+// BloomPass::Execute followed by the luminance-histogram dispatch of AutoExposurePass::Execute
+// (DeferredPipeline.cpp:276-298) on the pixels of `rect` = {x, y, w, h} of the bloomed image.
+pbr_status pbr_bloom_histogram(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                               pbr_half* A, pbr_half* B, float threshold, float knee,
+                               const uint32_t rect[4], float min_log, float inv_range, uint32_t* hist256) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, rect && hist256, "pbr_bloom_histogram: null pointer");
+    PBR_REQUIRE(ctx, rect[2] >= 1 && rect[3] >= 1 && rect[0] + rect[2] <= w && rect[1] + rect[3] <= h, "pbr_bloom_histogram: rect outside the image");
+    return bloom_impl(ctx, hdr, w, h, pitch, A, B, threshold, knee, rect, min_log, inv_range, hist256);
 }
 
 }  // extern "C"

@@ -141,6 +141,11 @@ class DeferredFrame:
         s = self.spec
         self.ctx.lum_histogram(self._hdr_interior_ptr(), s.w, s.h, s.ew, self.hist)
 
+    def bloom_histogram(self):
+        """Bloom with the interior-tile luminance histogram accumulated in its final kernel."""
+        s = self.spec
+        self.ctx.bloom_histogram(self.hdr, s.ew, s.eh, s.ew, self.chain_a, self.chain_b, (s.ix, s.iy, s.w, s.h), self.hist)
+
     def average(self):
         s = self.spec
         self.ctx.lum_average(self.hist, s.full_w * s.full_h, float(self.g.DeltaTime), self.avg)
@@ -153,8 +158,7 @@ class DeferredFrame:
         """One frame: every per-frame dispatch of the reference, in the frame graph's order."""
         self.clustered()
         self.shade()
-        self.bloom()
-        self.histogram()
+        self.bloom_histogram()
         if self.allreduce is not None:
             self.allreduce(self.hist)
         self.average()

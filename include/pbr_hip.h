@@ -217,9 +217,19 @@ pbr_status pbr_bloom_upsample_add(pbr_ctx* ctx, const pbr_half* upper, uint32_t 
 pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pbr_half* in,
                            uint32_t w, uint32_t h);
 /* BloomPass::Execute (DeferredPipeline.cpp:400-570), all 16 dispatches.  chain_a / chain_b:
- * pbr_bloom_chain_texels(w,h) half4 texels each (BloomMipchain / BloomTempTexture). */
+ * pbr_bloom_chain_texels(w,h) half4 texels each (BloomMipchain / BloomTempTexture).  The last
+ * three dispatches (V blur of B[0], merge) run as ONE kernel: level 0 of chain_a is an
+ * intermediate nobody reads afterwards and is NOT written; hdr is bit-identical to the unfused
+ * sequence of stage calls. */
 pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                      pbr_half* chain_a, pbr_half* chain_b, float threshold, float knee);
+
+/* pbr_bloom + the luminance histogram (pbr_lum_histogram) of rect = {x, y, w, h} of the bloomed
+ * image, accumulated inside the final bloom kernel (saves one full read of the HDR buffer).
+ * ADDS into hist256 like the separate pass. */
+pbr_status pbr_bloom_histogram(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                               pbr_half* chain_a, pbr_half* chain_b, float threshold, float knee,
+                               const uint32_t rect[4], float min_log, float inv_range, uint32_t* hist256);
 
 /* hdr_luminance_histogram.hlsl:23-59 (DeferredPipeline.cpp:276-298): ADDS into hist256. */
 pbr_status pbr_lum_histogram(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h,

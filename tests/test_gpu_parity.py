@@ -270,9 +270,42 @@ def test_bloom_chain_vs_golden_every_mip(ctx, orc, golden):
     for l in range(5):
         la, lb = _levels(ga, 128, 72)[l], _levels(gb_, 128, 72)[l]
         wa, wb = _levels(golden["bloom_chain_a"], 128, 72)[l], _levels(golden["bloom_chain_b"], 128, 72)[l]
-        assert np.array_equal(la.view(np.uint16), wa.view(np.uint16)), f"chain A level {l}"
+        if l > 0:   # pbr_bloom fuses V(B0) + merge: A[0] is an intermediate it never materialises
+            assert np.array_equal(la.view(np.uint16), wa.view(np.uint16)), f"chain A level {l}"
         assert np.array_equal(lb.view(np.uint16), wb.view(np.uint16)), f"chain B level {l}"
     assert np.array_equal(to_np_half(hdr).view(np.uint16), golden["bloom_hdr"].view(np.uint16))
+    # the unfused tail (stage calls) produces A[0] and the same HDR
+    hdr2 = dev_half(ctx, img)
+    a0 = ctx.zeros((72, 128, 4), torch.float16)
+    b0 = gb_[: 128 * 72].reshape(72, 128, 4)
+    ctx.blur_v(dev_half(ctx, b0), 128, 72, a0, 128, 72)
+    assert np.array_equal(to_np_half(a0).view(np.uint16), _levels(golden["bloom_chain_a"], 128, 72)[0].view(np.uint16))
+    ctx.bloom_merge(hdr2, 128, a0, 128, 72)
+    assert np.array_equal(to_np_half(hdr2).view(np.uint16), golden["bloom_hdr"].view(np.uint16))
+
+
+def test_bloom_histogram_fused_equals_separate(ctx, orc):
+    # 300x170 (ragged tiles), histogram of an interior rectangle only (multi-GPU apron case)
+    img = synth.hdr_noise_image(304, 176, seed=21)
+    rect = (16, 32, 256, 112)
+    hdr_a, hdr_b = dev_half(ctx, img), dev_half(ctx, img)
+    ca, cb = ctx.alloc_bloom_chain(304, 176), ctx.alloc_bloom_chain(304, 176)
+    hist_a = ctx.zeros((256,), torch.int32)
+    ctx.bloom_histogram(hdr_a, 304, 176, 304, ca, cb, rect, hist_a)
+    ctx.bloom(hdr_b, 304, 176, 304, ca, cb)
+    got = to_np_half(hdr_a)
+    assert np.array_equal(got.view(np.uint16), to_np_half(hdr_b).view(np.uint16))
+    want_hdr = img.copy()
+    orc.bloom(want_hdr)
+    assert np.array_equal(got.view(np.uint16), want_hdr.view(np.uint16))
+    x, y, w, h = rect
+    want_hist = orc.lum_histogram(np.ascontiguousarray(want_hdr[y:y + h, x:x + w]))
+    got_hist = hist_a.cpu().numpy().view(np.uint32)
+    assert got_hist.sum() == w * h
+    assert np.abs(got_hist.astype(np.int64) - want_hist.astype(np.int64)).sum() <= 2
+    hist_b = ctx.zeros((256,), torch.int32)
+    ctx.lum_histogram(hdr_b.data_ptr() + 8 * (y * 304 + x), w, h, 304, hist_b)
+    assert np.array_equal(got_hist, hist_b.cpu().numpy().view(np.uint32))
 
 
 def test_bloom_too_small_is_rejected(ctx):
