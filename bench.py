@@ -59,6 +59,24 @@ def build_ibl(ctx):
     return lut, env, sh.cpu().numpy()
 
 
+def pmc_traffic(kernel_prefix, workload_px):
+    """HBM-side bytes per launch of `kernel_prefix` from the committed rocprofv3 --pmc summary
+    (profiles/pmc_traffic_latest.json, produced by tools/summarize_pmc.py from separate FETCH_SIZE and
+    WRITE_SIZE passes).  Unit/correction per MI355X_MICROARCH.md: both counters are in KiB and gfx950's
+    FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled.  None if no matching profile."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    if d.get("_workload_pixels") != workload_px:
+        return None
+    for k, v in d.items():
+        if isinstance(v, dict) and kernel_prefix in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+    return None
+
+
 def time_stage(fn, iters, pre=None):
     """Average device time of `fn` in ms, HIP events on the stream the kernels run on
     (the ctx is bound to torch's current stream, so torch.cuda.Event sees them)."""
@@ -79,24 +97,30 @@ def time_stage(fn, iters, pre=None):
     return total / iters
 
 
-def cpu_baseline(g, lights, lut_np, env_np, width, height):
-    """The oracle ("port") on a bounded band of the same workload, all host threads, ~10-30 s."""
+def cpu_baseline(g, lights, lut_np, env_np, width, height, budget_s=12.0):
+    """The oracle ("port") on a bounded band of the same workload, all host threads.  A 64-row probe
+    sizes the band so the timed sample costs about `budget_s` seconds of CPU work (<= the whole frame)."""
     from oracle import binding as orc
-    rows = 128
-    y0 = (height - rows) // 2
-    gb = synth.gbuffer_tile(0, y0, width, rows, width, height)
-    cl = orc.cluster_build(g)
-    orc.cluster_cull(g, lights, cl)
-    t0 = time.perf_counter()
-    hdr, _ = orc.deferred_shade(g, Tile(0, y0, width, rows, width, height), gb, lut_np, env_np, ENV_SIZE, ENV_MIPS, cl, lights)
-    orc.bloom(hdr)
-    hist = orc.lum_histogram(hdr)
-    avg = orc.lum_average(hist, width * rows, 1.0 / 60.0, 0.18)
-    orc.tonemap(hdr, avg)
-    dt = time.perf_counter() - t0
+
+    def run(rows):
+        rows = max(16, min(height, rows) // 16 * 16)
+        y0 = (height - rows) // 2
+        gb = synth.gbuffer_tile(0, y0, width, rows, width, height)
+        cl = orc.cluster_build(g)
+        orc.cluster_cull(g, lights, cl)
+        t0 = time.perf_counter()
+        hdr, _ = orc.deferred_shade(g, Tile(0, y0, width, rows, width, height), gb, lut_np, env_np, ENV_SIZE, ENV_MIPS, cl, lights)
+        orc.bloom(hdr)
+        hist = orc.lum_histogram(hdr)
+        avg = orc.lum_average(hist, width * rows, 1.0 / 60.0, 0.18)
+        orc.tonemap(hdr, avg)
+        return rows, y0, time.perf_counter() - t0
+
+    rows, _, dt = run(64)
+    rows, y0, dt = run(int(rows * budget_s / max(dt, 1e-3)))
     return {"value": round(width * rows / dt / 1e6, 4), "unit": "Mpixel/s", "cores": orc.num_threads(), "kind": "port",
             "sample": f"{width}x{rows} band (rows {y0}..{y0 + rows - 1}) of the {width}x{height} frame: shade(256 lights+IBL)"
-                      f"+bloom+histogram+average+tonemap, oracle/pbr_oracle.cpp with OpenMP, {dt:.1f} s"}
+                      f"+bloom+histogram+average+tonemap, oracle/pbr_oracle.cpp with OpenMP on {orc.num_threads()} threads, {dt:.1f} s"}
 
 
 def main():
@@ -197,9 +221,10 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": {"shade": "k_deferred_shade", "bloom+histogram": "bloom chain (14 launches, histogram fused)",
                                                      "tonemap": "k_tonemap"}[dom],
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                           "traffic": None, "stage_ms": {k: v["ms"] for k, v in kern.items()},
+                           "traffic": pmc_traffic("k_deferred_shade", spec.ew * spec.eh) if dom == "shade" else None, "stage_ms": {k: v["ms"] for k, v in kern.items()},
                            "stage_GBps": {k: v["GB/s"] for k, v in kern.items()},
-                           "note": "shade with 256 clustered lights is FP32-VALU-bound (SURVEY D6): its HBM fraction is structurally low"}
+                           "note": "shade with 256 clustered lights is FP32-VALU-bound (SURVEY D6): its HBM fraction is structurally low; "
+                                   "traffic (when present) is the committed rocprofv3 PMC figure for this workload, IBL gathers served by L2/MALL included"}
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(g, lights, lut.cpu().view(torch.int16).numpy().view(np.float16),

@@ -267,7 +267,7 @@ static pbr_status bloom_final(pbr_ctx* ctx, const pbr_half* b0, pbr_half* hdr, u
     const float tx = 1.0f / (float)w, ty = 1.0f / (float)h;
     const int tiles_x = (int)((w + VT_W - 1) / VT_W), tiles_y = (int)((h + VT_R - 1) / VT_R);
     int blocks = tiles_x * tiles_y;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1280) blocks = 1280;   // 5 blocks (28.5 KB LDS each) resident per CU x 256 CUs: one full wave of persistent blocks
     if (hist256) {
         hipLaunchKernelGGL(k_blur_v_merge<true>, dim3(blocks), dim3(VT_W, 4), 0, ctx->stream, b0, (int)w, (int)h, tx, ty, hdr, (int)pitch, tiles_x, tiles_y,
                            (int)hist_rect[0], (int)hist_rect[1], (int)(hist_rect[0] + hist_rect[2]), (int)(hist_rect[1] + hist_rect[3]), min_log, inv_range, hist256);

@@ -1,0 +1,92 @@
+"""Tile + apron path on real hardware: two ranks (both on cuda:0 — the test box has one GPU; the
+collective is gloo on the host copy of the 256-bin histogram) against the single-GPU frame.
+What runs on the GPU is exactly what bench.py runs per rank: DeferredFrame on an apron-extended
+tile with global-pixel addressing, interior histogram, full-frame PixelCount."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import common
+
+pytestmark = pytest.mark.gpu
+TILE_W, TILE_H, N_LIGHTS = 512, 288, 256
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _frame(ctx, spec, ibl_dev, sh, allreduce=None):
+    from direct12pbrrenderer_amd.pipeline import DeferredFrame
+    lut, env = ibl_dev
+    cam, g, lights, gb, _ = common.shade_scene(spec.ew, spec.eh, N_LIGHTS, sh, full=(spec.full_w, spec.full_h),
+                                               x0=spec.ex0, y0=spec.ey0, rough_min=48, coverage_mask=False)
+    fr = DeferredFrame(ctx, spec, g, lights, lut, common.LUT_RES, env, common.ENV_SIZE, common.ENV_MIPS, allreduce=allreduce)
+    fr.upload_gbuffer(gb)
+    fr.set_prev_luminance(0.18)
+    fr.render()
+    ctx.sync()
+    return fr
+
+
+def _ibl_dev(ctx, ibl):
+    sky, env, lut, sh = ibl
+    up = lambda a: ctx.upload(np.ascontiguousarray(a, dtype=np.float16).view(np.uint16)).view(torch.float16)
+    return up(lut), up(env)
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from direct12pbrrenderer_amd.api import PbrContext
+    from direct12pbrrenderer_amd.pipeline import tile_for_rank
+    from oracle import binding as orc
+    ibl = common.small_ibl(orc)
+    ctx = PbrContext(0)
+
+    def allreduce(hist):   # host-side gloo stand-in for the RCCL all-reduce of bench.py
+        ctx.sync()
+        t = hist.cpu()
+        dist.all_reduce(t)
+        hist.copy_(t)
+
+    spec = tile_for_rank(rank, world, TILE_W, TILE_H)
+    fr = _frame(ctx, spec, _ibl_dev(ctx, ibl), ibl[3], allreduce)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), hdr=fr.hdr_interior().view(np.uint16), ldr=fr.ldr_numpy(),
+             avg=fr.avg.cpu().numpy(), rect=np.array([spec.x0, spec.y0, spec.w, spec.h]))
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_with_apron_match_single_gpu_frame(ctx, ibl):
+    from direct12pbrrenderer_amd.pipeline import TileSpec
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        ranks = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
+    W, H = TILE_W * 2, TILE_H
+    fr = _frame(ctx, TileSpec(0, 0, W, H, W, H, 0), _ibl_dev(ctx, ibl), ibl[3])
+    full_hdr = fr.hdr_interior()
+    full_ldr = fr.ldr_numpy()
+    assert ranks[0]["avg"][0] == ranks[1]["avg"][0]                         # bit-identical exposure on every rank
+    assert ranks[0]["avg"][0] == pytest.approx(float(fr.avg.cpu()[0]), rel=1e-6)
+    for r in ranks:
+        x0, y0, w, h = r["rect"]
+        d_ulp = common.half_ulp_diff(r["hdr"].view(np.float16), full_hdr[y0:y0 + h, x0:x0 + w])
+        assert d_ulp.max() <= 2 and (d_ulp > 0).mean() < 2e-3, (d_ulp.max(), (d_ulp > 0).mean())
+        a, b = r["ldr"], full_ldr[y0:y0 + h, x0:x0 + w]
+        for k in range(3):
+            assert np.abs(((a >> (8 * k)) & 255).astype(np.int32) - ((b >> (8 * k)) & 255).astype(np.int32)).max() <= 1
