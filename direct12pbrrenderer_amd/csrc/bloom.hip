@@ -3,9 +3,9 @@
 // bloom_upsample_add.hlsl, bloom_merge.hlsl; schedule BloomPass::Execute,
 // DeferredPipeline.cpp:400-570).
 //
-// This translation unit is compiled with -ffp-contract=off and follows the shader's operation
-// order, so every stage is bit-identical to the CPU oracle on the same input (the path is
-// HBM-bound; un-fused multiplies cost nothing measurable).
+// This translation unit is compiled with -ffp-contract=off and follows the oracle's operation
+// order (fused multiply-adds only where the oracle writes fmaf: sampler lerps and the blur's
+// multiply-accumulate), so every stage is bit-identical to the CPU oracle on the same input.
 //
 // Layout / mapping for MI355X:
 //  * H passes keep the reference's 256-texel row groups (one 64-lane wave = 64 consecutive
@@ -71,7 +71,7 @@ __device__ __forceinline__ void blur_h_fill(float4* cache, const pbr_half* in, i
 __device__ __forceinline__ F4 gauss9(const float4* c) {
     F4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-    for (int i = 0; i < 9; i++) v = v + from4(c[i]) * c_gauss[i];
+    for (int i = 0; i < 9; i++) v = fma4(from4(c[i]), c_gauss[i], v);   // value += pixel * weight (fused mad)
     return v;
 }
 
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_blur_v(const pbr_half* __restrict__ in,
         if (y >= oh) break;
         F4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-        for (int i = 0; i < 9; i++) v = v + from4(smp[r + i][threadIdx.x]) * c_gauss[i];
+        for (int i = 0; i < 9; i++) v = fma4(from4(smp[r + i][threadIdx.x]), c_gauss[i], v);
         store_h4(out + 4 * ((size_t)y * ow + x), v);
     }
 }
@@ -176,14 +176,14 @@ __global__ __launch_bounds__(256) void k_blur_v_merge(const pbr_half* __restrict
                 if (y >= h) break;
                 F4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-                for (int i = 0; i < 9; i++) v = v + from4(smp[r + i][threadIdx.x]) * c_gauss[i];
+                for (int i = 0; i < 9; i++) v = fma4(from4(smp[r + i][threadIdx.x]), c_gauss[i], v);
                 // A0 texel as the separate pass would have stored it
                 H4 a0;
-                a0.x = (h16)v.x; a0.y = (h16)v.y; a0.z = (h16)v.z; a0.w = (h16)v.w;
+                a0.x = to_half_rn(v.x); a0.y = to_half_rn(v.y); a0.z = to_half_rn(v.z); a0.w = to_half_rn(v.w);
                 pbr_half* px = hdr + 4 * ((size_t)y * pitch + x);
                 const F4 s = load_h4(px);
                 H4 o;
-                o.x = (h16)(s.x + (float)a0.x); o.y = (h16)(s.y + (float)a0.y); o.z = (h16)(s.z + (float)a0.z); o.w = (h16)(s.w + (float)a0.w);
+                o.x = to_half_rn(s.x + (float)a0.x); o.y = to_half_rn(s.y + (float)a0.y); o.z = to_half_rn(s.z + (float)a0.z); o.w = to_half_rn(s.w + (float)a0.w);
                 *reinterpret_cast<H4*>(px) = o;
                 if (HIST) {
                     if (x >= hx0 && x < hx1 && y >= hy0 && y < hy1)
@@ -267,7 +267,7 @@ static pbr_status bloom_final(pbr_ctx* ctx, const pbr_half* b0, pbr_half* hdr, u
     const float tx = 1.0f / (float)w, ty = 1.0f / (float)h;
     const int tiles_x = (int)((w + VT_W - 1) / VT_W), tiles_y = (int)((h + VT_R - 1) / VT_R);
     int blocks = tiles_x * tiles_y;
-    if (blocks > 1280) blocks = 1280;   // 5 blocks (28.5 KB LDS each) resident per CU x 256 CUs: one full wave of persistent blocks
+    if (blocks > 1280) blocks = 1280;   // 5 blocks (24.6 + 4 KB LDS each) resident per CU x 256 CUs: one full wave of persistent blocks
     if (hist256) {
         hipLaunchKernelGGL(k_blur_v_merge<true>, dim3(blocks), dim3(VT_W, 4), 0, ctx->stream, b0, (int)w, (int)h, tx, ty, hdr, (int)pitch, tiles_x, tiles_y,
                            (int)hist_rect[0], (int)hist_rect[1], (int)(hist_rect[0] + hist_rect[2]), (int)(hist_rect[1] + hist_rect[3]), min_log, inv_range, hist256);

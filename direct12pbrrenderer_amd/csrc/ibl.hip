@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void k_brdf_lut(uint32_t res, pbr_half* __rest
     A = A / (float)PBR_SAMPLE_COUNT;
     B = B / (float)PBR_SAMPLE_COUNT;
     H2 o;
-    o.x = (h16)A;
-    o.y = (h16)B;
+    o.x = to_half_rn(A);
+    o.y = to_half_rn(B);
     *reinterpret_cast<H2*>(out + 2 * ((size_t)y * res + x)) = o;
 }
 

@@ -47,9 +47,16 @@ __device__ __forceinline__ F4 load_h4(const pbr_half* p) {
     H4 h = *reinterpret_cast<const H4*>(p);
     return f4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
 }
+// fp32 -> fp16 as the render-target write does it: the fp32 value is rounded to nearest-even half.
+// The asm barrier pins the fp32 value: without it hipcc may fold a preceding fma into
+// v_fma_mixlo_f16 (ONE rounding straight to half), which differs from fp32-then-half by an ulp.
+__device__ __forceinline__ h16 to_half_rn(float v) {
+    asm volatile("" : "+v"(v));
+    return (h16)v;   // v_cvt_f16_f32: RNE, overflow -> inf
+}
 __device__ __forceinline__ void store_h4(pbr_half* p, F4 v) {
     H4 h;
-    h.x = (h16)v.x; h.y = (h16)v.y; h.z = (h16)v.z; h.w = (h16)v.w;   // v_cvt_f16_f32: RNE, overflow -> inf
+    h.x = to_half_rn(v.x); h.y = to_half_rn(v.y); h.z = to_half_rn(v.z); h.w = to_half_rn(v.w);
     *reinterpret_cast<H4*>(p) = h;
 }
 struct alignas(4) H2 { h16 x, y; };
@@ -67,11 +74,17 @@ __device__ __forceinline__ BilinearCoord bilinear_coord(float u, int size) {
     c.f = x - fl;
     return c;
 }
+// a*s + b with one rounding — written explicitly so the result does not depend on -ffp-contract
+__device__ __forceinline__ F4 fma4(F4 a, float s, F4 b) {
+    return f4(__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z), __builtin_fmaf(a.w, s, b.w));
+}
+// sampler lerps: the far tap is fused onto the weighted near tap (same operation order as the oracle)
+__device__ __forceinline__ F4 lerp_x(F4 c0, F4 c1, float wx0, float fx) { return fma4(c1, fx, c0 * wx0); }
 __device__ __forceinline__ F4 bilerp(F4 c00, F4 c10, F4 c01, F4 c11, float fx, float fy) {
     float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    F4 top = c00 * wx0 + c10 * fx;
-    F4 bot = c01 * wx0 + c11 * fx;
-    return top * wy0 + bot * fy;
+    F4 top = lerp_x(c00, c10, wx0, fx);
+    F4 bot = lerp_x(c01, c11, wx0, fx);
+    return fma4(bot, fy, top * wy0);
 }
 // Texture2D<half4>.SampleLevel(LinearClamp, uv, 0)
 __device__ __forceinline__ F4 sample_2d_h4(const pbr_half* img, int w, int h, int pitch, float u, float v) {
@@ -186,7 +199,7 @@ __device__ __forceinline__ F4 cube_trilinear(Ptr data, uint32_t size, uint32_t m
     if (f == 0.0f || l1 == l0) return a;
     TexelT t1{data + 4 * cube_mip_offset(size, l1), (int)(size >> l1)};
     F4 b = cube_bilinear((int)(size >> l1), dir, t1);
-    return a * (1.0f - f) + b * f;
+    return fma4(b, f, a * (1.0f - f));
 }
 
 // ---- brdf.hlsli:71-114 --------------------------------------------------------------------------

@@ -131,11 +131,14 @@ static inline BilinearCoord bilinear_coord(float u, int size) {
     c.f = x - fl;
     return c;
 }
+// a*s + b with ONE rounding (explicit fmaf — the only fused operations of the arithmetic model:
+// the sampler's lerps and the blur's multiply-accumulate, i.e. HLSL `mad`)
+static inline F4 fma4(F4 a, float s, F4 b) { return f4(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z), fmaf(a.w, s, b.w)); }
 static inline F4 bilerp(F4 c00, F4 c10, F4 c01, F4 c11, float fx, float fy) {
     float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    F4 top = c00 * wx0 + c10 * fx;
-    F4 bot = c01 * wx0 + c11 * fx;
-    return top * wy0 + bot * fy;
+    F4 top = fma4(c10, fx, c00 * wx0);
+    F4 bot = fma4(c11, fx, c01 * wx0);
+    return fma4(bot, fy, top * wy0);
 }
 
 // Texture2D<half4>.SampleLevel(SamplerLinearClamp, uv, 0)
@@ -229,7 +232,7 @@ static inline F4 cube_trilinear(uint32_t size, uint32_t mips, V3 dir, float lod,
     F4 a = cube_bilinear((int)(size >> l0), dir, mt(l0));
     if (f == 0.0f || l1 == l0) return a;
     F4 b = cube_bilinear((int)(size >> l1), dir, mt(l1));
-    return a * (1.0f - f) + b * f;
+    return fma4(b, f, a * (1.0f - f));
 }
 
 struct CubeF32 {
@@ -887,7 +890,7 @@ static void blur_v_group(const uint16_t* in, int iw, int ih, float tx, float ty,
 }
 static inline F4 gauss9(const F4* cache_at_t) {   // cache_at_t = &Cache[gtid] (tap -4)
     F4 v = f4(0, 0, 0, 0);
-    for (int i = 0; i < 9; i++) v = v + cache_at_t[i] * GAUSS_WEIGHT[i];
+    for (int i = 0; i < 9; i++) v = fma4(cache_at_t[i], GAUSS_WEIGHT[i], v);   // value += pixel * weight as a fused mad
     return v;
 }
 }  // namespace

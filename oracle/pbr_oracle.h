@@ -12,8 +12,9 @@
  * therefore pinned only by analytic known-answer tests and by reading the shader source;
  * every function cites the reference lines it restates.
  *
- * Arithmetic model: fp32 throughout, no FMA contraction (-ffp-contract=off), libm
- * transcendentals, dot products evaluated left to right, normalize(v) = v * (1/sqrt(v.v)),
+ * Arithmetic model: fp32 throughout, no implicit FMA contraction (-ffp-contract=off); the
+ * only fused operations are written as explicit fmaf: the samplers' lerps and the blur's
+ * multiply-accumulate (HLSL `mad`).  libm transcendentals, dot products evaluated left to right, normalize(v) = v * (1/sqrt(v.v)),
  * lerp(a,b,t) = a + t*(b-a); D3D fixed-function behaviour is DEFINED here as:
  * bilinear/trilinear weights in full fp32 from texel coordinate u*w-0.5, clamp addressing,
  * seamless cube edges (out-of-face taps are re-projected onto the neighbouring face, a tap
