@@ -115,18 +115,37 @@ __global__ __launch_bounds__(256) void k_prefilter_env(const float* __restrict__
     const V3 T = normalize3_exact(cross3(N, up));
     const V3 Bt = cross3(N, T);
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, wsum = 0.0f;
-    for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
-        const float4 h = tab[i];
-        V3 H = normalize3(T * h.x + Bt * h.y + N * h.z);
-        float VdH = dot3(N, H);   // V = N
-        V3 L = normalize3(H * (2.0f * VdH) - N);
-        float NdotL = fmaxf(dot3(N, L), 0.0f);
+    if (roughness == 0.0f) {
+        // Roughness 0 (mip 0): sin(theta) is exactly 0 for every sample, so H, L, N.L, the LOD (0) and the
+        // fetched colour are the same 1 024 times.  Fetch once and replay only the accumulation, which keeps
+        // the reference's running-sum rounding (env_map_gen.hlsl:69-101) without 1 023 redundant fetches.
+        const float4 h = tab[0];
+        const V3 H = normalize3(T * h.x + Bt * h.y + N * h.z);
+        const float VdH = dot3(N, H);
+        const V3 L = normalize3(H * (2.0f * VdH) - N);
+        const float NdotL = fmaxf(dot3(N, L), 0.0f);
         if (NdotL > 0.0f) {
-            F4 c = cube_trilinear<CubeTexelF32>(sky, sky_size, sky_mips, L, h.w);
-            cr += c.x * NdotL;
-            cg += c.y * NdotL;
-            cb += c.z * NdotL;
-            wsum += NdotL;
+            const F4 c = cube_trilinear<CubeTexelF32>(sky, sky_size, sky_mips, L, 0.0f);
+            const float pr = c.x * NdotL, pg = c.y * NdotL, pb = c.z * NdotL;
+            for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
+                cr += pr; cg += pg; cb += pb;
+                wsum += NdotL;
+            }
+        }
+    } else {
+        for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
+            const float4 h = tab[i];
+            V3 H = normalize3(T * h.x + Bt * h.y + N * h.z);
+            float VdH = dot3(N, H);   // V = N
+            V3 L = normalize3(H * (2.0f * VdH) - N);
+            float NdotL = fmaxf(dot3(N, L), 0.0f);
+            if (NdotL > 0.0f) {
+                F4 c = cube_trilinear<CubeTexelF32>(sky, sky_size, sky_mips, L, h.w);
+                cr += c.x * NdotL;
+                cg += c.y * NdotL;
+                cb += c.z * NdotL;
+                wsum += NdotL;
+            }
         }
     }
     const float inv = 1.0f / wsum;   // wsum == 0 -> NaN like the reference's 0/0

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Times the BASELINE.json configs other than the bench.py headline (cfg4) on one MI355X:
+cfg1 LUT 256^2 / 512^2, cfg2 1080p shade with 1 point light (+ full frame), cfg3 512^2 prefilter (5 mips, 1 024 spp)
++ SH9, cfg5 one rank's share of the 8K frame (1920x2160 tile + 256-px apron).  One JSON line per config."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from direct12pbrrenderer_amd import scene, synth  # noqa: E402
+from direct12pbrrenderer_amd.api import PbrContext  # noqa: E402
+from direct12pbrrenderer_amd.pipeline import DeferredFrame, TileSpec  # noqa: E402
+from direct12pbrrenderer_amd.structs import ENV_MIPS  # noqa: E402
+
+ctx = PbrContext(0)
+out = []
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+    out.append(kw)
+
+
+# ---- cfg1: split-sum BRDF LUT
+for res in (256, 512):
+    buf = ctx.empty((res, res, 2), torch.float16)
+    ms = bench.time_stage(lambda: ctx.brdf_lut(res, out=buf), 10)
+    emit(config="cfg1", what=f"BRDF LUT {res}x{res}, 1024 spp", ms=round(ms, 4), Msamples_per_s=round(res * res * 1024 / ms / 1e3, 1),
+         Mtexels_per_s=round(res * res / ms / 1e3, 2))
+
+# ---- cfg3: prefilter + SH9 on the 512^2 cube
+sky_mips = 10
+sky = ctx.upload(synth.env_cube(512, sky_mips))
+ctx.cube_gen_mips(sky, 512, sky_mips)
+envbuf = ctx.prefilter_env(sky, 512, sky_mips, 512, ENV_MIPS)
+ms = bench.time_stage(lambda: ctx.prefilter_env(sky, 512, sky_mips, 512, ENV_MIPS, out=envbuf), 5)
+texels = 6 * sum((512 >> m) ** 2 for m in range(5))
+emit(config="cfg3", what="GGX prefilter 512^2 cube, 5 mips, 1024 spp", ms=round(ms, 3), Gsamples_per_s=round(texels * 1024 / ms / 1e6, 2),
+     Mtexels_per_s=round(texels / ms / 1e3, 2))
+shbuf = ctx.empty((28,), torch.float32)
+ms = bench.time_stage(lambda: ctx.sh9_project(sky, 512, sky_mips, out=shbuf), 10)
+emit(config="cfg3", what="SH9 projection of the 512^2 cube (quadrature, 25.2 MB in)", ms=round(ms, 4), GBps=round(6 * 512 * 512 * 16 / ms / 1e6, 1))
+ms = bench.time_stage(lambda: ctx.env_pad(envbuf, 512, ENV_MIPS), 10)
+emit(config="cfg3", what="env_pad (padded copy of the prefiltered chain)", ms=round(ms, 4))
+
+# ---- cfg2 / cfg5: frames
+lut, env, sh = bench.build_ibl(ctx)
+
+
+def frame_times(name, spec, n_lights, what):
+    cam = scene.Camera.reference_default(spec.full_w, spec.full_h)
+    g = scene.make_global(cam, spec.full_w, spec.full_h, sh_pack=sh, delta_time=1.0 / 60.0)
+    lights = synth.reference_scene_light() if n_lights == 1 else synth.lights_in_view_box(n_lights, cam)
+    fr = DeferredFrame(ctx, spec, g, lights, lut, 512, env, 512, ENV_MIPS)
+    fr.upload_gbuffer(synth.gbuffer_tile(spec.ex0, spec.ey0, spec.ew, spec.eh, spec.full_w, spec.full_h))
+    fr.set_prev_luminance(0.18)
+    fr.render()
+    shade = bench.time_stage(fr.shade, 20)
+    full = bench.time_stage(fr.render, 20)
+    ext, inner = spec.ew * spec.eh, spec.w * spec.h
+    emit(config=name, what=what, shade_ms=round(shade, 4), frame_ms=round(full, 4), shade_Mpixel_per_s=round(ext / shade / 1e3, 1),
+         shade_GBps_algorithmic=round(25.0 * ext / shade / 1e6, 1), frame_Mpixel_per_s_interior=round(inner / full / 1e3, 1),
+         extended_pixels=ext, interior_pixels=inner)
+
+
+frame_times("cfg2", TileSpec(0, 0, 1920, 1080, 1920, 1080, 0), 1, "1920x1080 G-buffer, 1 point light + IBL")
+frame_times("cfg4", TileSpec(0, 0, 3840, 2160, 3840, 2160, 0), 256, "3840x2160 G-buffer, 256 clustered lights + IBL (bench.py headline)")
+frame_times("cfg5", TileSpec(1920, 0, 1920, 2160, 7680, 4320, 256), 256, "one of 8 ranks of the 7680x4320 frame: 1920x2160 tile + 256-px apron")
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
