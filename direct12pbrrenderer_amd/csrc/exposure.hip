@@ -84,44 +84,47 @@ __global__ __launch_bounds__(256) void k_lum_average(uint32_t* __restrict__ hist
     }
 }
 
-// hdr_tone_mapping.hlsl:27-36
+// hdr_tone_mapping.hlsl:27-36.  The result is quantised to 8 bits (tolerance 1 LSB), so the fast
+// reciprocal / log / exp instructions are used throughout: the pass must stay HBM-bound (12 B/pixel),
+// and three IEEE divisions + a libm pow per channel would make it VALU-bound.
 __device__ __forceinline__ float aces1(float x) {
     const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
-    return saturatef((x * (a * x + b)) / (x * (c * x + d) + e));
+    return saturatef((x * (a * x + b)) * rcp(x * (c * x + d) + e));
 }
-__device__ __forceinline__ uint32_t tonemap_px(float r, float g, float b, float inv_exposure_den) {
+__device__ __forceinline__ uint32_t tonemap_px(float r, float g, float b, float inv_den) {
     // exposed = luminance / (l_max + 0.001); pow(x, 0.454545) = exp2(0.454545*log2(x)) (x in [0,1])
-    const float m[3] = {aces1(r * inv_exposure_den), aces1(g * inv_exposure_den), aces1(b * inv_exposure_den)};
+    const float m[3] = {aces1(r * inv_den), aces1(g * inv_den), aces1(b * inv_den)};
     uint32_t px = 0xFF000000u;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float gc = m[k] > 0.0f ? __builtin_amdgcn_exp2f(0.454545f * __builtin_amdgcn_logf(m[k])) : 0.0f;
-        px |= (uint32_t)floorf(saturatef(gc) * 255.0f + 0.5f) << (8 * k);
+        px |= (uint32_t)(saturatef(gc) * 255.0f + 0.5f) << (8 * k);
     }
     return px;
 }
 
-// grid (ceil(w/512), h), block 256: two pixels per lane (16-byte load, 8-byte store) when aligned
+// persistent grid (<= 2048 blocks of 256), two pixels per lane per trip: 16-byte load, 8-byte store
 __global__ __launch_bounds__(256) void k_tonemap(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
                                                    const float* __restrict__ avg, uint32_t* __restrict__ out, uint32_t out_pitch, bool aligned) {
-    const uint32_t y = blockIdx.y;
-    const uint32_t x = (blockIdx.x * 256 + threadIdx.x) * 2;
-    if (x >= w || y >= h) return;
     const float l_max = 9.6f * avg[0];
-    const float den = l_max + 0.001f;
-    const bool vec2 = aligned && (x + 1 < w);
-    if (vec2) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(hdr + 4 * ((size_t)y * pitch + x));
-        const H4 p0 = *reinterpret_cast<const H4*>(&raw.x);
-        const H4 p1 = *reinterpret_cast<const H4*>(&raw.z);
-        uint2 o;
-        o.x = tonemap_px((float)p0.x / den, (float)p0.y / den, (float)p0.z / den, 1.0f);
-        o.y = tonemap_px((float)p1.x / den, (float)p1.y / den, (float)p1.z / den, 1.0f);
-        *reinterpret_cast<uint2*>(out + (size_t)y * out_pitch + x) = o;
-    } else {
-        for (uint32_t xx = x; xx < min(x + 2, w); xx++) {
-            const F4 c = load_h4(hdr + 4 * ((size_t)y * pitch + xx));
-            out[(size_t)y * out_pitch + xx] = tonemap_px(c.x / den, c.y / den, c.z / den, 1.0f);
+    const float inv_den = 1.0f / (l_max + 0.001f);
+    const uint32_t wp = (w + 1) >> 1;   // pixel pairs per row
+    const size_t n = (size_t)wp * h;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const uint32_t y = (uint32_t)(t / wp), x = (uint32_t)(t % wp) * 2;
+        if (aligned && x + 1 < w) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(hdr + 4 * ((size_t)y * pitch + x));
+            const H4 p0 = *reinterpret_cast<const H4*>(&raw.x);
+            const H4 p1 = *reinterpret_cast<const H4*>(&raw.z);
+            uint2 o;
+            o.x = tonemap_px((float)p0.x, (float)p0.y, (float)p0.z, inv_den);
+            o.y = tonemap_px((float)p1.x, (float)p1.y, (float)p1.z, inv_den);
+            *reinterpret_cast<uint2*>(out + (size_t)y * out_pitch + x) = o;
+        } else {
+            for (uint32_t xx = x; xx < min(x + 2, w); xx++) {
+                const F4 c = load_h4(hdr + 4 * ((size_t)y * pitch + xx));
+                out[(size_t)y * out_pitch + xx] = tonemap_px(c.x, c.y, c.z, inv_den);
+            }
         }
     }
 }
@@ -155,7 +158,10 @@ pbr_status pbr_tonemap(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, hdr && avg && rgba8, "pbr_tonemap: null pointer");
     PBR_REQUIRE(ctx, w && h && w <= 65535 && h <= 65535 && pitch >= w && out_pitch >= w, "pbr_tonemap: bad size");
-    dim3 grid((w + 511) / 512, h);
+    size_t pairs = (size_t)((w + 1) / 2) * h;
+    unsigned blocks = (unsigned)((pairs + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid(blocks);
     const bool aligned = (((uintptr_t)hdr & 15u) == 0u) && (((uintptr_t)rgba8 & 7u) == 0u) && (((pitch | out_pitch) & 1u) == 0u);
     hipLaunchKernelGGL(k_tonemap, grid, dim3(256), 0, ctx->stream, hdr, w, h, pitch, avg, rgba8, out_pitch, aligned);
     return launched(ctx, "k_tonemap");

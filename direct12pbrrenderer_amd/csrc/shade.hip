@@ -170,8 +170,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // light planes put the same component of both lights into an adjacent VGPR pair with no moves.
         f2 a1x = f2s(0.0f), a1y = f2s(0.0f), a1z = f2s(0.0f), a2x = f2s(0.0f), a2y = f2s(0.0f), a2z = f2s(0.0f), a3x = f2s(0.0f), a3y = f2s(0.0f), a3z = f2s(0.0f);
         auto light2 = [&](int liA, int liB, float wB) {
-            const float* la = llds + min(liA, n_lights - 1);   // never index past the staged table
-            const float* lb = llds + min(liB, n_lights - 1);
+            const float* la = llds + liA;   // indices were clamped to the staged table when the lists were staged
+            const float* lb = llds + liB;
             auto comp = [&](int c) { return f2{la[c * LSTRIDE], lb[c * LSTRIDE]}; };
             const f2 dx = comp(0) - f2s(pos.x), dy = comp(1) - f2s(pos.y), dz = comp(2) - f2s(pos.z);
             const f2 d2 = dx * dx + dy * dy + dz * dz;
@@ -181,14 +181,19 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const f2 NdotL = max2(NdL, f2s(0.0f));
             const f2 LdV = (dx * view.x + dy * view.y + dz * view.z) * invd;
             // |L + V|^2 = 2 + 2 L.V ; N.H = (N.L + N.V) / |L + V|
-            const f2 NdotH = max2((NdL + f2s(NdV)) * rsq2(max2(LdV * 2.0f + f2s(2.0f), f2s(1e-12f))), f2s(0.0f));
+            // (|.| is a free source modifier of v_rsq: rounding can push 2+2 L.V a hair below 0; at exactly 0, L = -V,
+            //  N.L + N.V is 0 too and max(NaN, 0) = 0)
+            const f2 h2 = LdV * 2.0f + f2s(2.0f);
+            const f2 NdotH = max2((NdL + f2s(NdV)) * f2{rsq(__builtin_fabsf(h2.x)), rsq(__builtin_fabsf(h2.y))}, f2s(0.0f));
             const f2 t = (NdotH * NdotH) * a4m1 + f2s(1.0f);
             const f2 T = max2(t * t, f2s(t_floor));
             const f2 A = NdotL * one_k + f2s(k);
             const f2 B = max2(NdotL * ndv4, f2s(0.0001f));
             const f2 Q = max2(comp(6) + comp(7) * dist + comp(8) * d2, f2s(EPSILON_F));
             const f2 X = (NdotL * rcp2(Q)) * f2{1.0f, wB};   // attenuation * NdotL (light B masked off on an odd tail)
-            const f2 fm = max2(f2s(1.0f) - NdotL, f2s(EPSILON_F));   // fresnel on NdotL (Q3)
+            // fresnel on NdotL (Q3).  The shader's max(1-NdotL, 1e-6) only matters within 1e-6 of NdotL = 1, where it
+            // changes f5 by < 1e-30: dropped.
+            const f2 fm = f2s(1.0f) - NdotL;
             const f2 fm2 = fm * fm;
             const f2 f5 = fm2 * fm2 * fm;
             const f2 w2 = X * NdotL * rcp2(T * A * B);   // X * s
@@ -212,8 +217,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const pbr_cluster* cl = p.clusters + (sz + sx * PBR_CLUSTER_Z + sy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
             const int nl = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
             int i = 0;
-            for (; i + 1 < nl; i += 2) light2(max(cl->LightIndex[i], 0), max(cl->LightIndex[i + 1], 0), 1.0f);
-            if (i < nl) light2(max(cl->LightIndex[i], 0), max(cl->LightIndex[i], 0), 0.0f);
+            auto idx = [&](int q) { return min(max(cl->LightIndex[q], 0), n_lights - 1); };
+            for (; i + 1 < nl; i += 2) light2(idx(i), idx(i + 1), 1.0f);
+            if (i < nl) light2(idx(i), idx(i), 0.0f);
         }
         s1x = a1x.x + a1x.y; s1y = a1y.x + a1y.y; s1z = a1z.x + a1z.y;
         s2x = a2x.x + a2x.y; s2y = a2y.x + a2y.y; s2z = a2z.x + a2z.y;
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
             const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
             int val = 0;
             if (j == 0) val = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
-            else if (j >= 2) val = min(max(cl->LightIndex[j - 2], 0), PBR_MAX_SCENE_LIGHTS - 1);
+            else if (j >= 2) val = min(max(cl->LightIndex[j - 2], 0), n_lights - 1);   // never index past the staged light table
             lists[e] = (uint16_t)val;
         }
     }
