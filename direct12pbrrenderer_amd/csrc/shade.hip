@@ -36,6 +36,7 @@ struct ShadeParams {
     uint32_t lut_res;
     const pbr_half* env;   // padded layout
     uint32_t env_size, env_mips;
+    uint32_t env_mip_off[16];   // texel offset of each padded mip (host-computed)
     const pbr_cluster* clusters;
     const pbr_light* lights;
     pbr_half* hdr;
@@ -113,7 +114,7 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 //   3. material: re-reads the A/C planes (L2 hits) and folds the sums;
 //   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
 template <bool STAGED_LISTS, int LSTRIDE>
-__device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint16_t* lists,
+__device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint16_t* lists, const uint32_t* mip_off,
                                             int tile_x0, int tile_y0, int tiles_x, int n_lights, uint32_t px, uint32_t py) {
     const size_t gi = (size_t)py * p.pitch + px;
     if (p.stencil[gi] == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
@@ -269,24 +270,37 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         const float fl = floorf(lod);
         const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1, p.env_mips - 1);
         const float env_f = lod - fl;
+        // face + uv of R (D3D cube addressing).  v_rcp instead of an IEEE divide: u,v only feed a continuous filter
         uint32_t face;
         float cu, cv;
-        cube_face_uv(R, face, cu, cv);
-        auto fetch = [&](uint32_t l) {
+        {
+            const float ax = fabsf(R.x), ay = fabsf(R.y), az = fabsf(R.z);
+            float sc, tc, ma;
+            if (ax >= ay && ax >= az) { ma = ax; face = R.x >= 0.0f ? 0u : 1u; sc = R.x >= 0.0f ? -R.z : R.z; tc = -R.y; }
+            else if (ay >= az)        { ma = ay; face = R.y >= 0.0f ? 2u : 3u; sc = R.x; tc = R.y >= 0.0f ? R.z : -R.z; }
+            else                      { ma = az; face = R.z >= 0.0f ? 4u : 5u; sc = R.z >= 0.0f ? R.x : -R.x; tc = -R.y; }
+            const float inv = rcp(ma);
+            cu = (sc * inv + 1.0f) * 0.5f;
+            cv = (tc * inv + 1.0f) * 0.5f;
+        }
+        auto fetch = [&](uint32_t l, uint32_t mip_off) {
             const int s = (int)(p.env_size >> l), sp = s + 2;
-            const BilinearCoord cx = bilinear_coord(cu, s), cy = bilinear_coord(cv, s);
-            const H4* m = reinterpret_cast<const H4*>(p.env) + env_padded_mip_offset(p.env_size, l);
-            const size_t o = ((size_t)face * sp + (size_t)(cy.i0 + 1)) * sp + (size_t)(cx.i0 + 1);
+            // u in [0,1] -> texel coordinate in [-0.5, s-0.5]: no NaN / range guard needed here
+            const float fxp = cu * (float)s - 0.5f, fyp = cv * (float)s - 0.5f;
+            const float flx = floorf(fxp), fly = floorf(fyp);
+            const float fx = fxp - flx, fy = fyp - fly;
+            const H4* m = reinterpret_cast<const H4*>(p.env) + mip_off;
+            const uint32_t o = (face * (uint32_t)sp + (uint32_t)((int)fly + 1)) * (uint32_t)sp + (uint32_t)((int)flx + 1);
             const H4x2 r0 = *reinterpret_cast<const H4x2*>(m + o);
             const H4x2 r1 = *reinterpret_cast<const H4x2*>(m + o + sp);
-            const float wx0 = 1.0f - cx.f, wy0 = 1.0f - cy.f;
-            const float tr = (float)r0.a.x * wx0 + (float)r0.b.x * cx.f, br = (float)r1.a.x * wx0 + (float)r1.b.x * cx.f;
-            const float tg = (float)r0.a.y * wx0 + (float)r0.b.y * cx.f, bg = (float)r1.a.y * wx0 + (float)r1.b.y * cx.f;
-            const float tb = (float)r0.a.z * wx0 + (float)r0.b.z * cx.f, bb = (float)r1.a.z * wx0 + (float)r1.b.z * cx.f;
-            return v3(tr * wy0 + br * cy.f, tg * wy0 + bg * cy.f, tb * wy0 + bb * cy.f);
+            const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+            const float tr = (float)r0.a.x * wx0 + (float)r0.b.x * fx, br = (float)r1.a.x * wx0 + (float)r1.b.x * fx;
+            const float tg = (float)r0.a.y * wx0 + (float)r0.b.y * fx, bg = (float)r1.a.y * wx0 + (float)r1.b.y * fx;
+            const float tb = (float)r0.a.z * wx0 + (float)r0.b.z * fx, bb = (float)r1.a.z * wx0 + (float)r1.b.z * fx;
+            return v3(tr * wy0 + br * fy, tg * wy0 + bg * fy, tb * wy0 + bb * fy);
         };
-        const V3 ea = fetch(l0);
-        const V3 eb = fetch(l1);
+        const V3 ea = fetch(l0, mip_off[l0]);   // per-lane index: the table sits in LDS (an SGPR array would spill to scratch)
+        const V3 eb = fetch(l1, mip_off[l1]);
         const float w0 = 1.0f - env_f;
         const V3 envc = v3(ea.x * w0 + eb.x * env_f, ea.y * w0 + eb.y * env_f, ea.z * w0 + eb.z * env_f);
         // LUT bilinear with clamp addressing (Q5): one 8-byte pair per row; at the borders both taps are
@@ -326,6 +340,8 @@ template <bool STAGED_LISTS, int LSTRIDE>
 #endif
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters) {
     extern __shared__ float4 lds_raw[];
+    __shared__ uint32_t s_mip_off[16];
+    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
     float* llds = reinterpret_cast<float*>(lds_raw);
     uint16_t* lists = reinterpret_cast<uint16_t*>(llds + LIGHT_PLANES * LSTRIDE);
     for (int i = threadIdx.x; i < n_lights; i += SHADE_BLOCK) {
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     __syncthreads();
     const uint32_t px = bx0 + threadIdx.x;
     if (px >= p.w) return;
-    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE>(p, llds, lists, tile_x0, tile_y0, tiles_x, n_lights, px, py);
+    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, px, py);
 }
 
 extern "C" {
@@ -419,6 +435,7 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
     p.x0 = tile->x0; p.y0 = tile->y0; p.w = tile->w; p.h = tile->h; p.full_w = tile->full_w; p.full_h = tile->full_h;
     p.A = gb->A; p.B = gb->B; p.C = gb->C; p.depth = gb->depth; p.stencil = gb->stencil; p.pitch = gb->pitch;
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
+    for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)env_padded_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
     p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch;
     dim3 grid((tile->w + SHADE_BLOCK - 1) / SHADE_BLOCK, (tile->h + SHADE_ROWS - 1) / SHADE_ROWS);
     // A block covers 256 x 8 pixels.  It can stage its cluster lists when that rectangle spans at most

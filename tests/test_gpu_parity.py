@@ -183,8 +183,9 @@ def _check_shade(got, want, want_f32, stencil, what):
     on = stencil > 0
     scale = np.abs(want_f32[on][:, :3]).max()
     err = np.abs(got.astype(np.float32) - want.astype(np.float32))[on][:, :3]
-    # fp16 storage of the largest value costs up to scale * 2^-11; the 1e-4 L-inf bound is on top of it
-    assert err.max() <= 1e-4 * scale + scale * 2.0 ** -11, f"{what}: L-inf {err.max()} vs scale {scale}"
+    # the kernel only exposes the fp16 target: one fp16 ulp of the largest value (scale * 2^-10) is the
+    # storage granularity, the 1e-4 relative L-inf bound of SURVEY 8c sits on top of it
+    assert err.max() <= 1e-4 * scale + scale * 2.0 ** -10, f"{what}: L-inf {err.max()} vs scale {scale}"
     assert_half_close(got[on], want[on], 2, what, frac_over=1e-3, hard_ulp=64)
     assert np.all(got[on][:, 3] == 1.0)
 
