@@ -118,9 +118,17 @@ def cpu_baseline(g, lights, lut_np, env_np, width, height, budget_s=12.0):
 
     rows, _, dt = run(64)
     rows, y0, dt = run(int(rows * budget_s / max(dt, 1e-3)))
+    reps = 1
+    if rows >= height // 16 * 16 and dt < 0.7 * budget_s:   # many-core host: the whole frame is too short a sample, repeat it
+        reps = max(1, min(32, int(budget_s / max(dt, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run(rows)
+        dt = (time.perf_counter() - t0) / reps
     return {"value": round(width * rows / dt / 1e6, 4), "unit": "Mpixel/s", "cores": orc.num_threads(), "kind": "port",
             "sample": f"{width}x{rows} band (rows {y0}..{y0 + rows - 1}) of the {width}x{height} frame: shade(256 lights+IBL)"
-                      f"+bloom+histogram+average+tonemap, oracle/pbr_oracle.cpp with OpenMP on {orc.num_threads()} threads, {dt:.1f} s"}
+                      f"+bloom+histogram+average+tonemap, oracle/pbr_oracle.cpp with OpenMP on {orc.num_threads()} threads, "
+                      f"{reps} x {dt:.2f} s (input synthesis included)"}
 
 
 def main():
