@@ -336,7 +336,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
 // dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 68 B of light lists.
 template <bool STAGED_LISTS, int LSTRIDE>
 #ifndef SHADE_MIN_WAVES
-#define SHADE_MIN_WAVES 5   // 96 VGPRs, no spills: best of 4..8 measured (tools_probe_shade.py)
+#define SHADE_MIN_WAVES 5   // 96 VGPRs, no spills: best of 4..8 measured (tools/probe_shade.py)
 #endif
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters) {
     extern __shared__ float4 lds_raw[];

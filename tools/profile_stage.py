@@ -1,6 +1,6 @@
-"""Runs one stage of the 4K frame a few times (for rocprofv3 --pmc passes).  usage: tools_profile_stage.py shade|bloom|all [n_lights]"""
+"""Runs one stage of the 4K frame a few times (for rocprofv3 --pmc passes).  usage: tools/profile_stage.py shade|bloom|all [n_lights]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from direct12pbrrenderer_amd import scene, synth
 from direct12pbrrenderer_amd.api import PbrContext
