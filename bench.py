@@ -77,6 +77,20 @@ def pmc_traffic(kernel_prefix, workload_px):
     return None
 
 
+def pmc_valu(kernel_prefix, workload_px):
+    """VALU wave-instructions per launch of `kernel_prefix` from the committed SQ counter summary."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq_latest.json")))
+    except Exception:
+        return None
+    if d.get("_workload_pixels") != workload_px:
+        return None
+    for k, v in d.items():
+        if isinstance(v, dict) and kernel_prefix in k and "SQ_INSTS_VALU" in v:
+            return v["SQ_INSTS_VALU"]
+    return None
+
+
 def time_stage(fn, iters, pre=None):
     """Average device time of `fn` in ms, HIP events on the stream the kernels run on
     (the ctx is bound to torch's current stream, so torch.cuda.Event sees them)."""
@@ -136,11 +150,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PBR_BENCH_REHEARSAL=1: every rank on cuda:0 with a gloo collective — exercises this file's
+    # multi-rank path on a one-GPU box; not a measurement
+    rehearsal = os.environ.get("PBR_BENCH_REHEARSAL", "0") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -163,6 +185,11 @@ def main():
             dist.broadcast_object_list(ids, src=0)
             ctx.comm_init(world, rank, ids[0])
             allreduce = ctx.allreduce_hist
+        elif rehearsal:
+            def allreduce(h):
+                t = h.cpu()
+                dist.all_reduce(t)
+                h.copy_(t)
         else:
             allreduce = lambda h: dist.all_reduce(h)   # RCCL, int32 sum == uint32 sum bit for bit  # noqa: E731
 
@@ -186,7 +213,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{dev}")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{dev}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
@@ -201,7 +228,7 @@ def main():
         "config": {"workload": f"{a.width}x{a.height} G-buffer per GPU ({spec.full_w}x{spec.full_h} frame), {N_LIGHTS} clustered "
                                f"lights + IBL (env {ENV_SIZE}^2 x{ENV_MIPS} mips, LUT {LUT_RES}^2, SH9), auto-exposure + ACES + 9-tap bloom",
                    "tile": [spec.x0, spec.y0, spec.w, spec.h], "apron": spec.apron,
-                   "allreduce": ("none" if world == 1 else ("rccl-capi" if use_capi_rccl else "rccl-torch"))},
+                   "allreduce": ("none" if world == 1 else ("gloo-rehearsal" if rehearsal else ("rccl-capi" if use_capi_rccl else "rccl-torch")))},
     }
 
     if rank == 0 and not a.no_kernel_timing:
@@ -233,6 +260,14 @@ def main():
                            "stage_GBps": {k: v["GB/s"] for k, v in kern.items()},
                            "note": "shade with 256 clustered lights is FP32-VALU-bound (SURVEY D6): its HBM fraction is structurally low; "
                                    "traffic (when present) is the committed rocprofv3 PMC figure for this workload, IBL gathers served by L2/MALL included"}
+        nv = pmc_valu("k_deferred_shade", spec.ew * spec.eh)
+        if nv:
+            # supplementary compute roofline for the VALU-bound shade: measured issue cost of a plain fp32 VALU
+            # instruction on gfx950 is ~4 cycles per SIMD (tools/valu_rate2.hip); 1024 SIMDs at the 2.4 GHz max clock
+            peak = 1024 * 2.4e9 / 4.0
+            out["roofline"]["valu"] = {"wave_insts_per_launch": nv, "achieved_Ginst_s": round(nv / (kern["shade"]["ms"] * 1e-3) / 1e9, 1),
+                                       "peak_Ginst_s": round(peak / 1e9, 1), "frac": round(nv / (kern["shade"]["ms"] * 1e-3) / peak, 3),
+                                       "source": "profiles/pmc_sq_latest.json (rocprofv3 SQ_INSTS_VALU) + tools/valu_rate2.hip"}
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(g, lights, lut.cpu().view(torch.int16).numpy().view(np.float16),
