@@ -53,20 +53,31 @@ __global__ __launch_bounds__(256) void k_bloom_prefilter(const pbr_half* __restr
 }
 
 // ---------------------------------------------------------------- blur.hlsli:24-55
-// Fills one 264-entry cache for the 256-texel group starting at gx0 of output row y.
-__device__ __forceinline__ void blur_h_fill(float4* cache, const pbr_half* in, int iw, int ih, float tx, float ty, int gx0, int y) {
-    const int t = threadIdx.x;
-    const float uvx = ((float)(gx0 + t) + 0.5f) * tx;
-    const float uvy = ((float)y + 0.5f) * ty;
-    if (t < 4) {
-        const float xx = fmaxf(uvx - 4.0f * tx, 0.0f);
-        cache[t] = to4(sample_2d_h4(in, iw, ih, iw, xx, uvy));
-    }
-    if (t >= 252) {
-        const float xx = fminf(uvx + 4.0f * tx, 1.0f);
-        cache[t + 8] = to4(sample_2d_h4(in, iw, ih, iw, xx, uvy));
-    }
-    cache[t + 4] = to4(sample_2d_h4(in, iw, ih, iw, uvx, uvy));
+// One 256-thread group = 256 consecutive output texels of a row, the bilinear-sampled row cached in LDS
+// (264 float4 entries incl. the 4+4 halo slots) exactly like the shader's Cache[].  A block walks HB_ROWS
+// rows of its column group and software-pipelines them: the four raw taps of row r+1 are in flight while
+// row r is filtered out of a double-buffered cache (one barrier per row).  The stand-alone one-row block
+// was latency-bound (one dependent HBM round trip per 256 outputs, SQ_WAIT_ANY ~50 %).
+constexpr int HB_MAX_ROWS = 8;   // rows per block: chosen per launch so that small pyramid levels still fill the chip
+struct RawTap {   // the four texels of one bilinear sample, still in half precision, + the y weight
+    H4 c00, c10, c01, c11;
+    float fy;
+};
+struct ColumnCoord { int x0, x1; float fx; };   // x side of a sample: row-invariant
+__device__ __forceinline__ ColumnCoord column_coord(float u, int iw) {
+    const BilinearCoord c = bilinear_coord(u, iw);
+    return ColumnCoord{clampi(c.i0, 0, iw - 1), clampi(c.i1, 0, iw - 1), c.f};
+}
+__device__ __forceinline__ RawTap load_tap(const pbr_half* __restrict__ in, int iw, int ih, const ColumnCoord& cc, float v) {
+    const BilinearCoord cy = bilinear_coord(v, ih);
+    const int y0 = clampi(cy.i0, 0, ih - 1), y1 = clampi(cy.i1, 0, ih - 1);
+    const H4* r0 = reinterpret_cast<const H4*>(in) + (size_t)y0 * iw;
+    const H4* r1 = reinterpret_cast<const H4*>(in) + (size_t)y1 * iw;
+    return RawTap{r0[cc.x0], r0[cc.x1], r1[cc.x0], r1[cc.x1], cy.f};
+}
+__device__ __forceinline__ F4 h4f(H4 h) { return f4((float)h.x, (float)h.y, (float)h.z, (float)h.w); }
+__device__ __forceinline__ float4 finish_tap(const RawTap& r, float fx) {
+    return to4(bilerp(h4f(r.c00), h4f(r.c10), h4f(r.c01), h4f(r.c11), fx, r.fy));
 }
 __device__ __forceinline__ F4 gauss9(const float4* c) {
     F4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -75,21 +86,53 @@ __device__ __forceinline__ F4 gauss9(const float4* c) {
     return v;
 }
 
-// grid (ceil(ow/256), oh), block 256.  DUAL: bloom_upsample_add.hlsl:13-25 (lower first, then upper)
+// grid (ceil(ow/256), ceil(oh/rows_per_block)), block 256.  DUAL: bloom_upsample_add.hlsl:13-25 (lower first, then upper)
 template <bool DUAL>
 __global__ __launch_bounds__(256) void k_blur_h(const pbr_half* __restrict__ in, int iw, int ih,
                                                  const pbr_half* __restrict__ in2, int iw2, int ih2,
-                                                 pbr_half* __restrict__ out, int ow, int oh, float tx, float ty) {
-    __shared__ float4 cache[DUAL ? 2 : 1][264];
-    const int gx0 = blockIdx.x * 256, y = blockIdx.y;
-    blur_h_fill(cache[0], in, iw, ih, tx, ty, gx0, y);
-    if (DUAL) blur_h_fill(cache[1], in2, iw2, ih2, tx, ty, gx0, y);
-    __syncthreads();
-    const int x = gx0 + threadIdx.x;
-    if (x >= ow) return;
-    F4 v = gauss9(cache[0] + threadIdx.x);
-    if (DUAL) v = v + gauss9(cache[1] + threadIdx.x);
-    store_h4(out + 4 * ((size_t)y * ow + x), v);
+                                                 pbr_half* __restrict__ out, int ow, int oh, float tx, float ty, int rows_per_block) {
+    constexpr int NS = DUAL ? 2 : 1;
+    __shared__ float4 cache[2][NS][264];
+    const int t = threadIdx.x;
+    const int gx0 = blockIdx.x * 256;
+    const int y_begin = blockIdx.y * rows_per_block, y_end = min(y_begin + rows_per_block, oh);
+    // sample positions in x (blur.hlsli:26-43): every thread its own texel; threads 0-3 / 252-255 also one halo tap
+    const float uvx = ((float)(gx0 + t) + 0.5f) * tx;
+    const bool halo = (t < 4) | (t >= 252);
+    const float uvx_h = t < 4 ? fmaxf(uvx - 4.0f * tx, 0.0f) : fminf(uvx + 4.0f * tx, 1.0f);
+    const int slot_h = t < 4 ? t : t + 8;
+    const ColumnCoord cm = column_coord(uvx, iw), ch = column_coord(uvx_h, iw);
+    ColumnCoord cm2 = cm, ch2 = ch;
+    if (DUAL) { cm2 = column_coord(uvx, iw2); ch2 = column_coord(uvx_h, iw2); }
+
+    RawTap m[NS], hh[NS];
+    auto load_row = [&](int y) {
+        const float uvy = ((float)y + 0.5f) * ty;
+        m[0] = load_tap(in, iw, ih, cm, uvy);
+        if (halo) hh[0] = load_tap(in, iw, ih, ch, uvy);
+        if (DUAL) {
+            m[NS - 1] = load_tap(in2, iw2, ih2, cm2, uvy);
+            if (halo) hh[NS - 1] = load_tap(in2, iw2, ih2, ch2, uvy);
+        }
+    };
+    load_row(y_begin);
+    for (int y = y_begin; y < y_end; y++) {
+        const int buf = (y - y_begin) & 1;
+        cache[buf][0][t + 4] = finish_tap(m[0], cm.fx);
+        if (halo) cache[buf][0][slot_h] = finish_tap(hh[0], ch.fx);
+        if (DUAL) {
+            cache[buf][NS - 1][t + 4] = finish_tap(m[NS - 1], cm2.fx);
+            if (halo) cache[buf][NS - 1][slot_h] = finish_tap(hh[NS - 1], ch2.fx);
+        }
+        __syncthreads();
+        if (y + 1 < y_end) load_row(y + 1);   // in flight while this row is filtered
+        const int x = gx0 + t;
+        if (x < ow) {
+            F4 v = gauss9(cache[buf][0] + t);
+            if (DUAL) v = v + gauss9(cache[buf][NS - 1] + t);
+            store_h4(out + 4 * ((size_t)y * ow + x), v);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- blur.hlsli:58-89
@@ -208,6 +251,13 @@ __global__ __launch_bounds__(256) void k_bloom_merge(pbr_half* __restrict__ hdr,
     store_h4(p, load_h4(p) + load_h4(in + 4 * ((size_t)y * w + x)));
 }
 
+// rows a k_blur_h block pipelines: as many as keep >= ~2048 blocks (8 per CU) in the grid
+static int blur_h_rows(uint32_t ow, uint32_t oh) {
+    const uint64_t row_blocks = (uint64_t)((ow + 255) / 256) * oh;
+    int rows = (int)(row_blocks / 2048);
+    return rows < 1 ? 1 : (rows > HB_MAX_ROWS ? HB_MAX_ROWS : rows);
+}
+
 extern "C" {
 
 pbr_status pbr_bloom_prefilter(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
@@ -227,8 +277,9 @@ pbr_status pbr_blur_h(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih
     PBR_REQUIRE(ctx, in && out, "pbr_blur_h: null pointer");
     PBR_REQUIRE(ctx, iw && ih && ow && oh && iw <= 65535 && ih <= 65535 && ow <= 65535 && oh <= 65535, "pbr_blur_h: bad size");
     const float tx = 1.0f / (float)ow, ty = 1.0f / (float)oh;
-    dim3 grid((ow + 255) / 256, oh);
-    hipLaunchKernelGGL(k_blur_h<false>, grid, dim3(256), 0, ctx->stream, in, (int)iw, (int)ih, (const pbr_half*)nullptr, 0, 0, out, (int)ow, (int)oh, tx, ty);
+    const int rows = blur_h_rows(ow, oh);
+    dim3 grid((ow + 255) / 256, (oh + rows - 1) / rows);
+    hipLaunchKernelGGL(k_blur_h<false>, grid, dim3(256), 0, ctx->stream, in, (int)iw, (int)ih, (const pbr_half*)nullptr, 0, 0, out, (int)ow, (int)oh, tx, ty, rows);
     return launched(ctx, "k_blur_h");
 }
 
@@ -248,8 +299,9 @@ pbr_status pbr_bloom_upsample_add(pbr_ctx* ctx, const pbr_half* upper, uint32_t 
     PBR_REQUIRE(ctx, upper && lower && out, "pbr_bloom_upsample_add: null pointer");
     PBR_REQUIRE(ctx, uw && uh && lw && lh && uw <= 65535 && uh <= 65535, "pbr_bloom_upsample_add: bad size");
     const float tx = 1.0f / (float)uw, ty = 1.0f / (float)uh;
-    dim3 grid((uw + 255) / 256, uh);
-    hipLaunchKernelGGL(k_blur_h<true>, grid, dim3(256), 0, ctx->stream, lower, (int)lw, (int)lh, upper, (int)uw, (int)uh, out, (int)uw, (int)uh, tx, ty);
+    const int rows = blur_h_rows(uw, uh);
+    dim3 grid((uw + 255) / 256, (uh + rows - 1) / rows);
+    hipLaunchKernelGGL(k_blur_h<true>, grid, dim3(256), 0, ctx->stream, lower, (int)lw, (int)lh, upper, (int)uw, (int)uh, out, (int)uw, (int)uh, tx, ty, rows);
     return launched(ctx, "k_blur_h<dual>");
 }
 
