@@ -38,6 +38,8 @@ SIGNATURES = {
     "pbr_cluster_cull": (_int, [_vp, C.POINTER(Global), _vp, _int, _vp]),
     "pbr_deferred_shade": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer),
                                   _vp, _u32, _vp, _u32, _u32, _vp, _vp, _int, _vp, _u32]),
+    "pbr_skybox": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(CubeF32), _vp, _u32, _vp, _u32]),
+    "pbr_gbuffer_encode": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pbr_bloom_prefilter": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _f32, _f32]),
     "pbr_blur_h": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32]),
     "pbr_blur_v": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32]),

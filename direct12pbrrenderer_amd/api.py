@@ -135,6 +135,17 @@ class PbrContext:
                                                 _ptr(env), env_size, env_mips, _ptr(clusters), _ptr(lights),
                                                 int(num_lights), _ptr(hdr), hdr_pitch))
 
+    def skybox(self, g: Global, tile: Tile, sky, sky_size, sky_mips, stencil, pitch, hdr, hdr_pitch):
+        """skybox.hlsl: sky colour into hdr where stencil == 0 (run before deferred_shade)."""
+        c = CubeF32(sky.data_ptr(), sky_size, sky_mips)
+        self._check(self.lib.pbr_skybox(self.h, C.byref(g), C.byref(tile), C.byref(c), _ptr(stencil), pitch,
+                                        _ptr(hdr), hdr_pitch))
+
+    def gbuffer_encode(self, m0, m1, m2, w, h, pitch, A, B, Cc):
+        """gbuffer.hlsl::ps_main on per-pixel material planes (float4 each) -> RGBA8 G-buffer planes."""
+        self._check(self.lib.pbr_gbuffer_encode(self.h, _ptr(m0), _ptr(m1), _ptr(m2), w, h, pitch,
+                                                _ptr(A), _ptr(B), _ptr(Cc)))
+
     def bloom_prefilter(self, hdr, w, h, pitch, out, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE):
         self._check(self.lib.pbr_bloom_prefilter(self.h, _ptr(hdr), w, h, pitch, _ptr(out), threshold, knee))
 

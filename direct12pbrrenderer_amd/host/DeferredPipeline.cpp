@@ -91,9 +91,19 @@ void GBufferPass::Execute(FGContext* context) {
     auto* b = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::GBufferB));
     auto* c = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::GBufferC));
     auto* ds = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::DepthStencil));
-    ThrowIfFailed(hipMemcpy(a->DevicePtr(), src.A.data(), n * 4, hipMemcpyHostToDevice), "upload GBufferA");
-    ThrowIfFailed(hipMemcpy(b->DevicePtr(), src.B.data(), n * 4, hipMemcpyHostToDevice), "upload GBufferB");
-    ThrowIfFailed(hipMemcpy(c->DevicePtr(), src.C.data(), n * 4, hipMemcpyHostToDevice), "upload GBufferC");
+    if (src.HasMaterials()) {   // gbuffer.hlsl::ps_main on the rasterizer's per-pixel attributes
+        if (!mMaterialPlanes || mMaterialPlanes->Size() != n * 48)
+            mMaterialPlanes = std::make_unique<DeviceStructuredBuffer>((uint32)(n * 48), 16);
+        float* m = (float*)mMaterialPlanes->DevicePtr();
+        ThrowIfFailed(hipMemcpy(m, src.M0.data(), n * 16, hipMemcpyHostToDevice), "upload material plane 0");
+        ThrowIfFailed(hipMemcpy(m + 4 * n, src.M1.data(), n * 16, hipMemcpyHostToDevice), "upload material plane 1");
+        ThrowIfFailed(hipMemcpy(m + 8 * n, src.M2.data(), n * 16, hipMemcpyHostToDevice), "upload material plane 2");
+        context->CommandList->EncodeGBuffer(&mShadingState, m, m + 4 * n, m + 8 * n, a, b, c);
+    } else {
+        ThrowIfFailed(hipMemcpy(a->DevicePtr(), src.A.data(), n * 4, hipMemcpyHostToDevice), "upload GBufferA");
+        ThrowIfFailed(hipMemcpy(b->DevicePtr(), src.B.data(), n * 4, hipMemcpyHostToDevice), "upload GBufferB");
+        ThrowIfFailed(hipMemcpy(c->DevicePtr(), src.C.data(), n * 4, hipMemcpyHostToDevice), "upload GBufferC");
+    }
     ThrowIfFailed(hipMemcpy(ds->DepthPlane(), src.Depth.data(), n * 4, hipMemcpyHostToDevice), "upload depth");
     ThrowIfFailed(hipMemcpy(ds->StencilPlane(), src.Stencil.data(), n, hipMemcpyHostToDevice), "upload stencil");
 }
@@ -103,7 +113,12 @@ SkyboxPass::SkyboxPass() {   // DeferredPipeline.cpp:46-57
     WriteResource(DeferredPipelineResource::DeferredShadingRT);
     WriteResource(DeferredPipelineResource::DepthStencil);
 }
-void SkyboxPass::Execute(FGContext*) {}   // raster pass, out of scope
+void SkyboxPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:59-75
+    SkyBox* sky_box = context->Scene->GetSkyBox();
+    if (!sky_box) return;
+    mShadingState.SetTexture("SkyBox", sky_box->Resource());
+    context->CommandList->DrawMesh(&mShadingState);   // sky sphere, depth test on / write off
+}
 
 // ----------------------------------------------------------------------------------- deferred shading
 DeferredShadingPass::DeferredShadingPass(RenderSize s) {   // DeferredPipeline.h:157-182

@@ -3,10 +3,10 @@
 // Same classes, resource names, constants and declared reads/writes as
 // Engine/Include/Renderer/Pipeline/DeferredPipeline.h (line references per class); Execute bodies
 // in DeferredPipeline.cpp bind by the reference's shader resource names and dispatch with the
-// reference's thread-group counts.  GBufferPass / SkyboxPass are raster passes and out of scope:
-// GBufferPass uploads the frame's G-buffer planes (what gbuffer.hlsl would have written) and
-// SkyboxPass is kept as an empty node so the graph — and therefore the execution order — is
-// the reference's.
+// reference's thread-group counts.  GBufferPass / SkyboxPass are raster passes; rasterization is out
+// of scope, their per-pixel work is not: GBufferPass uploads either the encoded G-buffer
+// planes or the rasterizer's per-pixel material attributes and encodes them with gbuffer.hlsl's
+// pixel-shader math; SkyboxPass resolves the sky on the pixels geometry left uncovered.
 #pragma once
 #include "FrameGraph.h"
 #include "Scene.h"
@@ -63,13 +63,14 @@ protected:
     bool mReady;
 };
 
-class GBufferPass : public GraphicsPass {   // :101-137 (raster: out of scope, uploads planes)
+class GBufferPass : public GraphicsPass {   // :101-137 (rasterization out of scope; ps_main's encode is pbr_gbuffer_encode)
 public:
     explicit GBufferPass(RenderSize s);
     const char* Name() const override { return "GBuffer"; }
     void Execute(FGContext* context) override;
 protected:
     ShadingState mShadingState;
+    std::unique_ptr<DeviceStructuredBuffer> mMaterialPlanes;   // device copy of GBufferSource::M0..M2
 };
 
 class DeferredShadingPass : public GraphicsPass {   // :139-190
@@ -81,7 +82,7 @@ protected:
     ShadingState mShadingState;
 };
 
-class SkyboxPass : public GraphicsPass {   // :192-206, DeferredPipeline.cpp:46-75 (raster: empty node)
+class SkyboxPass : public GraphicsPass {   // :192-206, DeferredPipeline.cpp:46-75 (sky resolve on stencil == 0)
 public:
     SkyboxPass();
     const char* Name() const override { return "Skybox"; }

@@ -114,13 +114,16 @@ IDeviceResource* FrameGraph::GetFGResource(IRenderPass* pass, FGResourceId id) {
 void FrameGraph::PreparePass(HipCommandList* cmd, uint32 pass_index) {
     auto* pass = dynamic_cast<GraphicsPass*>(mParser.GetExecutionOrder()[pass_index]);
     if (!pass) return;
-    DeviceTexture2D* rt = nullptr;
+    DeviceTexture2D *rt = nullptr, *ds = nullptr;
     for (FGResourceId id : pass->GetOutputResources()) {
         const auto& d = FGResourceDescriptionTable::Instance()->Get(id);
-        if (auto* t = std::get_if<FGTransientTextureDescription>(&d))
+        if (auto* t = std::get_if<FGTransientTextureDescription>(&d)) {
             if (t->Format != ETextureFormat_DepthStencil && !rt) rt = dynamic_cast<DeviceTexture2D*>(mFGResourceAllocator.GetResource(id));
+            if (t->Format == ETextureFormat_DepthStencil && !ds) ds = dynamic_cast<DeviceTexture2D*>(mFGResourceAllocator.GetResource(id));
+        }
     }
     cmd->SetRenderTarget(rt);
+    cmd->SetDepthStencil(ds);
 }
 
 IDeviceResource* IRenderPass::GetTransientResource(FGContext* context, FGResourceId id) { return context->FrameGraph->GetFGResource(this, id); }

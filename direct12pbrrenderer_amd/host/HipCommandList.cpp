@@ -254,4 +254,28 @@ void HipCommandList::DrawScreen(ShadingState* s) {
     }
 }
 
+void HipCommandList::DrawMesh(ShadingState* s) {   // D3D12CommandList.cpp DrawMesh; SkyboxPass::Execute :59-75
+    if (!s || s->IsCompute()) throw HipException("DrawMesh: graphics shading state expected");
+    const std::string_view f = s->File();
+    mDispatchCount++;
+    if (f != "skybox.hlsl") throw HipException("DrawMesh: " + std::string(f) + " is a raster shader without a kernel in this build");
+    if (!mRenderTarget || !mDepthStencil) throw HipException("DrawMesh: render target / depth-stencil not bound (FrameGraph::PreparePass)");
+    auto* sky = dynamic_cast<DeviceTexture2DArray*>(s->Texture("SkyBox").Texture);
+    if (!sky) throw HipException("skybox: SkyBox is not bound to a cube texture");
+    const uint32 w = mRenderTarget->Width(), h = mRenderTarget->Height();
+    pbr_tile tile = mTile.w ? mTile : pbr_tile{0, 0, w, h, w, h};
+    pbr_cube_f32 cube{(const float*)sky->DevicePtr(), sky->Size(), sky->MipLevels()};
+    Check(pbr_skybox(mCtx, &mGlobal, &tile, &cube, mDepthStencil->StencilPlane(), w, (pbr_half*)mRenderTarget->DevicePtr(), w), "pbr_skybox");
+}
+
+void HipCommandList::EncodeGBuffer(ShadingState* s, const float* m0, const float* m1, const float* m2,
+                                   DeviceTexture2D* a, DeviceTexture2D* b, DeviceTexture2D* c) {
+    if (!s || s->File() != "gbuffer.hlsl") throw HipException("EncodeGBuffer: gbuffer.hlsl shading state expected");
+    if (!a || !b || !c || a->Width() != b->Width() || a->Width() != c->Width() || a->Height() != b->Height() || a->Height() != c->Height())
+        throw HipException("EncodeGBuffer: G-buffer planes of one size expected");
+    mDispatchCount++;
+    Check(pbr_gbuffer_encode(mCtx, m0, m1, m2, a->Width(), a->Height(), a->Width(), (uint32_t*)a->DevicePtr(),
+                             (uint32_t*)b->DevicePtr(), (uint32_t*)c->DevicePtr()), "pbr_gbuffer_encode");
+}
+
 }  // namespace MRendererHip

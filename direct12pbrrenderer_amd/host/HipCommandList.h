@@ -27,6 +27,7 @@ public:
     void SetStencilRef(uint32 ref) { mStencilRef = ref; }
     // bound by FrameGraph::PreparePass for a GraphicsPass (Engine/Source/Renderer/FrameGraph.cpp:94-141)
     void SetRenderTarget(DeviceTexture2D* rt) { mRenderTarget = rt; }
+    void SetDepthStencil(DeviceTexture2D* ds) { mDepthStencil = ds; }
     // multi-GPU: the region of the full frame this device renders; default = whole target
     void SetTile(const pbr_tile& tile) { mTile = tile; }
 
@@ -34,6 +35,13 @@ public:
     void Dispatch(ShadingState* state, uint32 thread_group_count_x, uint32 thread_group_count_y, uint32 thread_group_count_z);
     // full-screen triangle with `state`'s pixel shader
     void DrawScreen(ShadingState* state);
+    // D3D12CommandList::DrawMesh (D3D12CommandList.h:75): the only mesh draw with a kernel in this build is the
+    // sky sphere of skybox.hlsl (depth test on, depth write off => exactly the stencil == 0 pixels)
+    void DrawMesh(ShadingState* state);
+    // gbuffer.hlsl::ps_main on per-pixel material attributes already resolved by the rasterizer (three float4
+    // device planes) -> GBufferA/B/C of the bound pass
+    void EncodeGBuffer(ShadingState* state, const float* m0, const float* m1, const float* m2,
+                       DeviceTexture2D* a, DeviceTexture2D* b, DeviceTexture2D* c);
     void Present(DeviceTexture2D* tex) { mPresented = tex; }
 
     pbr_ctx* Context() const { return mCtx; }
@@ -52,6 +60,7 @@ private:
     int32 mNumLights = 0;
     DeviceTexture2D* mPresented = nullptr;
     DeviceTexture2D* mRenderTarget = nullptr;
+    DeviceTexture2D* mDepthStencil = nullptr;
     pbr_tile mTile{};
     // padded copies of prefiltered env chains (pbr_env_pad), keyed by the plain texture; rebuilt after
     // env_map_gen.hlsl rewrites the texture

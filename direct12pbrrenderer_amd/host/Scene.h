@@ -83,12 +83,17 @@ struct SkyBox {
     const pbr_sh_pack& GetSHCoefficients() const { return SH; }
 };
 
-// host copy of the G-buffer a frame starts from (the raster GBufferPass is out of scope)
+// What the rasterizer hands the frame (rasterization itself is out of scope): depth + stencil, and either
+// the encoded G-buffer planes A/B/C, or the per-pixel material attributes gbuffer.hlsl::ps_main starts from
+// (M0 = albedo.rgb (gamma space) + emission, M1 = normal_ws.xyz + roughness, M2 = metallic, ao, -, -; float4
+// each), which GBufferPass then encodes on the GPU (pbr_gbuffer_encode).
 struct GBufferSource {
     uint32 Width = 0, Height = 0;
     std::vector<uint32_t> A, B, C;
+    std::vector<float> M0, M1, M2;
     std::vector<float> Depth;
     std::vector<uint8_t> Stencil;
+    bool HasMaterials() const { return !M0.empty(); }
 };
 
 class Scene {

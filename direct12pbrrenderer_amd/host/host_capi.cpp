@@ -87,9 +87,25 @@ int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, con
         const size_t n = (size_t)r->width * r->height;
         g.Width = r->width;
         g.Height = r->height;
+        g.M0.clear(); g.M1.clear(); g.M2.clear();
         g.A.assign(A, A + n);
         g.B.assign(B, B + n);
         g.C.assign(C, C + n);
+        g.Depth.assign(depth, depth + n);
+        g.Stencil.assign(stencil, stencil + n);
+    });
+}
+
+int pbrh_set_materials(pbrh_renderer* r, const float* m0, const float* m1, const float* m2, const float* depth, const uint8_t* stencil) {
+    return guarded(r, [&] {
+        GBufferSource& g = r->scene->GBuffer();
+        const size_t n = (size_t)r->width * r->height;
+        g.Width = r->width;
+        g.Height = r->height;
+        g.A.clear(); g.B.clear(); g.C.clear();
+        g.M0.assign(m0, m0 + 4 * n);
+        g.M1.assign(m1, m1 + 4 * n);
+        g.M2.assign(m2, m2 + 4 * n);
         g.Depth.assign(depth, depth + n);
         g.Stencil.assign(stencil, stencil + n);
     });

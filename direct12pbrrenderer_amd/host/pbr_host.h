@@ -19,6 +19,9 @@ int pbrh_set_skybox(pbrh_renderer* r, const float* cube_mip0, uint32_t size);
 /* n lights: position[3], color[3], radius, intensity (8 floats each) */
 int pbrh_set_lights(pbrh_renderer* r, const float* lights, int n);
 int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, const uint32_t* C, const float* depth, const uint8_t* stencil);
+/* alternative to pbrh_set_gbuffer: the rasterizer's per-pixel material attributes (three float4 planes, see
+ * pbr_gbuffer_encode in pbr_hip.h); GBufferPass encodes them on the GPU */
+int pbrh_set_materials(pbrh_renderer* r, const float* m0, const float* m1, const float* m2, const float* depth, const uint8_t* stencil);
 int pbrh_set_initial_luminance(pbrh_renderer* r, float v);
 /* one frame through RenderScheduler::ExecutePipeline; blocks until the GPU is done */
 int pbrh_render(pbrh_renderer* r, float delta_time);

@@ -92,8 +92,11 @@ class DeferredFrame:
     """Owns the device buffers of one rank and runs the per-frame passes through the C ABI."""
 
     def __init__(self, ctx: PbrContext, spec: TileSpec, g: Global, lights_np, lut, lut_res, env, env_size,
-                 env_mips=ENV_MIPS, allreduce=None):
+                 env_mips=ENV_MIPS, allreduce=None, sky=None):
+        """sky: optional (cube tensor fp32 RGBA with mips, size, mips) — resolved on stencil == 0 pixels
+        before the shade like the reference's SkyboxPass; without it those pixels keep what the buffer holds."""
         self.ctx, self.spec, self.g = ctx, spec, g
+        self.sky = sky
         self.n_lights = int(len(lights_np))
         self.lights = ctx.upload(lights_np) if self.n_lights else None
         # env: plain prefiltered chain (pbr_prefilter_env); the shade samples its padded copy (one-shot)
@@ -128,6 +131,11 @@ class DeferredFrame:
         self.ctx.cluster_build(self.g, self.clusters)
         self.ctx.cluster_cull(self.g, self.lights, self.n_lights, self.clusters)
 
+    def skybox(self):
+        s = self.spec
+        cube, size, mips = self.sky
+        self.ctx.skybox(self.g, self.tile, cube, size, mips, self.gb["stencil"], s.ew, self.hdr, s.ew)
+
     def shade(self):
         s = self.spec
         self.ctx.deferred_shade(self.g, self.tile, self.gb, s.ew, self.lut, self.lut_res, self.env, self.env_size,
@@ -157,6 +165,8 @@ class DeferredFrame:
     def render(self):
         """One frame: every per-frame dispatch of the reference, in the frame graph's order."""
         self.clustered()
+        if self.sky is not None:
+            self.skybox()
         self.shade()
         self.bloom_histogram()
         if self.allreduce is not None:

@@ -73,6 +73,33 @@ def gbuffer_tile(x0, y0, w, h, full_w, full_h, near=0.1, far=1000.0, rough_min=4
     return {"A": A.astype(np.uint32), "B": B.astype(np.uint32), "C": Cc.astype(np.uint32), "depth": depth, "stencil": stencil}
 
 
+SEED_MATERIAL = 0x5EED0020
+
+
+def material_tile(x0, y0, w, h, full_w, full_h, seed=SEED_MATERIAL):
+    """Per-pixel material attributes as the rasterizer + texture fetches hand them to gbuffer.hlsl::ps_main:
+    three float32 [h,w,4] planes — m0 = (albedo.rgb in gamma space, emission), m1 = (un-normalised world
+    normal, roughness), m2 = (metallic, ambient occlusion, 0, 0).  Values uniform in [0,1] (normal components
+    in [-1,1], length in [0.2, 1.7]); one pixel in 64 carries an out-of-range value (< 0 or > 1) in emission /
+    roughness / AO to exercise UNORM saturation."""
+    ys, xs = np.meshgrid(np.arange(y0, y0 + h, dtype=np.uint64), np.arange(x0, x0 + w, dtype=np.uint64), indexing="ij")
+    idx = (ys * np.uint64(full_w) + xs) & _M32
+    u = [_unit(hash_stream(idx, seed, k)).astype(np.float32) for k in range(12)]
+    m0 = np.stack([u[0], u[1], u[2], u[3]], axis=-1)
+    n = np.stack([2 * u[4] - 1, 2 * u[5] - 1, 2 * u[6] - 1], axis=-1)
+    ln = np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 0.2)
+    n = np.where(np.linalg.norm(n, axis=-1, keepdims=True) < 0.2, np.float32([0.0, 0.2, 0.0]), n).astype(np.float32)
+    m1 = np.concatenate([n, u[7][..., None]], axis=-1)
+    m2 = np.stack([u[8], u[9], np.zeros_like(u[8]), np.zeros_like(u[8])], axis=-1)
+    wild = (hash_stream(idx, seed, 12) & np.uint32(63)) == 0
+    m0[..., 3] = np.where(wild, 3.0 * u[3] - 1.0, m0[..., 3])
+    m1[..., 3] = np.where(wild, 3.0 * u[7] - 1.0, m1[..., 3])
+    m2[..., 1] = np.where(wild, 3.0 * u[9] - 1.0, m2[..., 1])
+    del ln
+    return (np.ascontiguousarray(m0, dtype=np.float32), np.ascontiguousarray(m1, dtype=np.float32),
+            np.ascontiguousarray(m2, dtype=np.float32))
+
+
 def lights_in_view_box(n, camera: Camera, seed=SEED_LIGHTS, radius=2.0, intensity=10.0):
     """n lights uniform in the view-space box x[-25,25] y[-8,8] z[1,60], moved to world space."""
     i = np.arange(n, dtype=np.uint64)

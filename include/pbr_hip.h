@@ -200,6 +200,23 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
                               const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
                               pbr_half* hdr, uint32_t hdr_pitch);
 
+/* ---- SURVEY 8f "next" rows: the two raster passes either side of the shade, minus rasterization ---- */
+/* skybox.hlsl:12-28 (SkyboxPass::Execute, DeferredPipeline.cpp:59-75): the sky sphere is drawn at the far
+ * plane with depth test and no depth write, i.e. it lands exactly on the pixels geometry did not cover
+ * (stencil == 0).  hdr(px) = SkyBox.Sample(LinearWrap, camera ray through px).rgb, alpha 1; pixels with
+ * stencil > 0 are left untouched (the shade overwrites them).  The sampler's implicit LOD is defined as
+ * log2 of the larger forward-difference footprint (in mip-0 texels) of the ray on the centre pixel's face. */
+pbr_status pbr_skybox(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile, const pbr_cube_f32* sky,
+                      const uint8_t* stencil, uint32_t pitch, pbr_half* hdr, uint32_t hdr_pitch);
+
+/* gbuffer.hlsl::ps_main :88-149 without the rasterizer / texture fetches: per-pixel material attributes ->
+ * G-buffer planes.  m0 = (albedo.rgb as authored (gamma space), emission), m1 = (normal_ws.xyz, roughness),
+ * m2 = (metallic, ambient occlusion, -, -): three float4 planes of pitch `pitch` pixels.
+ * A = UNORM8(decode_gamma(albedo), emission), B = UNORM8(octahedral(normalize(n)), 1, 0),
+ * C = UNORM8(roughness, metallic, ao, 0)  (global.hlsli:73-77,101-133; formats DeferredPipeline.h:107-109). */
+pbr_status pbr_gbuffer_encode(pbr_ctx* ctx, const float* m0, const float* m1, const float* m2,
+                              uint32_t w, uint32_t h, uint32_t pitch, uint32_t* A, uint32_t* B, uint32_t* C);
+
 /* bloom_prefilter.hlsl:17-60 (DeferredPipeline.cpp:411-427): hdr (w x h) -> out (w>>1 x h>>1). */
 pbr_status pbr_bloom_prefilter(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h,
                                uint32_t pitch, pbr_half* out, float threshold, float knee);

@@ -69,6 +69,8 @@ def lib():
         L.orc_cluster_cull.argtypes = [C.POINTER(Global), _vp, _int, _vp]
         L.orc_deferred_shade.argtypes = [C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer), _vp, _u32, _vp, _u32,
                                          _u32, _vp, _vp, _vp, _u32, _vp]
+        L.orc_skybox.argtypes = [C.POINTER(Global), C.POINTER(Tile), _vp, _u32, _u32, _vp, _u32, _vp, _u32]
+        L.orc_gbuffer_encode.argtypes = [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]
         L.orc_bloom_prefilter.argtypes = [_vp, _u32, _u32, _u32, _vp, _f32, _f32]
         L.orc_blur_h.argtypes = [_vp, _u32, _u32, _vp, _u32, _u32]
         L.orc_blur_v.argtypes = [_vp, _u32, _u32, _vp, _u32, _u32]
@@ -231,6 +233,21 @@ def deferred_shade(g, tile: Tile, gb, lut, env, env_size, env_mips, clusters, li
                                  _p(clusters), _p(lights) if len(lights) else None, _p(hdr), w,
                                  _p(f32) if want_f32 else None), "deferred_shade")
     return hdr, f32
+
+
+def skybox(g, tile: Tile, sky, sky_size, sky_mips, stencil, hdr):
+    """In place on hdr [h,w,4] half: sky colour where stencil == 0."""
+    h, w = stencil.shape
+    stencil = np.ascontiguousarray(stencil)
+    _ok(lib().orc_skybox(C.byref(g), C.byref(tile), _p(sky), sky_size, sky_mips, _p(stencil), w, _p(hdr), w), "skybox")
+    return hdr
+
+
+def gbuffer_encode(m0, m1, m2):
+    h, w = m0.shape[:2]
+    A, B, Cc = (np.zeros((h, w), dtype=np.uint32) for _ in range(3))
+    _ok(lib().orc_gbuffer_encode(_p(m0), _p(m1), _p(m2), w, h, w, _p(A), _p(B), _p(Cc)), "gbuffer_encode")
+    return A, B, Cc
 
 
 def bloom_prefilter(hdr, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE):

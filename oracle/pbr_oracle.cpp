@@ -824,6 +824,77 @@ int orc_deferred_shade(const pbr_global* g, const pbr_tile* tile, const pbr_gbuf
     return PBR_OK;
 }
 
+// ==================================================================== 8f-1: skybox.hlsl:12-28
+namespace {
+// face coordinates (sc/ma, tc/ma in [-1,1]) of `d` on a GIVEN face (no major-axis test)
+static inline void cube_project_on_face(V3 d, uint32_t face, float& u, float& v) {
+    float sc, tc, ma;
+    switch (face) {
+        case 0: ma = d.x;  sc = -d.z; tc = -d.y; break;
+        case 1: ma = -d.x; sc = d.z;  tc = -d.y; break;
+        case 2: ma = d.y;  sc = d.x;  tc = d.z;  break;
+        case 3: ma = -d.y; sc = d.x;  tc = -d.z; break;
+        case 4: ma = d.z;  sc = d.x;  tc = -d.y; break;
+        default: ma = -d.z; sc = -d.x; tc = -d.y; break;
+    }
+    u = sc / ma;
+    v = tc / ma;
+}
+}  // namespace
+
+int orc_skybox(const pbr_global* g, const pbr_tile* tile, const float* sky, uint32_t sky_size, uint32_t sky_mips,
+               const uint8_t* stencil, uint32_t pitch, uint16_t* hdr, uint32_t hdr_pitch) {
+    if (!g || !tile || !sky || !stencil || !hdr) return PBR_ERR_INVALID;
+    CubeF32 cube{sky, sky_size, sky_mips};
+    const float near_height = 2 * g->Near * tanf(g->Fov / 2);
+    const float near_width = near_height * g->Ratio;
+    auto ray = [&](float gx, float gy) {   // world-space camera ray through the centre of global pixel (gx, gy)
+        float u = (gx + 0.5f) / (float)tile->full_w, v = (gy + 0.5f) / (float)tile->full_h;
+        float ndc_x = 2.0f * u - 1.0f, ndc_y = 1.0f - 2.0f * v;
+        return mul_m4_dir(g->InvView, v3(ndc_x * 0.5f * near_width, ndc_y * 0.5f * near_height, g->Near));
+    };
+#pragma omp parallel for schedule(static)
+    for (int64_t py = 0; py < (int64_t)tile->h; py++)
+        for (uint32_t px = 0; px < tile->w; px++) {
+            if (stencil[(size_t)py * pitch + px] != 0) continue;
+            const float gx = (float)(tile->x0 + px), gy = (float)(tile->y0 + (uint32_t)py);
+            V3 d = ray(gx, gy);
+            uint32_t face; float fu, fv;
+            cube_face_uv(d, face, fu, fv);
+            float u0, v0, ux, vx, uy, vy;
+            cube_project_on_face(d, face, u0, v0);
+            cube_project_on_face(ray(gx + 1.0f, gy), face, ux, vx);
+            cube_project_on_face(ray(gx, gy + 1.0f), face, uy, vy);
+            const float half_size = 0.5f * (float)sky_size;
+            float rx = half_size * sqrtf((ux - u0) * (ux - u0) + (vx - v0) * (vx - v0));
+            float ry = half_size * sqrtf((uy - u0) * (uy - u0) + (vy - v0) * (vy - v0));
+            float lod = log2f(fmaxf(rx, ry));
+            F4 c = cube_trilinear(sky_size, sky_mips, d, lod, cube);
+            store_h4(hdr + 4 * ((size_t)py * hdr_pitch + px), f4(c.x, c.y, c.z, 1.0f));
+        }
+    return PBR_OK;
+}
+
+// ==================================================================== 8f-2: gbuffer.hlsl::ps_main :88-149
+int orc_gbuffer_encode(const float* m0, const float* m1, const float* m2, uint32_t w, uint32_t h, uint32_t pitch,
+                       uint32_t* A, uint32_t* B, uint32_t* C) {
+    if (!m0 || !m1 || !m2 || !A || !B || !C) return PBR_ERR_INVALID;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const size_t i = (size_t)y * pitch + x;
+            const float* a = m0 + 4 * i; const float* b = m1 + 4 * i; const float* c = m2 + 4 * i;
+            // decode_gamma (global.hlsli:73-77): pow(c, 2.2) per channel
+            uint32_t pa = unorm8(powf(a[0], 2.2f)) | (unorm8(powf(a[1], 2.2f)) << 8) | (unorm8(powf(a[2], 2.2f)) << 16) | (unorm8(a[3]) << 24);
+            V3 n = normalize3(v3(b[0], b[1], b[2]));
+            float uv[2];
+            orc_octa_encode(&n.x, uv);
+            uint32_t pb = unorm8(uv[0]) | (unorm8(uv[1]) << 8) | (255u << 16);   // (pack_normal, 1, 0)
+            uint32_t pc = unorm8(b[3]) | (unorm8(c[0]) << 8) | (unorm8(c[1]) << 16);
+            A[i] = pa; B[i] = pb; C[i] = pc;
+        }
+    return PBR_OK;
+}
+
 // ==================================================================== a14: bloom_prefilter.hlsl:17-60
 int orc_bloom_prefilter(const uint16_t* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                         uint16_t* out, float threshold, float knee) {

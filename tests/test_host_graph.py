@@ -27,6 +27,7 @@ def host():
     L.pbrh_last_error.restype = C.c_char_p
     L.pbrh_last_error.argtypes = [C.c_void_p]
     L.pbrh_set_skybox.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.pbrh_set_materials.argtypes = [C.c_void_p] * 6
     L.pbrh_set_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.pbrh_set_gbuffer.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.pbrh_set_initial_luminance.argtypes = [C.c_void_p, C.c_float]
@@ -89,7 +90,7 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
         assert host.pbrh_set_gbuffer(r, *[np.ascontiguousarray(gb[k]).ctypes.data for k in ("A", "B", "C", "depth", "stencil")]) == 0
         assert host.pbrh_set_initial_luminance(r, 0.18) == 0
         assert host.pbrh_render(r, 1.0 / 60.0) == 0, host.pbrh_last_error(r)
-        assert host.pbrh_dispatch_count(r) == 5 + 1 + 2 + 1 + 16 + 2 + 1      # first frame incl. one-shot IBL
+        assert host.pbrh_dispatch_count(r) == 5 + 1 + 2 + 1 + 1 + 16 + 2 + 1      # first frame incl. one-shot IBL; sky draw + shade
         buf = C.create_string_buffer(512)
         assert host.pbrh_execution_order(r, buf, 512) == 0 and buf.value.decode() == REFERENCE_ORDER
 
@@ -115,19 +116,20 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
         for f in ("InvView", "View", "Projection", "CameraPos"):      # C++ Camera == Python Camera
             assert np.allclose(np.array(getattr(g_host, f)[:]), np.array(getattr(g, f)[:]), rtol=1e-6, atol=1e-7), f
         assert bytes(g_host.SkyBoxSH) == bytes(g.SkyBoxSH)
-        fr = DeferredFrame(ctx, TileSpec(0, 0, W, H, W, H, 0), g_host, lights, lut, LUT, env, ENV, 5)
+        fr = DeferredFrame(ctx, TileSpec(0, 0, W, H, W, H, 0), g_host, lights, lut, LUT, env, ENV, 5, sky=(sky, ENV, sky_mips))
         fr.upload_gbuffer(gb)
         fr.set_prev_luminance(0.18)
         fr.render()
         hdr_py = fr.hdr.cpu().view(torch.int16).numpy().view(np.float16)
         on = gb["stencil"] > 0
-        assert np.array_equal(hdr1[on].view(np.uint16), hdr_py[on].view(np.uint16))
-        assert np.array_equal(ldr1[on], fr.ldr_numpy()[on])
+        assert (~on).sum() > 1000                                   # the sky pass had pixels to resolve
+        assert np.array_equal(hdr1.view(np.uint16), hdr_py.view(np.uint16))
+        assert np.array_equal(ldr1, fr.ldr_numpy())
         assert avg1 == fr.avg.cpu().numpy()[0]
 
         # --- second frame: one-shot passes latched (mReady), 22 dispatches, exposure keeps adapting
         assert host.pbrh_render(r, 1.0 / 60.0) == 0
-        assert host.pbrh_dispatch_count(r) == 22
+        assert host.pbrh_dispatch_count(r) == 23
         avg2 = read("AverageLuminance", (1,), np.float32)[0]
         fr.render()
         assert avg2 == fr.avg.cpu().numpy()[0] and avg2 != avg1
@@ -139,11 +141,27 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
         orc.cluster_cull(g_host, lights, cl)
         from direct12pbrrenderer_amd.structs import Tile
         want, _ = orc.deferred_shade(g_host, Tile(0, 0, W, H, W, H), gb, lut_np, env_np, ENV, 5, cl, lights)
+        sky_full = sky.cpu().numpy()
+        orc.skybox(g_host, Tile(0, 0, W, H, W, H), sky_full, ENV, sky_mips, gb["stencil"], want)
         orc.bloom(want)
-        scale = np.abs(want.astype(np.float32)[on][:, :3]).max()
-        d = common.half_ulp_diff(hdr1[on][:, :3], want[on][:, :3])
+        scale = np.abs(want.astype(np.float32)[:, :, :3]).max()
+        d = common.half_ulp_diff(hdr1[:, :, :3], want[:, :, :3])
         assert (d > 2).mean() <= 1e-3, (d.max(), (d > 2).mean())   # rare slice/threshold flips move a single pixel
-        assert np.abs(hdr1.astype(np.float32) - want.astype(np.float32))[on][:, :3].max() <= 5e-3 * scale
+        assert np.abs(hdr1.astype(np.float32) - want.astype(np.float32))[:, :, :3].max() <= 5e-3 * scale
         assert bloom_chain_texels(W, H) == 320 * 192 + 160 * 96 + 80 * 48 + 40 * 24 + 20 * 12
+
+        # --- third frame from the rasterizer's material attributes: GBufferPass encodes them on the GPU
+        m0, m1, m2 = synth.material_tile(0, 0, W, H, W, H)
+        assert host.pbrh_set_materials(r, m0.ctypes.data, m1.ctypes.data, m2.ctypes.data,
+                                       np.ascontiguousarray(gb["depth"]).ctypes.data, np.ascontiguousarray(gb["stencil"]).ctypes.data) == 0
+        assert host.pbrh_render(r, 1.0 / 60.0) == 0, host.pbrh_last_error(r)
+        assert host.pbrh_dispatch_count(r) == 24
+        wantA, wantB, wantC = orc.gbuffer_encode(m0, m1, m2)
+        assert np.array_equal(read("GBufferB", (H, W), np.uint32), wantB)
+        assert np.array_equal(read("GBufferC", (H, W), np.uint32), wantC)
+        gotA = read("GBufferA", (H, W), np.uint32)
+        assert np.abs(gotA.view(np.uint8).astype(np.int16) - wantA.view(np.uint8).astype(np.int16)).max() <= 1
+        hdr3 = read("DeferredShadingRT", (H, W, 4), np.float16)
+        assert np.isfinite(hdr3.astype(np.float32)[on]).mean() > 0.99 and not np.array_equal(hdr3, hdr1)
     finally:
         host.pbrh_destroy(r)

@@ -71,4 +71,22 @@ def frame_times(name, spec, n_lights, what):
 frame_times("cfg2", TileSpec(0, 0, 1920, 1080, 1920, 1080, 0), 1, "1920x1080 G-buffer, 1 point light + IBL")
 frame_times("cfg4", TileSpec(0, 0, 3840, 2160, 3840, 2160, 0), 256, "3840x2160 G-buffer, 256 clustered lights + IBL (bench.py headline)")
 frame_times("cfg5", TileSpec(1920, 0, 1920, 2160, 7680, 4320, 256), 256, "one of 8 ranks of the 7680x4320 frame: 1920x2160 tile + 256-px apron")
+
+# ---- SURVEY 8f "next" rows at the headline size: G-buffer encode (48 B in + 12 B out per pixel) and a full-screen sky
+W4, H4 = 3840, 2160
+band = synth.material_tile(0, 0, W4, 216, W4, H4)                      # tile the planes from one band (host time)
+m = [ctx.upload(np.ascontiguousarray(np.tile(p, (10, 1, 1)))) for p in band]
+A4, B4, C4 = (ctx.zeros((H4, W4), torch.int32) for _ in range(3))
+ms = bench.time_stage(lambda: ctx.gbuffer_encode(m[0], m[1], m[2], W4, H4, W4, A4, B4, C4), 20)
+emit(config="8f", what="G-buffer encode 3840x2160 (gbuffer.hlsl ps_main; 60 B/pixel)", ms=round(ms, 4),
+     Mpixel_per_s=round(W4 * H4 / ms / 1e3, 1), GBps_algorithmic=round(60.0 * W4 * H4 / ms / 1e6, 1))
+del m
+cam4 = scene.Camera.reference_default(W4, H4)
+g4 = scene.make_global(cam4, W4, H4, sh_pack=sh)
+from direct12pbrrenderer_amd.structs import Tile  # noqa: E402
+st0 = ctx.zeros((H4, W4), torch.uint8)
+hdr4 = ctx.zeros((H4, W4, 4), torch.float16)
+ms = bench.time_stage(lambda: ctx.skybox(g4, Tile(0, 0, W4, H4, W4, H4), sky, 512, sky_mips, st0, W4, hdr4, W4), 20)
+emit(config="8f", what="skybox resolve 3840x2160, every pixel sky (512^2 fp32 cube; 9 B/pixel + cube reads)", ms=round(ms, 4),
+     Mpixel_per_s=round(W4 * H4 / ms / 1e3, 1))
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bench_configs.json"), "w"), indent=1)
