@@ -1,6 +1,6 @@
 // raster.hip — the two raster passes either side of the shade, minus the rasterizer:
 //   k_skybox          skybox.hlsl:12-28         (SkyboxPass::Execute, DeferredPipeline.cpp:59-75)
-//   k_gbuffer_encode  gbuffer.hlsl::ps_main :88-149  (GBufferPass, DeferredPipeline.cpp:24-57)
+//   k_gbuffer_encode  gbuffer.hlsl::ps_main :88-149  (GBufferPass::Execute, DeferredPipeline.cpp:138-185)
 // Both are streaming, HBM-bound kernels: one lane per pixel, rows contiguous across the wave.
 // Built with -ffp-contract=off: same operation order as the oracle (the ray feeds floor() in the
 // cube addressing, the gamma/octahedral results feed UNORM8 rounding).
@@ -69,6 +69,13 @@ __global__ __launch_bounds__(256) void k_skybox(SkyParams p, const float* __rest
 
 __device__ __forceinline__ uint32_t unorm8(float x) { return (uint32_t)floorf(saturatef(x) * 255.0f + 0.5f); }
 __device__ __forceinline__ float sign_custom(float x) { return x < 0.0f ? -1.0f : 1.0f; }
+// decode_gamma (global.hlsli:73-77): pow(c, 2.2) the way the shader compiler lowers it, exp2(2.2 * log2(c)) on
+// the transcendental unit (v_log_f32 / v_exp_f32, 1 ULP each).  The result only feeds an 8-bit UNORM target:
+// relative error < 1e-6 moves a value across a rounding boundary on ~1e-4 of the texels (by one step).
+// pow(0) = 0, pow(negative) = NaN -> saturate -> 0, like the libm formulation.
+__device__ __forceinline__ float decode_gamma(float c) {
+    return __builtin_amdgcn_exp2f(2.2f * __builtin_amdgcn_logf(c));
+}
 
 __global__ __launch_bounds__(256) void k_gbuffer_encode(const float4* __restrict__ m0, const float4* __restrict__ m1,
                                                         const float4* __restrict__ m2, uint32_t w, uint32_t h,
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_encode(const float4* __restrict
     const size_t i = (size_t)y * pitch + x;
     const float4 a = m0[i], b = m1[i], c = m2[i];
     // decode_gamma, global.hlsli:73-77
-    const uint32_t pa = unorm8(powf(a.x, 2.2f)) | (unorm8(powf(a.y, 2.2f)) << 8) | (unorm8(powf(a.z, 2.2f)) << 16) |
+    const uint32_t pa = unorm8(decode_gamma(a.x)) | (unorm8(decode_gamma(a.y)) << 8) | (unorm8(decode_gamma(a.z)) << 16) |
                         (unorm8(a.w) << 24);
     // pack_normal(normalize(n)), global.hlsli:117-128
     V3 n = normalize3_exact(v3(b.x, b.y, b.z));

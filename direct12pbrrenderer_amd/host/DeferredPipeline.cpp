@@ -167,7 +167,10 @@ void ClusteredPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:208-
     if (context->Scene->GetLightCount() > (uint32)MaxSceneLights) throw HipException("ClusteredPass: more than MaxSceneLights lights");
     std::vector<pbr_light> lights(MaxSceneLights);
     int i = 0;
-    context->Scene->CullLight([&](SceneLight* light) {
+    // frustum culling point lights (DeferredPipeline.cpp:224-241): membership and buffer order come from the octree walk
+    const Matrix4x4 view_projection = context->Camera->GetProjectionMatrix() * context->Camera->GetLocalSpaceMatrix();
+    const FrustumVolume volume = FrustumVolume::FromMatrix(view_projection.m);
+    context->Scene->CullLight(volume, [&](SceneLight* light) {
         const Vector3 p = light->GetTranslation(), c = light->GetColor();
         const PointLightAttenuation& a = light->GetAttenuationCoefficients();
         lights[i++] = pbr_light{{p.x, p.y, p.z}, {c.x, c.y, c.z}, light->GetIntensity(), a.Radius, a.ConstantCoefficent, a.LinearCoefficent, a.QuadraticCoefficent};

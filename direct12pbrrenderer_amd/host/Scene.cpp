@@ -5,6 +5,17 @@
 
 namespace MRendererHip {
 
+Matrix4x4 operator*(const Matrix4x4& a, const Matrix4x4& b) {
+    Matrix4x4 r{};
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < 4; k++) acc += a.At(i, k) * b.At(k, j);
+            r.At(i, j) = acc;
+        }
+    return r;
+}
+
 Matrix4x4 ProjectionMatrix1(float fov, float ratio, float near_z, float far_z) {   // MathLib.cpp:35-68
     const float htan = std::tan(fov * 0.5f);
     const float r = near_z * ratio * htan, l = -r, t = near_z * htan, b = -t;

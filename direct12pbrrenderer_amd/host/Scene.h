@@ -12,10 +12,9 @@
 #include <vector>
 
 #include "HipCommandList.h"
+#include "LightCull.h"
 
 namespace MRendererHip {
-
-struct Vector3 { float x, y, z; };
 
 struct Matrix4x4 {
     float m[16];   // row-major, M*v
@@ -28,6 +27,7 @@ struct Matrix4x4 {
     float At(int r, int c) const { return m[r * 4 + c]; }
 };
 
+Matrix4x4 operator*(const Matrix4x4& a, const Matrix4x4& b);
 Matrix4x4 ProjectionMatrix1(float fov, float ratio, float near_z, float far_z);
 Matrix4x4 QuickInverse(const Matrix4x4& m);
 Matrix4x4 Inverse(const Matrix4x4& m);
@@ -67,6 +67,12 @@ public:
     float GetRadius() const { return mRadius; }
     float GetIntensity() const { return mIntensity; }
     const PointLightAttenuation& GetAttenuationCoefficients() const { return mAttenuation; }
+    // at ~1.81418 * radius the preset attenuation falls below 1/256 (Scene.h:118); Scene.cpp:122-130
+    static constexpr float CullingRadiusCoefficient = 1.81418f;
+    AABB GetWorldBound() const {
+        const float r = mRadius * CullingRadiusCoefficient * std::sqrt(mIntensity);
+        return AABB{{mTranslation.x - r, mTranslation.y - r, mTranslation.z - r}, {mTranslation.x + r, mTranslation.y + r, mTranslation.z + r}};
+    }
     static PointLightAttenuation CaclAttenuationCoefficients(float radius);   // Scene.cpp:132-165 (step function, quirk Q18)
 protected:
     Vector3 mTranslation, mColor;
@@ -98,18 +104,27 @@ struct GBufferSource {
 
 class Scene {
 public:
-    void AddLight(const SceneLight& l) { mLights.push_back(l); }
-    void ClearLights() { mLights.clear(); }
+    static constexpr float WorldBound = 1000.0f;   // Scene.h:194
+    // Scene::AddSceneLight -> AddOctreeElementInternal (Scene.h:246-258)
+    void AddLight(const SceneLight& l) {
+        if (!mOctreeSceneLight.AddObject(l.GetWorldBound(), (int)mLights.size()))
+            throw HipException("Scene::AddLight: the light's culling bound leaves the world box (+-500)");
+        mLights.push_back(l);
+    }
+    void ClearLights() { mLights.clear(); mOctreeSceneLight.Reset(WorldBound); }
     uint32 GetLightCount() const { return (uint32)mLights.size(); }
-    // Scene::CullLight(volume, fn): octree frustum cull in the reference (Scene.h:229-237).  The
-    // lights of the synthetic scenes are generated inside the frustum, so every light is visited.
+    const SceneLight* LightAt(size_t i) const { return &mLights[i]; }
+    // call fn for each light whose bound intersects the frustum, in octree order (Scene.h:229-237)
     template <class Fn>
-    void CullLight(Fn&& fn) { for (auto& l : mLights) fn(&l); }
+    void CullLight(const FrustumVolume& volume, Fn&& fn) {
+        mOctreeSceneLight.FrustumCull(volume, [&](int index) { fn(&mLights[index]); });
+    }
     void SetSkyBox(std::shared_ptr<SkyBox> s) { mSkyBox = std::move(s); }
     SkyBox* GetSkyBox() const { return mSkyBox.get(); }
     GBufferSource& GBuffer() { return mGBuffer; }
 private:
     std::vector<SceneLight> mLights;
+    LightOctree mOctreeSceneLight{WorldBound};
     std::shared_ptr<SkyBox> mSkyBox;
     GBufferSource mGBuffer;
 };

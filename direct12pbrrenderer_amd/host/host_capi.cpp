@@ -152,6 +152,27 @@ int pbrh_get_global(const pbrh_renderer* r, void* dst) {
     return 0;
 }
 
+// CPU-only: the reference default camera (App.cpp:99-101) moved/rotated as given, a Scene with the n lights
+// added in order, and the light indices Scene::CullLight visits, in visiting order.
+int pbrh_cull_lights(uint32_t width, uint32_t height, const float cam_pos_yaw[4], const float* l, int n, int* indices, int max_indices) {
+    try {
+        Camera camera(0.333f * 3.14159265359f, width, height, 0.1f, 1000.0f);
+        camera.Move(Vector3{cam_pos_yaw[0], cam_pos_yaw[1], cam_pos_yaw[2]});
+        camera.Rotate(0, cam_pos_yaw[3], 0);
+        Scene scene;
+        for (int i = 0; i < n; i++, l += 8) scene.AddLight(SceneLight(Vector3{l[0], l[1], l[2]}, Vector3{l[3], l[4], l[5]}, l[6], l[7]));
+        const Matrix4x4 vp = camera.GetProjectionMatrix() * camera.GetLocalSpaceMatrix();
+        int count = 0;
+        scene.CullLight(FrustumVolume::FromMatrix(vp.m), [&](SceneLight* light) {
+            if (count < max_indices) indices[count] = (int)(light - scene.LightAt(0));
+            count++;
+        });
+        return count;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
 int pbrh_dry_run_execution_order(uint32_t width, uint32_t height, char* buf, size_t len) {
     try {
         DeviceMemory::DryRun() = true;

@@ -33,6 +33,10 @@ long pbrh_read(pbrh_renderer* r, const char* resource_name, void* dst, size_t ds
 /* the global constants the last frame used (412 bytes) */
 int pbrh_get_global(const pbrh_renderer* r, void* dst_412_bytes);
 /* builds DeferredRenderPipeline + FrameGraph without touching a GPU and returns the sorted pass order */
+/* CPU only (no device): which of the n lights (8 floats each, as pbrh_set_lights) Scene::CullLight hands to the
+ * light buffer for the reference camera at cam_pos_yaw = (x, y, z, yaw), and in what order; returns the count
+ * (may exceed max_indices), -1 if a light's culling bound leaves the world box */
+int pbrh_cull_lights(uint32_t width, uint32_t height, const float cam_pos_yaw[4], const float* lights, int n, int* indices, int max_indices);
 int pbrh_dry_run_execution_order(uint32_t width, uint32_t height, char* buf, size_t len);
 /* ShadingState contract probes (no GPU work): 1 = the call returned true */
 int pbrh_probe_binding(const char* shader_file, int is_compute, const char* semantic_name, int kind);

@@ -27,6 +27,7 @@ def host():
     L.pbrh_last_error.restype = C.c_char_p
     L.pbrh_last_error.argtypes = [C.c_void_p]
     L.pbrh_set_skybox.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.pbrh_cull_lights.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.pbrh_set_materials.argtypes = [C.c_void_p] * 6
     L.pbrh_set_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.pbrh_set_gbuffer.argtypes = [C.c_void_p] + [C.c_void_p] * 5
@@ -85,7 +86,15 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
         cam = scene.Camera.reference_default(W, H)
         lights = synth.lights_in_view_box(256, cam)
         packed = np.concatenate([lights["Position"], lights["Color"], np.full((256, 1), 2.0, np.float32), lights["Intensity"][:, None]], axis=1).astype(np.float32)
-        assert host.pbrh_set_lights(r, np.ascontiguousarray(packed).ctypes.data, 256) == 0
+        packed = np.ascontiguousarray(packed)
+        assert host.pbrh_set_lights(r, packed.ctypes.data, 256) == 0
+        # ClusteredPass fills the light buffer in the order Scene::CullLight walks its octree:
+        # the Python / oracle side of this test gets the lights in that order
+        order = np.zeros(256, np.int32)
+        cam4 = np.float32([0.0, 3.0, 10.0, 3.14159265359])
+        assert host.pbrh_cull_lights(W, H, cam4.ctypes.data, packed.ctypes.data, 256, order.ctypes.data, 256) == 256
+        assert sorted(order.tolist()) == list(range(256)) and order.tolist() != list(range(256))
+        lights = lights[order]
         gb = synth.gbuffer_tile(0, 0, W, H, W, H, coverage_mask=True)
         assert host.pbrh_set_gbuffer(r, *[np.ascontiguousarray(gb[k]).ctypes.data for k in ("A", "B", "C", "depth", "stencil")]) == 0
         assert host.pbrh_set_initial_luminance(r, 0.18) == 0
