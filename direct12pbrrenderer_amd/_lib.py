@@ -29,6 +29,7 @@ SIGNATURES = {
     "pbr_last_error": (C.c_char_p, [_vp]),
     "pbr_sync": (_int, [_vp]),
     "pbr_brdf_lut": (_int, [_vp, _u32, _vp]),
+    "pbr_rgbe_decode": (_int, [_vp, _vp, C.c_size_t, _vp]),
     "pbr_cube_gen_mips": (_int, [_vp, _vp, _u32, _u32]),
     "pbr_prefilter_env": (_int, [_vp, C.POINTER(CubeF32), _u32, _u32, _vp]),
     "pbr_prefilter_env_mip": (_int, [_vp, C.POINTER(CubeF32), _u32, _u32, _f32, _vp]),

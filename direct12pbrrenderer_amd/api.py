@@ -135,6 +135,10 @@ class PbrContext:
                                                 _ptr(env), env_size, env_mips, _ptr(clusters), _ptr(lights),
                                                 int(num_lights), _ptr(hdr), hdr_pitch))
 
+    def rgbe_decode(self, rgbe, out):
+        """rgbe: uint8 device tensor [..., 4] (Radiance texels); out: float32 [..., 4]."""
+        self._check(self.lib.pbr_rgbe_decode(self.h, _ptr(rgbe), rgbe.numel() // 4, _ptr(out)))
+
     def skybox(self, g: Global, tile: Tile, sky, sky_size, sky_mips, stencil, pitch, hdr, hdr_pitch):
         """skybox.hlsl: sky colour into hdr where stencil == 0 (run before deferred_shade)."""
         c = CubeF32(sky.data_ptr(), sky_size, sky_mips)

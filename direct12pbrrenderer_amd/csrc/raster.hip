@@ -1,6 +1,7 @@
-// raster.hip — the two raster passes either side of the shade, minus the rasterizer:
+// raster.hip — the passes and data formats either side of the shade, minus the rasterizer:
 //   k_skybox          skybox.hlsl:12-28         (SkyboxPass::Execute, DeferredPipeline.cpp:59-75)
 //   k_gbuffer_encode  gbuffer.hlsl::ps_main :88-149  (GBufferPass::Execute, DeferredPipeline.cpp:138-185)
+//   k_rgbe_decode     Radiance .hdr texels -> fp32 (ResourceLoader::LoadHDRImageFile, ResourceLoader.cpp:381-406)
 // Both are streaming, HBM-bound kernels: one lane per pixel, rows contiguous across the wave.
 // Built with -ffp-contract=off: same operation order as the oracle (the ray feeds floor() in the
 // cube addressing, the gamma/octahedral results feed UNORM8 rounding).
@@ -104,9 +105,31 @@ __global__ __launch_bounds__(256) void k_gbuffer_encode(const float4* __restrict
     A[i] = pa; B[i] = pb; C[i] = pc;
 }
 
+// Radiance RGBE -> fp32 RGBA (4 B in, 16 B out per texel; one texel per lane, grid-stride)
+__global__ __launch_bounds__(256) void k_rgbe_decode(const uint32_t* __restrict__ rgbe, size_t texels, float4* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < texels; i += (size_t)gridDim.x * 256u) {
+        const uint32_t v = rgbe[i];
+        const int e = (int)(v >> 24);
+        // 2^(e-136) built in the exponent field (e-136+127 in [-8, 246]: subnormal scale below e = 10)
+        const float scale = e ? ldexpf(1.0f, e - 136) : 0.0f;
+        out[i] = make_float4((float)(v & 255u) * scale, (float)((v >> 8) & 255u) * scale, (float)((v >> 16) & 255u) * scale, 1.0f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+pbr_status pbr_rgbe_decode(pbr_ctx* ctx, const uint8_t* rgbe, size_t texels, float* out_rgba) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, rgbe && out_rgba && texels, "pbr_rgbe_decode: null pointer / empty image");
+    PBR_REQUIRE(ctx, (((uintptr_t)rgbe & 3u) | ((uintptr_t)out_rgba & 15u)) == 0u, "pbr_rgbe_decode: unaligned buffer");
+    size_t blocks = (texels + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_rgbe_decode, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t*>(rgbe), texels,
+                       reinterpret_cast<float4*>(out_rgba));
+    return pbr::launched(ctx, "k_rgbe_decode");
+}
 
 pbr_status pbr_skybox(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile, const pbr_cube_f32* sky,
                       const uint8_t* stencil, uint32_t pitch, pbr_half* hdr, uint32_t hdr_pitch) {

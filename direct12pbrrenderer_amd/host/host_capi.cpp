@@ -1,7 +1,9 @@
 // host_capi.cpp — C embedding of the pass graph (see pbr_host.h).
 #include "pbr_host.h"
+#include "HdrImage.h"
 
 #include <cstdio>
+#include <cstring>
 #include <string>
 
 #include "DeferredPipeline.h"
@@ -72,6 +74,31 @@ int pbrh_set_skybox(pbrh_renderer* r, const float* cube, uint32_t size) {
         r->scene->SetSkyBox(sky);
         r->pipeline->mPrefilterEnvMapPass->Invalidate();
     });
+}
+
+int pbrh_load_skybox(pbrh_renderer* r, const char* dir) {
+    return guarded(r, [&] {
+        r->scene->SetSkyBox(LoadCubeMap(r->scheduler->CommandList()->Context(), dir));
+        r->pipeline->mPrefilterEnvMapPass->Invalidate();
+    });
+}
+
+// CPU only: parse one .hdr file held in memory; *w, *h and (when rgbe != NULL and rgbe_bytes suffices) the expanded
+// RGBE texels.  Returns 0, or -1 with the reason in err.
+int pbrh_parse_hdr(const uint8_t* file, size_t bytes, uint32_t* w, uint32_t* h, uint8_t* rgbe, size_t rgbe_bytes, char* err, size_t err_len) {
+    try {
+        HdrImage img = ParseRadianceHDR(file, bytes);
+        if (w) *w = img.Width;
+        if (h) *h = img.Height;
+        if (rgbe) {
+            if (rgbe_bytes < img.Rgbe.size()) throw HipException("hdr: output buffer too small");
+            std::memcpy(rgbe, img.Rgbe.data(), img.Rgbe.size());
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", e.what());
+        return -1;
+    }
 }
 
 int pbrh_set_lights(pbrh_renderer* r, const float* l, int n) {

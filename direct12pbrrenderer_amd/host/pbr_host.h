@@ -16,6 +16,10 @@ void pbrh_destroy(pbrh_renderer* r);
 const char* pbrh_last_error(const pbrh_renderer* r);
 /* fp32 RGBA cube mip 0 (host, 6*size*size*4 floats): uploaded, box mips + SH9 computed on the GPU */
 int pbrh_set_skybox(pbrh_renderer* r, const float* cube_mip0, uint32_t size);
+/* LoadCubeMap: <dir>/{px,nx,py,ny,pz,nz}.hdr (Radiance RGBE) -> sky cube + mips + SH9 on the GPU */
+int pbrh_load_skybox(pbrh_renderer* r, const char* dir);
+/* CPU only: parse one .hdr file held in memory (header + flat / run-length scanlines) into RGBE texels */
+int pbrh_parse_hdr(const uint8_t* file, size_t bytes, uint32_t* w, uint32_t* h, uint8_t* rgbe, size_t rgbe_bytes, char* err, size_t err_len);
 /* n lights: position[3], color[3], radius, intensity (8 floats each) */
 int pbrh_set_lights(pbrh_renderer* r, const float* lights, int n);
 int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, const uint32_t* C, const float* depth, const uint8_t* stencil);

@@ -155,6 +155,13 @@ const char* pbr_version(void);
  * out: res*res half2, row-major [y][x]; x -> roughness, y -> NdotV. */
 pbr_status pbr_brdf_lut(pbr_ctx* ctx, uint32_t res, pbr_half* out_rg);
 
+/* Radiance RGBE texels (R, G, B mantissas + shared exponent, 4 bytes) -> fp32 RGBA, alpha 1: the per-texel half of
+ * DirectX::LoadFromHDRFile as called by ResourceLoader::LoadHDRImageFile (ResourceLoader.cpp:381-406; DirectXTex
+ * is an un-vendored, unpinned vcpkg dependency).  Published rule (G. Ward, "Real Pixels", Graphics Gems II):
+ * e == 0 -> 0, else channel = mantissa * 2^(e - 136).  The file-level parse (header, scanline RLE) is host work
+ * (host/HdrImage.h). */
+pbr_status pbr_rgbe_decode(pbr_ctx* ctx, const uint8_t* rgbe, size_t texels, float* out_rgba);
+
 /* 2x2 box mips of an fp32 RGBA cube in place (stands in for DirectXTex GenerateMipMaps,
  * ResourceLoader.cpp:465-507).  cube->data mip 0 must be filled; mips 1.. are written. */
 pbr_status pbr_cube_gen_mips(pbr_ctx* ctx, float* cube_data, uint32_t size, uint32_t mips);

@@ -71,6 +71,7 @@ def lib():
                                          _u32, _vp, _vp, _vp, _u32, _vp]
         L.orc_skybox.argtypes = [C.POINTER(Global), C.POINTER(Tile), _vp, _u32, _u32, _vp, _u32, _vp, _u32]
         L.orc_gbuffer_encode.argtypes = [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]
+        L.orc_rgbe_decode.argtypes = [_vp, C.c_size_t, _vp]
         L.orc_bloom_prefilter.argtypes = [_vp, _u32, _u32, _u32, _vp, _f32, _f32]
         L.orc_blur_h.argtypes = [_vp, _u32, _u32, _vp, _u32, _u32]
         L.orc_blur_v.argtypes = [_vp, _u32, _u32, _vp, _u32, _u32]
@@ -248,6 +249,14 @@ def gbuffer_encode(m0, m1, m2):
     A, B, Cc = (np.zeros((h, w), dtype=np.uint32) for _ in range(3))
     _ok(lib().orc_gbuffer_encode(_p(m0), _p(m1), _p(m2), w, h, w, _p(A), _p(B), _p(Cc)), "gbuffer_encode")
     return A, B, Cc
+
+
+def rgbe_decode(rgbe):
+    """rgbe: uint8 [..., 4] -> float32 [..., 4]."""
+    rgbe = np.ascontiguousarray(rgbe, dtype=np.uint8)
+    out = np.zeros(rgbe.shape, dtype=np.float32)
+    _ok(lib().orc_rgbe_decode(_p(rgbe), rgbe.size // 4, _p(out)), "rgbe_decode")
+    return out
 
 
 def bloom_prefilter(hdr, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE):

@@ -895,6 +895,22 @@ int orc_gbuffer_encode(const float* m0, const float* m1, const float* m2, uint32
     return PBR_OK;
 }
 
+// ==================================================================== 8f-3: Radiance RGBE texel decode
+// ResourceLoader.cpp:381-406 calls DirectX::LoadFromHDRFile (DirectXTex: vcpkg dependency, absent, unpinned);
+// restated from the published format (Ward, "Real Pixels"): e == 0 -> 0, else mantissa * 2^(e - (128 + 8)).
+int orc_rgbe_decode(const uint8_t* rgbe, size_t texels, float* out) {
+    if (!rgbe || !out) return PBR_ERR_INVALID;
+    for (size_t i = 0; i < texels; i++) {
+        const uint8_t* p = rgbe + 4 * i;
+        float f = p[3] ? ldexpf(1.0f, (int)p[3] - 136) : 0.0f;
+        out[4 * i + 0] = (float)p[0] * f;
+        out[4 * i + 1] = (float)p[1] * f;
+        out[4 * i + 2] = (float)p[2] * f;
+        out[4 * i + 3] = 1.0f;
+    }
+    return PBR_OK;
+}
+
 // ==================================================================== a14: bloom_prefilter.hlsl:17-60
 int orc_bloom_prefilter(const uint16_t* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                         uint16_t* out, float threshold, float knee) {

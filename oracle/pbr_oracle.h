@@ -84,6 +84,7 @@ int orc_skybox(const pbr_global* g, const pbr_tile* tile, const float* sky, uint
                const uint8_t* stencil, uint32_t pitch, uint16_t* hdr, uint32_t hdr_pitch);                  /* 8f-1 */
 int orc_gbuffer_encode(const float* m0, const float* m1, const float* m2, uint32_t w, uint32_t h, uint32_t pitch,
                        uint32_t* A, uint32_t* B, uint32_t* C);                                              /* 8f-2 */
+int orc_rgbe_decode(const uint8_t* rgbe, size_t texels, float* out_rgba);                                  /* 8f-3 */
 int orc_bloom_prefilter(const uint16_t* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                         uint16_t* out, float threshold, float knee);               /* a14 */
 int orc_blur_h(const uint16_t* in, uint32_t iw, uint32_t ih, uint16_t* out, uint32_t ow, uint32_t oh);

@@ -505,3 +505,19 @@ def test_skybox_then_shade_compose(ctx, orc, ibl):
     assert d_sky.max() <= 2
     d = common.half_ulp_diff(got[~off][:, :3], want[~off][:, :3])
     assert (d > 2).mean() <= 1e-3
+
+
+@pytest.mark.gpu
+def test_rgbe_decode_bit_exact(ctx, orc):
+    """Radiance RGBE -> fp32: every exponent byte (incl. 0 and the subnormal scales below e = 10) x random mantissas,
+    plus a ragged count; exact (power-of-two scale)."""
+    rng = np.random.default_rng(0x5EED0040)
+    n = 256 * 257 + 13
+    t = rng.integers(0, 256, size=(n, 4), dtype=np.uint8)
+    t[:256 * 257, 3] = np.repeat(np.arange(256, dtype=np.uint8), 257)
+    want = orc.rgbe_decode(t)
+    out = ctx.zeros((n, 4), torch.float32)
+    ctx.rgbe_decode(torch.from_numpy(t).to(ctx.torch_device), out)
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert (want[t[:, 3] == 0][:, :3] == 0).all() and (want[:, 3] == 1).all()

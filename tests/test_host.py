@@ -174,3 +174,62 @@ def test_light_cull_matches_restatement_on_random_scenes():
         assert cnt == len(want) and got == want
         assert 0 < cnt <= n and got != sorted(got)          # octree order, not scene order
         assert cnt < n or spread < 10                       # the wide scenes really lose lights to the frustum
+
+
+# ------------------------------------------------------------------------- .hdr ingestion
+def _parse_hdr(L, blob, cap=None):
+    import ctypes as C
+    L.pbrh_parse_hdr.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    err = C.create_string_buffer(256)
+    if L.pbrh_parse_hdr(blob, len(blob), C.byref(w), C.byref(h), None, 0, err, 256) != 0:
+        return None, err.value.decode()
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    assert L.pbrh_parse_hdr(blob, len(blob), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes if cap is None else cap, err, 256) == (0 if cap is None else -1)
+    return out, err.value.decode()
+
+
+def test_hdr_parse_flat_rle_and_malformed():
+    import hdr_writer
+    L = _host_lib()
+    rng = np.random.default_rng(7)
+    img = rng.uniform(0, 4, size=(12, 40, 3)).astype(np.float32)
+    img[3, 5:30] = (0.25, 0.5, 1.0)            # long runs in every component
+    img[7] = 0.0                                # a black row: exponent byte 0
+    img[9, :, 1] = 1000.0
+    rgbe = hdr_writer.float_to_rgbe(img)
+    assert tuple(rgbe[3, 5]) == (32, 64, 128, 129) and tuple(rgbe[7, 0]) == (0, 0, 0, 0)
+    for rle in (False, True):
+        for crlf in (False, True):
+            blob = hdr_writer.encode_hdr(rgbe, rle=rle, extra_header=("# made by tests", "EXPOSURE=1.0"), crlf=crlf)
+            got, err = _parse_hdr(L, blob)
+            assert got is not None, err
+            assert np.array_equal(got, rgbe)
+    assert len(hdr_writer.encode_hdr(rgbe, rle=True)) < len(hdr_writer.encode_hdr(rgbe, rle=False))
+    # a 4-wide image is always flat (RLE needs 8 <= w < 32768)
+    small = hdr_writer.float_to_rgbe(rng.uniform(0, 1, size=(4, 4, 3)))
+    got, _ = _parse_hdr(L, hdr_writer.encode_hdr(small, rle=True))
+    assert np.array_equal(got, small)
+    good = hdr_writer.encode_hdr(rgbe, rle=True)
+    for blob, why in [(b"#?RADIANCX" + good[10:], "signature"), (good[:-7], "truncated"), (good.replace(b"32-bit_rle_rgbe", b"32-bit_rle_xyze"), "unsupported"),
+                      (good.replace(b"-Y 12 +X 40", b"+Y 12 +X 40"), "resolution"), (good.replace(b"-Y 12 +X 40", b"-Y 12 +X 48"), "width"),
+                      (good.replace(b"FORMAT=32-bit_rle_rgbe\n", b"EXPOSURE=2.0\nFORMAT=32-bit_rle_rgbe\n"), "EXPOSURE"), (b"", "small")]:
+        got, err = _parse_hdr(L, blob)
+        assert got is None and why in err, (why, err)
+    _, err = _parse_hdr(L, good, cap=16)
+    assert "too small" in err
+
+
+def test_rgbe_decode_oracle_known_answers(orc):
+    # published rule: e == 0 -> 0, else mantissa * 2^(e - 136); alpha 1
+    t = np.uint8([[128, 64, 32, 129], [255, 0, 1, 128], [9, 9, 9, 0], [1, 2, 3, 136], [255, 255, 255, 255], [1, 0, 0, 1]])
+    d = orc.rgbe_decode(t).astype(np.float64)
+    assert d[0].tolist() == [1.0, 0.5, 0.25, 1.0]
+    assert d[1].tolist() == [255 / 256, 0.0, 1 / 256, 1.0]
+    assert d[2].tolist() == [0.0, 0.0, 0.0, 1.0]
+    assert d[3].tolist() == [1.0, 2.0, 3.0, 1.0]
+    assert d[4, 0] == 255.0 * 2.0 ** 119 and d[5, 0] == 2.0 ** -135           # top of the range, a subnormal
+    import hdr_writer
+    x = np.exp(np.random.default_rng(3).uniform(-20, 20, size=(1000, 3))).astype(np.float32)
+    back = orc.rgbe_decode(hdr_writer.float_to_rgbe(x))[:, :3]
+    assert np.all(back <= x) and np.all(x - back <= x.max(axis=1, keepdims=True) / 128.0)   # truncating 8-bit mantissa
