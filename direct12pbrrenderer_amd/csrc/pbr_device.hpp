@@ -63,28 +63,33 @@ struct alignas(4) H2 { h16 x, y; };
 
 // ---- software samplers (sampler s3 LinearClamp / s1 PointClamp, D3D12Device.cpp:665-684) -----
 struct BilinearCoord { int i0, i1; float f; };
+// D3D fixed-function addressing: u*size snapped to x.8 fixed point (round to nearest,
+// D3D12_SUBTEXEL_FRACTIONAL_BIT_COUNT = 8), then the half-texel offset; weight = multiple of 1/256
+__device__ __forceinline__ float snap8(float x) { return floorf(x * 256.0f + 0.5f) * (1.0f / 256.0f); }
 __device__ __forceinline__ BilinearCoord bilinear_coord(float u, int size) {
-    float x = u * (float)size - 0.5f;
-    x = (x == x) ? x : 0.0f;
-    x = fminf(fmaxf(x, -2.0f), (float)size + 1.0f);
+    float c = u * (float)size;
+    c = (c == c) ? c : 0.5f;
+    c = fminf(fmaxf(c, -1.5f), (float)size + 1.5f);
+    float x = snap8(c) - 0.5f;
     float fl = floorf(x);
-    BilinearCoord c;
-    c.i0 = (int)fl;
-    c.i1 = c.i0 + 1;
-    c.f = x - fl;
-    return c;
+    BilinearCoord b;
+    b.i0 = (int)fl;
+    b.i1 = b.i0 + 1;
+    b.f = x - fl;
+    return b;
 }
 // a*s + b with one rounding — written explicitly so the result does not depend on -ffp-contract
 __device__ __forceinline__ F4 fma4(F4 a, float s, F4 b) {
     return f4(__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z), __builtin_fmaf(a.w, s, b.w));
 }
-// sampler lerps: the far tap is fused onto the weighted near tap (same operation order as the oracle)
-__device__ __forceinline__ F4 lerp_x(F4 c0, F4 c1, float wx0, float fx) { return fma4(c1, fx, c0 * wx0); }
+// sampler lerps: the far tap is fused onto the weighted near tap (same operation order as the oracle); a tap
+// with weight exactly 0 does not contribute (a sample at a texel centre is that texel, inf/NaN neighbours or not)
+__device__ __forceinline__ F4 lerp4(F4 a, F4 b, float f) {
+    const F4 r = fma4(b, f, a * (1.0f - f));
+    return f == 0.0f ? a : r;
+}
 __device__ __forceinline__ F4 bilerp(F4 c00, F4 c10, F4 c01, F4 c11, float fx, float fy) {
-    float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    F4 top = lerp_x(c00, c10, wx0, fx);
-    F4 bot = lerp_x(c01, c11, wx0, fx);
-    return fma4(bot, fy, top * wy0);
+    return lerp4(lerp4(c00, c10, fx), lerp4(c01, c11, fx), fy);
 }
 // Texture2D<half4>.SampleLevel(LinearClamp, uv, 0)
 __device__ __forceinline__ F4 sample_2d_h4(const pbr_half* img, int w, int h, int pitch, float u, float v) {
@@ -189,7 +194,7 @@ template <class TexelT, class Ptr>
 __device__ __forceinline__ F4 cube_trilinear(Ptr data, uint32_t size, uint32_t mips, V3 dir, float lod) {
     float maxl = (float)(mips - 1);
     lod = (lod == lod) ? lod : 0.0f;
-    lod = fminf(fmaxf(lod, 0.0f), maxl);
+    lod = snap8(fminf(fmaxf(lod, 0.0f), maxl));   // D3D12_MIP_LOD_FRACTIONAL_BIT_COUNT = 8
     float fl = floorf(lod);
     uint32_t l0 = (uint32_t)fl;
     uint32_t l1 = min(l0 + 1, mips - 1);

@@ -266,7 +266,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     {
         const V3 R = normalize3(n * (2.0f * NdV) - view);
         float lod = roughness * (float)PBR_ENV_MIPS;   // Q4: roughness*5 on a 5-mip chain
-        lod = fminf(fmaxf(lod, 0.0f), (float)(p.env_mips - 1));
+        lod = snap8(fminf(fmaxf(lod, 0.0f), (float)(p.env_mips - 1)));   // 8-bit LOD fraction
         const float fl = floorf(lod);
         const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1, p.env_mips - 1);
         const float env_f = lod - fl;
@@ -285,8 +285,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         }
         auto fetch = [&](uint32_t l, uint32_t mip_off) {
             const int s = (int)(p.env_size >> l), sp = s + 2;
-            // u in [0,1] -> texel coordinate in [-0.5, s-0.5]: no NaN / range guard needed here
-            const float fxp = cu * (float)s - 0.5f, fyp = cv * (float)s - 0.5f;
+            // u in [0,1] -> texel coordinate in [-0.5, s-0.5]: no NaN / range guard needed here; x.8 fixed-point snap
+            const float fxp = snap8(cu * (float)s) - 0.5f, fyp = snap8(cv * (float)s) - 0.5f;
             const float flx = floorf(fxp), fly = floorf(fyp);
             const float fx = fxp - flx, fy = fyp - fly;
             const H4* m = reinterpret_cast<const H4*>(p.env) + mip_off;
@@ -338,7 +338,8 @@ template <bool STAGED_LISTS, int LSTRIDE>
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 5   // 96 VGPRs, no spills: best of 4..8 measured (tools/probe_shade.py)
 #endif
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters) {
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters,
+                                                                                 uint32_t nb_big, uint32_t rows_small) {
     extern __shared__ float4 lds_raw[];
     __shared__ uint32_t s_mip_off[16];
     if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
@@ -357,8 +358,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         llds[8 * LSTRIDE + i] = l.C2;
     }
     const uint32_t bx0 = blockIdx.x * SHADE_BLOCK;
-    const uint32_t y_begin = blockIdx.y * SHADE_ROWS;
-    const uint32_t y_end = min(y_begin + SHADE_ROWS, p.h);
+    // two-zone schedule: the first nb_big block rows walk SHADE_ROWS rows each, the rest rows_small — the short
+    // blocks are dispatched last and fill the tail of the launch (a 4K frame is only ~3.2 waves of resident blocks)
+    const uint32_t by = blockIdx.y;
+    const uint32_t y_begin = by < nb_big ? by * SHADE_ROWS : nb_big * SHADE_ROWS + (by - nb_big) * rows_small;
+    const uint32_t y_end = min(y_begin + (by < nb_big ? (uint32_t)SHADE_ROWS : rows_small), p.h);
     int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
     if (STAGED_LISTS) {
         // cluster (x,y) tiles the block's pixel rectangle can fall into — same arithmetic as the per-pixel
@@ -437,7 +441,13 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
     for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)env_padded_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
     p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch;
-    dim3 grid((tile->w + SHADE_BLOCK - 1) / SHADE_BLOCK, (tile->h + SHADE_ROWS - 1) / SHADE_ROWS);
+    // schedule (see the kernel): long blocks first, short ones for the tail
+    static const float big_frac = getenv("PBR_SHADE_BIGFRAC") ? (float)atof(getenv("PBR_SHADE_BIGFRAC")) : 0.85f;
+    static const uint32_t rows_small_cfg = getenv("PBR_SHADE_ROWS_SMALL") ? (uint32_t)atoi(getenv("PBR_SHADE_ROWS_SMALL")) : 2u;
+    const uint32_t rows_small = rows_small_cfg >= 1 && rows_small_cfg <= (uint32_t)SHADE_ROWS ? rows_small_cfg : 2u;
+    uint32_t nb_big = (uint32_t)((float)(tile->h / SHADE_ROWS) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
+    const uint32_t rest = tile->h - nb_big * SHADE_ROWS;
+    dim3 grid((tile->w + SHADE_BLOCK - 1) / SHADE_BLOCK, nb_big + (rest + rows_small - 1) / rows_small);
     // A block covers 256 x 8 pixels.  It can stage its cluster lists when that rectangle spans at most
     // MAX_STAGED_TILES cluster tiles: a tile is full_w/24 x full_h/16 pixels, +1 per axis for straddling.
     const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
@@ -447,10 +457,10 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
     const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
     const size_t lds = (size_t)LIGHT_PLANES * lstride * sizeof(float) + (size_t)max_clusters * LIST_STRIDE_U16 * sizeof(uint16_t);
     const dim3 blk(SHADE_BLOCK);
-    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters);
-    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters);
-    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257>), grid, blk, lds, ctx->stream, p, num_lights, 0);
-    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1>), grid, blk, lds, ctx->stream, p, num_lights, 0);
+    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, nb_big, rows_small);
+    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, nb_big, rows_small);
+    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257>), grid, blk, lds, ctx->stream, p, num_lights, 0, nb_big, rows_small);
+    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1>), grid, blk, lds, ctx->stream, p, num_lights, 0, nb_big, rows_small);
     return launched(ctx, "k_deferred_shade");
 }
 

@@ -117,28 +117,32 @@ static inline void store_h4(uint16_t* p, F4 v) {
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 struct BilinearCoord { int i0, i1; float f; };
-// texel coordinate u*size-0.5, full fp32 fraction, indices NOT yet clamped
+// Fixed-function filter addressing as D3D specifies it: the scaled coordinate u*size is snapped to x.8 fixed
+// point, round to nearest (D3D12_SUBTEXEL_FRACTIONAL_BIT_COUNT = 8), THEN the half-texel offset is removed; the
+// filter weight is therefore a multiple of 1/256 in [0, 255/256].  Indices are NOT yet clamped.
+static inline float snap8(float x) { return floorf(x * 256.0f + 0.5f) * (1.0f / 256.0f); }
 static inline BilinearCoord bilinear_coord(float u, int size) {
-    float x = u * (float)size - 0.5f;
-    if (!(x == x)) x = 0.0f;
-    float lim = (float)size + 1.0f;
-    if (x > lim) x = lim;
-    if (x < -2.0f) x = -2.0f;
+    float c = u * (float)size;
+    if (!(c == c)) c = 0.5f;
+    float lim = (float)size + 1.5f;
+    if (c > lim) c = lim;
+    if (c < -1.5f) c = -1.5f;
+    float x = snap8(c) - 0.5f;
     float fl = floorf(x);
-    BilinearCoord c;
-    c.i0 = (int)fl;
-    c.i1 = c.i0 + 1;
-    c.f = x - fl;
-    return c;
+    BilinearCoord b;
+    b.i0 = (int)fl;
+    b.i1 = b.i0 + 1;
+    b.f = x - fl;
+    return b;
 }
 // a*s + b with ONE rounding (explicit fmaf — the only fused operations of the arithmetic model:
 // the sampler's lerps and the blur's multiply-accumulate, i.e. HLSL `mad`)
 static inline F4 fma4(F4 a, float s, F4 b) { return f4(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y), fmaf(a.z, s, b.z), fmaf(a.w, s, b.w)); }
+// A tap whose weight is exactly 0 does not contribute (so a sample at a texel centre IS that texel, whatever its
+// neighbours hold — inf/NaN included).
+static inline F4 lerp4(F4 a, F4 b, float f) { return f == 0.0f ? a : fma4(b, f, a * (1.0f - f)); }
 static inline F4 bilerp(F4 c00, F4 c10, F4 c01, F4 c11, float fx, float fy) {
-    float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-    F4 top = fma4(c10, fx, c00 * wx0);
-    F4 bot = fma4(c11, fx, c01 * wx0);
-    return fma4(bot, fy, top * wy0);
+    return lerp4(lerp4(c00, c10, fx), lerp4(c01, c11, fx), fy);
 }
 
 // Texture2D<half4>.SampleLevel(SamplerLinearClamp, uv, 0)
@@ -225,6 +229,7 @@ static inline F4 cube_trilinear(uint32_t size, uint32_t mips, V3 dir, float lod,
     float maxl = (float)(mips - 1);
     if (!(lod == lod)) lod = 0.0f;
     lod = lod < 0.0f ? 0.0f : (lod > maxl ? maxl : lod);
+    lod = snap8(lod);   // D3D12_MIP_LOD_FRACTIONAL_BIT_COUNT = 8
     float fl = floorf(lod);
     uint32_t l0 = (uint32_t)fl;
     uint32_t l1 = l0 + 1 < mips ? l0 + 1 : mips - 1;

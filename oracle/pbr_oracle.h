@@ -16,7 +16,10 @@
  * only fused operations are written as explicit fmaf: the samplers' lerps and the blur's
  * multiply-accumulate (HLSL `mad`).  libm transcendentals, dot products evaluated left to right, normalize(v) = v * (1/sqrt(v.v)),
  * lerp(a,b,t) = a + t*(b-a); D3D fixed-function behaviour is DEFINED here as:
- * bilinear/trilinear weights in full fp32 from texel coordinate u*w-0.5, clamp addressing,
+ * filter addressing in fixed point as the D3D functional spec prescribes — the scaled coordinate u*size is
+ * snapped to x.8 (round to nearest; D3D12_SUBTEXEL_FRACTIONAL_BIT_COUNT = 8) before the half-texel offset,
+ * the trilinear LOD fraction likewise to 1/256 (D3D12_MIP_LOD_FRACTIONAL_BIT_COUNT = 8); the lerps
+ * themselves run in fp32 and a tap with weight exactly 0 does not contribute; clamp addressing,
  * seamless cube edges (out-of-face taps are re-projected onto the neighbouring face, a tap
  * that leaves the face in both axes is first clamped in y), fp32->fp16 round-to-nearest-even
  * with overflow to inf, UNORM8 = floor(saturate(x)*255+0.5), UNORM8->float = c/255.

@@ -299,3 +299,24 @@ def test_skybox_known_answers(orc):
     part = np.zeros((10, 24, 4), np.float16)
     orc.skybox(g, Tile(16, 20, 24, 10, W, H), sky, 32, 6, np.zeros((10, 24), np.uint8), part)
     assert np.array_equal(part.view(np.uint16), full[20:30, 16:40].view(np.uint16))
+
+
+def test_sampler_fixed_point_addressing(orc):
+    # D3D fixed-function addressing: u*size snapped to x.8 fixed point, then -0.5; weights are multiples of 1/256;
+    # a zero-weight tap does not contribute (a sample at a texel centre is that texel even next to an inf)
+    img = np.zeros((1, 4, 4), np.float16)
+    img[0, :, 0] = [1, 3, 5, 7]
+    assert orc.sample_2d(img, (1 + 0.5) / 4, 0.5)[0] == 3.0
+    assert orc.sample_2d(img, (1 + 0.5 + 0.3) / 4, 0.5)[0] == 3.0 + 2.0 * (77.0 / 256.0)      # 1.8 -> 461/256
+    assert orc.sample_2d(img, (1 + 0.5 + 0.0009) / 4, 0.5)[0] == 3.0                          # below half an 1/256 step
+    assert orc.sample_2d(img, (1 + 0.5 - 0.0009) / 4, 0.5)[0] == 3.0
+    assert orc.sample_2d(img, 0.0, 0.5)[0] == 1.0 and orc.sample_2d(img, 1.0, 0.5)[0] == 7.0   # clamp addressing
+    img[0, 2, 0] = np.inf
+    assert orc.sample_2d(img, (1 + 0.5) / 4, 0.5)[0] == 3.0
+    assert orc.sample_2d(img, (1 + 0.5 + 0.3) / 4, 0.5)[0] == np.inf
+    # trilinear: LOD fraction snapped to 1/256 as well (level-coded cube: the sample returns the LOD used)
+    cube, mips = _level_coded_cube(8)
+    d = [0.3, -0.2, 1.0]
+    assert orc.sample_cube_f32(cube, 8, mips, d, 1.3)[0] == np.float32(1.0 + 77.0 / 256.0)
+    assert orc.sample_cube_f32(cube, 8, mips, d, 1.0009)[0] == 1.0
+    assert orc.sample_cube_f32(cube, 8, mips, d, 7.0)[0] == 3.0                                  # clamped to the last mip
