@@ -251,11 +251,234 @@ __global__ __launch_bounds__(256) void k_bloom_merge(pbr_half* __restrict__ hdr,
     store_h4(p, load_h4(p) + load_h4(in + 4 * ((size_t)y * w + x)));
 }
 
+// =====================================================================================================
+// Fast paths for exact 2x pyramids (every level exactly half the one above, sizes <= 8192).
+//
+// With the fixed-point sampler (pbr_device.hpp::bilinear_coord) every sample position of the bloom chain then
+// snaps to an exact dyadic coordinate: a same-size sample IS the texel, a 2x-down sample is the mean of a 2x2
+// quad (weights 1/2), a 2x-up sample has weights 1/4 | 3/4 — whatever float formula produced the coordinate
+// (the shader's group-edge formulas, `u + offset * texel`, ...).  So a sample is a function of its INTEGER
+// position alone, positions outside the image read the clamped edge texel, and
+//   * the prefilter's five samples per output are shared between neighbouring outputs (evaluated once per
+//     position, 1.16 instead of 5 evaluations per output — they carry the three IEEE divides of the soft knee),
+//   * the V pass's same-size "bilinear" sample is an exact texel of its own column, so H pass + V pass fuse
+//     into one kernel: a thread owns a column, walks down the rows and keeps the last nine H-blurred texels
+//     (rounded to fp16 exactly where the H pass would have stored them) in registers — the H result never
+//     goes to HBM.  The final instance adds the merge and the luminance histogram.
+// Results are bit-identical to the staged kernels above (tests/test_gpu_parity.py), which remain the generic path.
+
+constexpr int PF_TW = 64, PF_TH = 16;
+__global__ __launch_bounds__(256) void k_bloom_prefilter_2x(const pbr_half* __restrict__ hdr, int w, int h, int pitch,
+                                                              pbr_half* __restrict__ out, int ow, int oh, float threshold, float knee) {
+    __shared__ float4 pos[PF_TH + 2][PF_TW + 2];   // (colour * weight, weight) of every sample position the tile touches
+    const int tid = threadIdx.x;
+    const int px0 = blockIdx.x * PF_TW - 1, py0 = blockIdx.y * PF_TH - 1;
+    for (int e = tid; e < (PF_TH + 2) * (PF_TW + 2); e += 256) {
+        const int r = e / (PF_TW + 2), c = e - r * (PF_TW + 2);
+        const int p = px0 + c, q = py0 + r;
+        // position p samples u = p / ow: texel coordinate 2p - 1/2, i.e. the quad (2p-1, 2p) x (2q-1, 2q), weights 1/2
+        const int x0 = clampi(2 * p - 1, 0, w - 1), x1 = clampi(2 * p, 0, w - 1);
+        const int y0 = clampi(2 * q - 1, 0, h - 1), y1 = clampi(2 * q, 0, h - 1);
+        const F4 s = bilerp(load_h4(hdr + 4 * ((size_t)y0 * pitch + x0)), load_h4(hdr + 4 * ((size_t)y0 * pitch + x1)),
+                            load_h4(hdr + 4 * ((size_t)y1 * pitch + x0)), load_h4(hdr + 4 * ((size_t)y1 * pitch + x1)), 0.5f, 0.5f);
+        const float brightness = fmaxf(s.x, fmaxf(s.y, s.z));
+        float soft = fminf(fmaxf(brightness - threshold + threshold * knee, 0.0f), 2.0f * threshold * knee);
+        soft /= 4.0f * threshold * knee + 0.00001f;
+        const float contribution = fmaxf(soft, brightness - threshold) / fmaxf(brightness, 0.00001f);
+        const float cr = s.x * contribution, cg = s.y * contribution, cb = s.z * contribution;
+        const float wgt = 1.0f / (luminance(cr, cg, cb) + 1.0f);
+        pos[r][c] = make_float4(cr * wgt, cg * wgt, cb * wgt, wgt);
+    }
+    __syncthreads();
+    const int lx = tid & 63, x = blockIdx.x * PF_TW + lx;
+    if (x >= ow) return;
+#pragma unroll
+    for (int k = 0; k < PF_TH / 4; k++) {
+        const int ly = (tid >> 6) + 4 * k, y = blockIdx.y * PF_TH + ly;
+        if (y >= oh) break;
+        // the shader's order: centre, (-1,-1), (-1,+1), (+1,-1), (+1,+1)
+        const float4 e0 = pos[ly + 1][lx + 1], e1 = pos[ly][lx], e2 = pos[ly + 2][lx], e3 = pos[ly][lx + 2], e4 = pos[ly + 2][lx + 2];
+        float tr = (((e0.x + e1.x) + e2.x) + e3.x) + e4.x;
+        float tg = (((e0.y + e1.y) + e2.y) + e3.y) + e4.y;
+        float tb = (((e0.z + e1.z) + e2.z) + e3.z) + e4.z;
+        const float tw = (((e0.w + e1.w) + e2.w) + e3.w) + e4.w;
+        if (tw > 0.0f) { tr /= tw; tg /= tw; tb /= tw; }
+        store_h4(out + 4 * ((size_t)y * ow + x), f4(tr, tg, tb, 1.0f));
+    }
+}
+
+enum { M_SAME = 0, M_DOWN = 1, M_UP = 2 };
+// source taps of integer output position p along one axis: clamped indices and the weight of the second tap
+template <int MODE>
+__device__ __forceinline__ void tap1d(int p, int in_size, int& i0, int& i1, float& f) {
+    int a;
+    if (MODE == M_SAME) { a = p; f = 0.0f; }                       // the texel itself
+    else if (MODE == M_DOWN) { a = 2 * p; f = 0.5f; }             // (2p, 2p+1)
+    else { a = (p >> 1) - 1 + (p & 1); f = (p & 1) ? 0.25f : 0.75f; }   // p = 2k: (k-1, k) 3/4; p = 2k+1: (k, k+1) 1/4
+    i0 = clampi(a, 0, in_size - 1);
+    i1 = clampi(a + 1, 0, in_size - 1);
+}
+struct Tap2 { H4 c00, c10, c01, c11; };
+template <int MODE>
+__device__ __forceinline__ Tap2 load_tap2(const pbr_half* __restrict__ in, int iw, int x0, int x1, int y0, int y1) {
+    const H4* r0 = reinterpret_cast<const H4*>(in) + (size_t)y0 * iw;
+    Tap2 t;
+    t.c00 = r0[x0];
+    if (MODE != M_SAME) {
+        const H4* r1 = reinterpret_cast<const H4*>(in) + (size_t)y1 * iw;
+        t.c10 = r0[x1]; t.c01 = r1[x0]; t.c11 = r1[x1];
+    }
+    return t;
+}
+template <int MODE>
+__device__ __forceinline__ float4 finish_tap2(const Tap2& t, float fx, float fy) {
+    if (MODE == M_SAME) return to4(h4f(t.c00));
+    return to4(bilerp(h4f(t.c00), h4f(t.c10), h4f(t.c01), h4f(t.c11), fx, fy));
+}
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half4v round_h4(F4 v) {
+    half4v r;
+    r.x = to_half_rn(v.x); r.y = to_half_rn(v.y); r.z = to_half_rn(v.z); r.w = to_half_rn(v.w);
+    return r;
+}
+
+// H pass (+ optional second, same-size input: bloom_upsample_add) + V pass [+ merge + histogram] of one level.
+// grid (ceil(ow/BW), ceil(oh/rows)), block BW threads = BW columns; a block produces `rows` output rows and runs
+// the H pass on rows-4 .. rows+3 around them (clamped: rows outside the image repeat the edge row, as the V pass's
+// clamp addressing does).  LDS: the H pass's sampled row(s), double-buffered like k_blur_h.
+template <int MODE, bool DUAL, int TAIL, int BW>   // TAIL 0: store; 1: merge into hdr; 2: merge + histogram
+__global__ __launch_bounds__(BW) void k_blur_hv(const pbr_half* __restrict__ in, int iw, int ih,
+                                                 const pbr_half* __restrict__ in2,   // DUAL: ow x oh
+                                                 pbr_half* __restrict__ out, int ow, int oh, int out_pitch, int rows,
+                                                 int hx0, int hy0, int hx1, int hy1, float min_log, float inv_range,
+                                                 uint32_t* __restrict__ hist) {
+    constexpr int NS = DUAL ? 2 : 1;
+    constexpr int NW = BW / 64;
+    __shared__ float4 cache[2][NS][BW + 8];
+    __shared__ uint32_t sh_hist[TAIL == 2 ? NW : 1][TAIL == 2 ? PBR_HISTOGRAM_BINS : 1];
+    const int t = threadIdx.x;
+    if (TAIL == 2) {
+        for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += BW) (&sh_hist[0][0])[i] = 0u;
+    }
+    const int gx0 = blockIdx.x * BW;
+    const int y_begin = blockIdx.y * rows, y_end = min(y_begin + rows, oh);
+    const int x = gx0 + t;
+    // column taps are row-invariant: own position, and one halo position for the first / last four threads
+    const bool halo = (t < 4) | (t >= BW - 4);
+    const int slot_h = t < 4 ? t : t + 8;
+    const int p_h = t < 4 ? x - 4 : x + 4;
+    int mx0, mx1, hx0c, hx1c; float mfx, hfx;
+    tap1d<MODE>(x, iw, mx0, mx1, mfx);
+    tap1d<MODE>(p_h, iw, hx0c, hx1c, hfx);
+    const int sx = clampi(x, 0, ow - 1), sxh = clampi(p_h, 0, ow - 1);   // DUAL: same-size input, exact texel
+
+    Tap2 m, hh; H4 m2, hh2; float fy = 0.0f;
+    auto load_row = [&](int j) {
+        const int jj = clampi(j, 0, oh - 1);
+        int y0, y1;
+        tap1d<MODE>(jj, ih, y0, y1, fy);
+        m = load_tap2<MODE>(in, iw, mx0, mx1, y0, y1);
+        if (halo) hh = load_tap2<MODE>(in, iw, hx0c, hx1c, y0, y1);
+        if (DUAL) {
+            const H4* r = reinterpret_cast<const H4*>(in2) + (size_t)jj * ow;
+            m2 = r[sx];
+            if (halo) hh2 = r[sxh];
+        }
+    };
+    half4v win[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) win[i] = half4v{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    load_row(y_begin - 4);
+    float fy_cur = fy;
+    for (int j = y_begin - 4; j < y_end + 4; j++) {
+        const int buf = (j - y_begin) & 1;
+        cache[buf][0][t + 4] = finish_tap2<MODE>(m, mfx, fy_cur);
+        if (halo) cache[buf][0][slot_h] = finish_tap2<MODE>(hh, hfx, fy_cur);
+        if (DUAL) {
+            cache[buf][NS - 1][t + 4] = to4(h4f(m2));
+            if (halo) cache[buf][NS - 1][slot_h] = to4(h4f(hh2));
+        }
+        __syncthreads();
+        if (j + 1 < y_end + 4) { load_row(j + 1); }   // next row's taps in flight while this one is filtered
+        F4 v = gauss9(cache[buf][0] + t);
+        if (DUAL) v = v + gauss9(cache[buf][NS - 1] + t);
+        fy_cur = fy;
+#pragma unroll
+        for (int i = 0; i < 8; i++) win[i] = win[i + 1];
+        win[8] = round_h4(v);   // the H pass's fp16 store
+        const int y = j - 4;    // the output row whose nine taps are now in the window
+        if (y >= y_begin && x < ow) {
+            F4 a = f4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int i = 0; i < 9; i++) a = fma4(f4((float)win[i].x, (float)win[i].y, (float)win[i].z, (float)win[i].w), c_gauss[i], a);
+            if (TAIL == 0) {
+                store_h4(out + 4 * ((size_t)y * out_pitch + x), a);
+            } else {
+                const half4v a0 = round_h4(a);   // A0 texel as the separate V pass would have stored it
+                pbr_half* px = out + 4 * ((size_t)y * out_pitch + x);
+                const F4 s = load_h4(px);
+                H4 o;
+                o.x = to_half_rn(s.x + (float)a0.x); o.y = to_half_rn(s.y + (float)a0.y); o.z = to_half_rn(s.z + (float)a0.z); o.w = to_half_rn(s.w + (float)a0.w);
+                *reinterpret_cast<H4*>(px) = o;
+                if (TAIL == 2) {
+                    if (x >= hx0 && x < hx1 && y >= hy0 && y < hy1)
+                        atomicAdd(&sh_hist[t >> 6][luminance_bin_exact((float)o.x, (float)o.y, (float)o.z, min_log, inv_range)], 1u);
+                }
+            }
+        }
+    }
+    if (TAIL == 2) {
+        __syncthreads();
+        for (int i = t; i < PBR_HISTOGRAM_BINS; i += BW) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int wv = 0; wv < NW; wv++) sum += sh_hist[wv][i];
+            if (sum) atomicAdd(&hist[i], sum);
+        }
+    }
+}
+
 // rows a k_blur_h block pipelines: as many as keep >= ~2048 blocks (8 per CU) in the grid
 static int blur_h_rows(uint32_t ow, uint32_t oh) {
     const uint64_t row_blocks = (uint64_t)((ow + 255) / 256) * oh;
     int rows = (int)(row_blocks / 2048);
     return rows < 1 ? 1 : (rows > HB_MAX_ROWS ? HB_MAX_ROWS : rows);
+}
+
+// fast-path preconditions: the level below is exactly half, and the size keeps every snapped sample coordinate
+// on its dyadic value (coordinate error ~4 * 2^-24 * size must stay below half a 1/256 step)
+static bool exact_half(uint32_t n) { return (n & 1u) == 0u && n <= 8192u; }
+static bool force_staged() { static const bool v = getenv("PBR_BLOOM_STAGED") != nullptr; return v; }   // A/B switch for tests and profiling
+
+// rows per k_blur_hv block: halve from 64 until the grid has enough blocks to fill the chip (each block also
+// runs the H pass on 8 extra rows, so short blocks cost more)
+static int hv_rows(uint32_t col_blocks, uint32_t oh, uint32_t want_blocks) {
+    static const int forced = getenv("PBR_BLOOM_ROWS") ? atoi(getenv("PBR_BLOOM_ROWS")) : 0;
+    if (forced >= 1) return forced;
+    int rows = 64;
+    while (rows > 8 && (uint64_t)col_blocks * ((oh + rows - 1) / rows) < want_blocks) rows >>= 1;
+    return rows;
+}
+
+template <int MODE, bool DUAL, int TAIL>
+static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih, const pbr_half* in2,
+                            pbr_half* out, uint32_t ow, uint32_t oh, uint32_t out_pitch,
+                            const uint32_t* rect, float min_log, float inv_range, uint32_t* hist) {
+    const int hx0 = rect ? (int)rect[0] : 0, hy0 = rect ? (int)rect[1] : 0;
+    const int hx1 = rect ? (int)(rect[0] + rect[2]) : 0, hy1 = rect ? (int)(rect[1] + rect[3]) : 0;
+    if (ow >= 1024) {
+        const uint32_t cb = (ow + 255) / 256;
+        const int rows = hv_rows(cb, oh, 900);
+        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 256>), dim3(cb, (oh + rows - 1) / rows), dim3(256), 0, ctx->stream,
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, rows, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
+    } else {
+        const uint32_t cb = (ow + 63) / 64;
+        const int rows = hv_rows(cb, oh, 1024);
+        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 64>), dim3(cb, (oh + rows - 1) / rows), dim3(64), 0, ctx->stream,
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, rows, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
+    }
+    return launched(ctx, "k_blur_hv");
 }
 
 extern "C" {
@@ -267,6 +490,11 @@ pbr_status pbr_bloom_prefilter(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, ui
     PBR_REQUIRE(ctx, (w >> 1) >= 1 && (h >> 1) >= 1 && w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom_prefilter: bad size");
     const uint32_t ow = w >> 1, oh = h >> 1;
     const float tx = 1.0f / (float)ow, ty = 1.0f / (float)oh;   // DeferredPipeline.cpp:418
+    if (exact_half(w) && exact_half(h) && !force_staged()) {   // shared-sample kernel (bit-identical)
+        dim3 g2((ow + PF_TW - 1) / PF_TW, (oh + PF_TH - 1) / PF_TH);
+        hipLaunchKernelGGL(k_bloom_prefilter_2x, g2, dim3(256), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, threshold, knee);
+        return launched(ctx, "k_bloom_prefilter_2x");
+    }
     dim3 grid((ow + 63) / 64, (oh + 3) / 4);
     hipLaunchKernelGGL(k_bloom_prefilter, grid, dim3(64, 4), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, tx, ty, threshold, knee);
     return launched(ctx, "k_bloom_prefilter");
@@ -342,6 +570,24 @@ static pbr_status bloom_impl(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h
     auto H = [&](uint32_t l) { return h >> l; };
     pbr_status r;
     if ((r = pbr_bloom_prefilter(ctx, hdr, w, h, pitch, a(1), threshold, knee))) return r;
+    bool exact = !force_staged();
+    for (uint32_t l = 0; l + 1 < PBR_BLOOM_MIPS; l++) exact = exact && exact_half(W(l)) && exact_half(H(l));
+    if (exact) {
+        // exact 2x pyramid: H+V of every level fused (8 launches instead of 16 dispatches); the H results (chain B
+        // of the staged schedule) are never written.  Up-levels go to chain B so a block never overwrites what its
+        // neighbours still read; chain contents after the call are scratch.
+        for (uint32_t i = 0; i < PBR_BLOOM_STEP; i++) {
+            const uint32_t up = i + 1, lo = i + 2;
+            if ((r = launch_hv<M_DOWN, false, 0>(ctx, a(up), W(up), H(up), nullptr, a(lo), W(lo), H(lo), W(lo), nullptr, 0.0f, 0.0f, nullptr))) return r;
+        }
+        for (int i = PBR_BLOOM_STEP - 1; i >= 0; i--) {
+            const uint32_t up = (uint32_t)i + 1;
+            const pbr_half* lower = (up + 1 == PBR_BLOOM_MIPS - 1) ? a(up + 1) : b(up + 1);
+            if ((r = launch_hv<M_UP, true, 0>(ctx, lower, W(up + 1), H(up + 1), a(up), b(up), W(up), H(up), W(up), nullptr, 0.0f, 0.0f, nullptr))) return r;
+        }
+        if (hist256) return launch_hv<M_UP, false, 2>(ctx, b(1), W(1), H(1), nullptr, hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
+        return launch_hv<M_UP, false, 1>(ctx, b(1), W(1), H(1), nullptr, hdr, w, h, pitch, nullptr, 0.0f, 0.0f, nullptr);
+    }
     for (uint32_t i = 0; i < PBR_BLOOM_STEP; i++) {
         uint32_t up = i + 1, lo = i + 2;
         if ((r = pbr_blur_h(ctx, a(up), W(up), H(up), b(lo), W(lo), H(lo)))) return r;

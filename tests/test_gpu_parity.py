@@ -521,3 +521,31 @@ def test_rgbe_decode_bit_exact(ctx, orc):
     ctx.sync()
     assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
     assert (want[t[:, 3] == 0][:, :3] == 0).all() and (want[:, 3] == 1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(2048, 64), (1040, 48), (512, 288), (304, 176)])
+def test_bloom_fused_exact_pyramid_bit_exact(ctx, orc, w, h):
+    """Exact 2x pyramids take the fused path (shared-sample prefilter; H+V of a level in one kernel with the H
+    result kept in registers; merge + histogram in the last one): final HDR bit-identical to the oracle's staged
+    chain, histogram equal to the stand-alone pass.  Sizes cover 256- and 64-column blocks, ragged widths/heights."""
+    img = synth.hdr_noise_image(w, h, seed=w + h)
+    want = img.copy()
+    orc.bloom(want)
+    hdr = dev_half(ctx, img)
+    ca, cb = ctx.alloc_bloom_chain(w, h), ctx.alloc_bloom_chain(w, h)
+    hist = ctx.zeros((256,), torch.int32)
+    ctx.bloom_histogram(hdr, w, h, w, ca, cb, (0, 0, w, h), hist)
+    got = to_np_half(hdr)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    # the shared-sample prefilter on its own (chain contents after pbr_bloom are scratch)
+    pf = ctx.zeros((h // 2, w // 2, 4), torch.float16)
+    ctx.bloom_prefilter(dev_half(ctx, img), w, h, w, pf)
+    assert np.array_equal(to_np_half(pf).view(np.uint16), orc.bloom_prefilter(img).view(np.uint16))
+    hist_ref = ctx.zeros((256,), torch.int32)
+    ctx.lum_histogram(hdr, w, h, w, hist_ref)
+    assert np.array_equal(hist.cpu().numpy(), hist_ref.cpu().numpy())
+    # without the histogram
+    hdr2 = dev_half(ctx, img)
+    ctx.bloom(hdr2, w, h, w, ca, cb)
+    assert np.array_equal(to_np_half(hdr2).view(np.uint16), want.view(np.uint16))
