@@ -333,7 +333,11 @@ __device__ __forceinline__ Tap2 load_tap2(const pbr_half* __restrict__ in, int i
 template <int MODE>
 __device__ __forceinline__ float4 finish_tap2(const Tap2& t, float fx, float fy) {
     if (MODE == M_SAME) return to4(h4f(t.c00));
-    return to4(bilerp(h4f(t.c00), h4f(t.c10), h4f(t.c01), h4f(t.c11), fx, fy));
+    // weights are 1/4, 1/2 or 3/4 here — never 0, so lerp4's zero-weight select is dead: same values, fewer instructions
+    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+    const F4 top = fma4(h4f(t.c10), fx, h4f(t.c00) * wx0);
+    const F4 bot = fma4(h4f(t.c11), fx, h4f(t.c01) * wx0);
+    return to4(fma4(bot, fy, top * wy0));
 }
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -344,96 +348,118 @@ __device__ __forceinline__ half4v round_h4(F4 v) {
 }
 
 // H pass (+ optional second, same-size input: bloom_upsample_add) + V pass [+ merge + histogram] of one level.
-// grid (ceil(ow/BW), ceil(oh/rows)), block BW threads = BW columns; a block produces `rows` output rows and runs
-// the H pass on rows-4 .. rows+3 around them (clamped: rows outside the image repeat the edge row, as the V pass's
-// clamp addressing does).  LDS: the H pass's sampled row(s), double-buffered like k_blur_h.
-template <int MODE, bool DUAL, int TAIL, int BW>   // TAIL 0: store; 1: merge into hdr; 2: merge + histogram
-__global__ __launch_bounds__(BW) void k_blur_hv(const pbr_half* __restrict__ in, int iw, int ih,
-                                                 const pbr_half* __restrict__ in2,   // DUAL: ow x oh
-                                                 pbr_half* __restrict__ out, int ow, int oh, int out_pitch, int rows,
+// One block = one TW x TH tile of outputs, three barrier-separated phases, every global load issued up front:
+//   1. the (TH+8) x (TW+8) sampled positions around the tile -> LDS (fp32, the H pass's Cache[]), flattened over
+//      the block's threads so the 8-column halo costs its share and no more;
+//   2. H-gauss of the (TH+8) x TW positions, rounded to fp16 exactly where the H pass stores -> LDS (8 B texels);
+//   3. V-gauss down each column from LDS, then store / merge into the HDR buffer / histogram.
+// Rows and columns outside the image repeat the edge (clamp addressing of both passes).
+template <int MODE, bool DUAL, int TAIL, int TH, int NT>   // TAIL 0: store; 1: merge into hdr; 2: merge + histogram
+__global__ __launch_bounds__(NT) void k_blur_hv(const pbr_half* __restrict__ in, int iw, int ih,
+                                                 const pbr_half* __restrict__ in2,   // DUAL: ow x oh, same-size
+                                                 pbr_half* __restrict__ out, int ow, int oh, int out_pitch,
                                                  int hx0, int hy0, int hx1, int hy1, float min_log, float inv_range,
                                                  uint32_t* __restrict__ hist) {
-    constexpr int NS = DUAL ? 2 : 1;
-    constexpr int NW = BW / 64;
-    __shared__ float4 cache[2][NS][BW + 8];
+    constexpr int TW = 64, SW = TW + 8, SR = TH + 8;
+    constexpr int NW = NT / 64;
+    constexpr int PER_T = SR / NW;                      // sampled rows / H-gauss rows per wave (rows wv, wv + NW, ...)
+    constexpr int PER_O = TH / NW;                      // final outputs per thread
+    static_assert(SR % NW == 0 && TH % NW == 0 && SR * 8 <= NT, "rows must split evenly over the waves; one halo tap per thread");
+    __shared__ float4 sS[SR][SW];
+    __shared__ H4 sT[SR][TW];
     __shared__ uint32_t sh_hist[TAIL == 2 ? NW : 1][TAIL == 2 ? PBR_HISTOGRAM_BINS : 1];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: row arithmetic stays on the scalar unit
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int x = x0 + lane;
     if (TAIL == 2) {
-        for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += BW) (&sh_hist[0][0])[i] = 0u;
+        for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += NT) (&sh_hist[0][0])[i] = 0u;
     }
-    const int gx0 = blockIdx.x * BW;
-    const int y_begin = blockIdx.y * rows, y_end = min(y_begin + rows, oh);
-    const int x = gx0 + t;
-    // column taps are row-invariant: own position, and one halo position for the first / last four threads
-    const bool halo = (t < 4) | (t >= BW - 4);
-    const int slot_h = t < 4 ? t : t + 8;
-    const int p_h = t < 4 ? x - 4 : x + 4;
-    int mx0, mx1, hx0c, hx1c; float mfx, hfx;
-    tap1d<MODE>(x, iw, mx0, mx1, mfx);
-    tap1d<MODE>(p_h, iw, hx0c, hx1c, hfx);
-    const int sx = clampi(x, 0, ow - 1), sxh = clampi(p_h, 0, ow - 1);   // DUAL: same-size input, exact texel
-
-    Tap2 m, hh; H4 m2, hh2; float fy = 0.0f;
-    auto load_row = [&](int j) {
-        const int jj = clampi(j, 0, oh - 1);
-        int y0, y1;
-        tap1d<MODE>(jj, ih, y0, y1, fy);
-        m = load_tap2<MODE>(in, iw, mx0, mx1, y0, y1);
-        if (halo) hh = load_tap2<MODE>(in, iw, hx0c, hx1c, y0, y1);
-        if (DUAL) {
-            const H4* r = reinterpret_cast<const H4*>(in2) + (size_t)jj * ow;
-            m2 = r[sx];
-            if (halo) hh2 = r[sxh];
-        }
-    };
-    half4v win[9];
+    // the HDR texels the merge will need: in flight from the start
+    H4 hdr_in[PER_O];
+    if (TAIL != 0) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) win[i] = half4v{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
-    load_row(y_begin - 4);
-    float fy_cur = fy;
-    for (int j = y_begin - 4; j < y_end + 4; j++) {
-        const int buf = (j - y_begin) & 1;
-        cache[buf][0][t + 4] = finish_tap2<MODE>(m, mfx, fy_cur);
-        if (halo) cache[buf][0][slot_h] = finish_tap2<MODE>(hh, hfx, fy_cur);
-        if (DUAL) {
-            cache[buf][NS - 1][t + 4] = to4(h4f(m2));
-            if (halo) cache[buf][NS - 1][slot_h] = to4(h4f(hh2));
+        for (int k = 0; k < PER_O; k++) {
+            const int y = y0 + wv + NW * k;
+            if (x < ow && y < oh) hdr_in[k] = *reinterpret_cast<const H4*>(out + 4 * ((size_t)y * out_pitch + x));
         }
+    }
+    // sampled positions: columns x0-4 .. x0+67 (c = 0..71), rows clamp(y0-4 .. y0+TH+3) (r = 0..SR-1).
+    // A wave samples whole rows (c = lane: column taps fixed per thread, row taps wave-uniform); the 8 halo columns
+    // c = 64..71 of all SR rows are one extra tap for the first SR*8 threads.
+    const bool has_halo = t < SR * 8;
+    const int hr = t >> 3, hc = 64 + (t & 7);
+    F4 hacc[PER_T];
+    for (int pass = 0; pass < (DUAL ? 2 : 1); pass++) {
+        // ---- phase 1
+        Tap2 taps[PER_T], htap;
+        float fx = 0.0f, hfx = 0.0f, hfy = 0.0f, fy[PER_T];
+        if (pass == 0) {
+            int ax0, ax1, bx0, bx1;
+            tap1d<MODE>(x0 - 4 + lane, iw, ax0, ax1, fx);
+            tap1d<MODE>(x0 - 4 + hc, iw, bx0, bx1, hfx);
+#pragma unroll
+            for (int k = 0; k < PER_T; k++) {
+                int ay0, ay1;
+                tap1d<MODE>(clampi(y0 - 4 + wv + NW * k, 0, oh - 1), ih, ay0, ay1, fy[k]);
+                taps[k] = load_tap2<MODE>(in, iw, ax0, ax1, ay0, ay1);
+            }
+            if (has_halo) {
+                int ay0, ay1;
+                tap1d<MODE>(clampi(y0 - 4 + hr, 0, oh - 1), ih, ay0, ay1, hfy);
+                htap = load_tap2<MODE>(in, iw, bx0, bx1, ay0, ay1);
+            }
+        } else {   // the same-size input of bloom_upsample_add: exact texels
+            const int sx = clampi(x0 - 4 + lane, 0, ow - 1), shx = clampi(x0 - 4 + hc, 0, ow - 1);
+#pragma unroll
+            for (int k = 0; k < PER_T; k++)
+                taps[k].c00 = reinterpret_cast<const H4*>(in2)[(size_t)clampi(y0 - 4 + wv + NW * k, 0, oh - 1) * ow + sx];
+            if (has_halo) htap.c00 = reinterpret_cast<const H4*>(in2)[(size_t)clampi(y0 - 4 + hr, 0, oh - 1) * ow + shx];
+            __syncthreads();   // phase 2 of pass 0 has finished reading sS
+        }
+#pragma unroll
+        for (int k = 0; k < PER_T; k++)
+            sS[wv + NW * k][lane] = pass == 0 ? finish_tap2<MODE>(taps[k], fx, fy[k]) : to4(h4f(taps[k].c00));
+        if (has_halo) sS[hr][hc] = pass == 0 ? finish_tap2<MODE>(htap, hfx, hfy) : to4(h4f(htap.c00));
         __syncthreads();
-        if (j + 1 < y_end + 4) { load_row(j + 1); }   // next row's taps in flight while this one is filtered
-        F4 v = gauss9(cache[buf][0] + t);
-        if (DUAL) v = v + gauss9(cache[buf][NS - 1] + t);
-        fy_cur = fy;
+        // ---- phase 2: H-gauss; lane = column, wave wv takes rows wv, wv + NW, ...
 #pragma unroll
-        for (int i = 0; i < 8; i++) win[i] = win[i + 1];
-        win[8] = round_h4(v);   // the H pass's fp16 store
-        const int y = j - 4;    // the output row whose nine taps are now in the window
-        if (y >= y_begin && x < ow) {
-            F4 a = f4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k = 0; k < PER_T; k++) {
+            const F4 g = gauss9(&sS[wv + NW * k][lane]);
+            hacc[k] = pass == 0 ? g : hacc[k] + g;   // bloom_upsample_add: lower first, then upper
+        }
+    }
 #pragma unroll
-            for (int i = 0; i < 9; i++) a = fma4(f4((float)win[i].x, (float)win[i].y, (float)win[i].z, (float)win[i].w), c_gauss[i], a);
-            if (TAIL == 0) {
-                store_h4(out + 4 * ((size_t)y * out_pitch + x), a);
-            } else {
-                const half4v a0 = round_h4(a);   // A0 texel as the separate V pass would have stored it
-                pbr_half* px = out + 4 * ((size_t)y * out_pitch + x);
-                const F4 s = load_h4(px);
-                H4 o;
-                o.x = to_half_rn(s.x + (float)a0.x); o.y = to_half_rn(s.y + (float)a0.y); o.z = to_half_rn(s.z + (float)a0.z); o.w = to_half_rn(s.w + (float)a0.w);
-                *reinterpret_cast<H4*>(px) = o;
-                if (TAIL == 2) {
-                    if (x >= hx0 && x < hx1 && y >= hy0 && y < hy1)
-                        atomicAdd(&sh_hist[t >> 6][luminance_bin_exact((float)o.x, (float)o.y, (float)o.z, min_log, inv_range)], 1u);
-                }
+    for (int k = 0; k < PER_T; k++) store_h4(reinterpret_cast<pbr_half*>(&sT[wv + NW * k][lane]), hacc[k]);   // the H pass's fp16 store
+    __syncthreads();
+    // ---- phase 3: V-gauss + tail
+#pragma unroll
+    for (int k = 0; k < PER_O; k++) {
+        const int r = wv + NW * k, y = y0 + r;
+        if (x >= ow || y >= oh) continue;
+        F4 a = f4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int i = 0; i < 9; i++) a = fma4(h4f(sT[r + i][lane]), c_gauss[i], a);
+        if (TAIL == 0) {
+            store_h4(out + 4 * ((size_t)y * out_pitch + x), a);
+        } else {
+            const half4v a0 = round_h4(a);   // A0 texel as the separate V pass would have stored it
+            const F4 s = h4f(hdr_in[k]);
+            H4 o;
+            o.x = to_half_rn(s.x + (float)a0.x); o.y = to_half_rn(s.y + (float)a0.y); o.z = to_half_rn(s.z + (float)a0.z); o.w = to_half_rn(s.w + (float)a0.w);
+            *reinterpret_cast<H4*>(out + 4 * ((size_t)y * out_pitch + x)) = o;
+            if (TAIL == 2) {
+                if (x >= hx0 && x < hx1 && y >= hy0 && y < hy1)
+                    atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.x, (float)o.y, (float)o.z, min_log, inv_range)], 1u);
             }
         }
     }
     if (TAIL == 2) {
         __syncthreads();
-        for (int i = t; i < PBR_HISTOGRAM_BINS; i += BW) {
+        for (int i = t; i < PBR_HISTOGRAM_BINS; i += NT) {
             uint32_t sum = 0;
 #pragma unroll
-            for (int wv = 0; wv < NW; wv++) sum += sh_hist[wv][i];
+            for (int w2 = 0; w2 < NW; w2++) sum += sh_hist[w2][i];
             if (sum) atomicAdd(&hist[i], sum);
         }
     }
@@ -451,32 +477,21 @@ static int blur_h_rows(uint32_t ow, uint32_t oh) {
 static bool exact_half(uint32_t n) { return (n & 1u) == 0u && n <= 8192u; }
 static bool force_staged() { static const bool v = getenv("PBR_BLOOM_STAGED") != nullptr; return v; }   // A/B switch for tests and profiling
 
-// rows per k_blur_hv block: halve from 64 until the grid has enough blocks to fill the chip (each block also
-// runs the H pass on 8 extra rows, so short blocks cost more)
-static int hv_rows(uint32_t col_blocks, uint32_t oh, uint32_t want_blocks) {
-    static const int forced = getenv("PBR_BLOOM_ROWS") ? atoi(getenv("PBR_BLOOM_ROWS")) : 0;
-    if (forced >= 1) return forced;
-    int rows = 64;
-    while (rows > 8 && (uint64_t)col_blocks * ((oh + rows - 1) / rows) < want_blocks) rows >>= 1;
-    return rows;
-}
-
 template <int MODE, bool DUAL, int TAIL>
 static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih, const pbr_half* in2,
                             pbr_half* out, uint32_t ow, uint32_t oh, uint32_t out_pitch,
                             const uint32_t* rect, float min_log, float inv_range, uint32_t* hist) {
     const int hx0 = rect ? (int)rect[0] : 0, hy0 = rect ? (int)rect[1] : 0;
     const int hx1 = rect ? (int)(rect[0] + rect[2]) : 0, hy1 = rect ? (int)(rect[1] + rect[3]) : 0;
-    if (ow >= 1024) {
-        const uint32_t cb = (ow + 255) / 256;
-        const int rows = hv_rows(cb, oh, 900);
-        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 256>), dim3(cb, (oh + rows - 1) / rows), dim3(256), 0, ctx->stream,
-                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, rows, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
+    // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 (256) below
+    static const int forced = getenv("PBR_BLOOM_TILE") ? atoi(getenv("PBR_BLOOM_TILE")) : 0;
+    const bool big = forced ? forced == 32 : (uint64_t)((ow + 63) / 64) * ((oh + 31) / 32) >= 1024;
+    if (big) {
+        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 32, 512>), dim3((ow + 63) / 64, (oh + 31) / 32), dim3(512), 0, ctx->stream,
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
     } else {
-        const uint32_t cb = (ow + 63) / 64;
-        const int rows = hv_rows(cb, oh, 1024);
-        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 64>), dim3(cb, (oh + rows - 1) / rows), dim3(64), 0, ctx->stream,
-                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, rows, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
+        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 16, 256>), dim3((ow + 63) / 64, (oh + 15) / 16), dim3(256), 0, ctx->stream,
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
     }
     return launched(ctx, "k_blur_hv");
 }
