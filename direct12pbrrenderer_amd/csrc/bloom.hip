@@ -348,33 +348,38 @@ __device__ __forceinline__ half4v round_h4(F4 v) {
 }
 
 // H pass (+ optional second, same-size input: bloom_upsample_add) + V pass [+ merge + histogram] of one level.
-// One block = one TW x TH tile of outputs, three barrier-separated phases, every global load issued up front:
-//   1. the (TH+8) x (TW+8) sampled positions around the tile -> LDS (fp32, the H pass's Cache[]), flattened over
-//      the block's threads so the 8-column halo costs its share and no more;
-//   2. H-gauss of the (TH+8) x TW positions, rounded to fp16 exactly where the H pass stores -> LDS (8 B texels);
-//   3. V-gauss down each column from LDS, then store / merge into the HDR buffer / histogram.
-// Rows and columns outside the image repeat the edge (clamp addressing of both passes).
+// One block = one 64 x TH tile of outputs:
+//   1+2. every wave owns (TH+8)/NW of the TH+8 rows the V pass will tap (rows outside the image repeat the edge).
+//        It samples its rows' 72 positions (64 columns + the 4+4 halo; all global loads issued up front), then row
+//        by row writes the samples to a wave-private LDS line (the H pass's Cache[]), H-gausses it and rounds to
+//        fp16 exactly where the H pass stores — no block barrier: LDS operations of one wave execute in order;
+//   3.   after the only barrier, V-gauss down each column from the shared fp16 tile, then store / merge into the
+//        HDR buffer / histogram.
 template <int MODE, bool DUAL, int TAIL, int TH, int NT>   // TAIL 0: store; 1: merge into hdr; 2: merge + histogram
-__global__ __launch_bounds__(NT) void k_blur_hv(const pbr_half* __restrict__ in, int iw, int ih,
+__global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ in, int iw, int ih,
                                                  const pbr_half* __restrict__ in2,   // DUAL: ow x oh, same-size
                                                  pbr_half* __restrict__ out, int ow, int oh, int out_pitch,
+                                                 int tiles_x, int n_tiles,
                                                  int hx0, int hy0, int hx1, int hy1, float min_log, float inv_range,
                                                  uint32_t* __restrict__ hist) {
     constexpr int TW = 64, SW = TW + 8, SR = TH + 8;
     constexpr int NW = NT / 64;
-    constexpr int PER_T = SR / NW;                      // sampled rows / H-gauss rows per wave (rows wv, wv + NW, ...)
-    constexpr int PER_O = TH / NW;                      // final outputs per thread
-    static_assert(SR % NW == 0 && TH % NW == 0 && SR * 8 <= NT, "rows must split evenly over the waves; one halo tap per thread");
-    __shared__ float4 sS[SR][SW];
+    constexpr int PER_T = SR / NW;                      // sampled / H-gaussed rows per wave: rows wv*PER_T .. +PER_T-1
+    constexpr int PER_O = TH / NW;                      // final outputs per thread (rows wv, wv + NW, ...)
+    static_assert(SR % NW == 0 && TH % NW == 0 && PER_T * 8 <= 64, "rows must split evenly over the waves; one halo tap per lane");
+    __shared__ float4 sLine[DUAL ? 2 : 1][NW][SW];
     __shared__ H4 sT[SR][TW];
     __shared__ uint32_t sh_hist[TAIL == 2 ? NW : 1][TAIL == 2 ? PBR_HISTOGRAM_BINS : 1];
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: row arithmetic stays on the scalar unit
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int x = x0 + lane;
     if (TAIL == 2) {
         for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += NT) (&sh_hist[0][0])[i] = 0u;
     }
+    // 1-D grid over tiles; the histogram instance is launched with fewer blocks than tiles (each walks several) so
+    // that the per-block flush of 256 global atomics stays rare
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+    const int x = x0 + lane;
     // the HDR texels the merge will need: in flight from the start
     H4 hdr_in[PER_O];
     if (TAIL != 0) {
@@ -384,53 +389,59 @@ __global__ __launch_bounds__(NT) void k_blur_hv(const pbr_half* __restrict__ in,
             if (x < ow && y < oh) hdr_in[k] = *reinterpret_cast<const H4*>(out + 4 * ((size_t)y * out_pitch + x));
         }
     }
-    // sampled positions: columns x0-4 .. x0+67 (c = 0..71), rows clamp(y0-4 .. y0+TH+3) (r = 0..SR-1).
-    // A wave samples whole rows (c = lane: column taps fixed per thread, row taps wave-uniform); the 8 halo columns
-    // c = 64..71 of all SR rows are one extra tap for the first SR*8 threads.
-    const bool has_halo = t < SR * 8;
-    const int hr = t >> 3, hc = 64 + (t & 7);
-    F4 hacc[PER_T];
-    for (int pass = 0; pass < (DUAL ? 2 : 1); pass++) {
-        // ---- phase 1
+    // positions: columns x0-4+c (c = 0..71), rows clamp(y0-4+r) (r = 0..SR-1).  Main tap of row k: c = lane; the halo
+    // columns c = 64..71 of the wave's PER_T rows are ONE extra tap: lane -> (row lane / 8, column 64 + lane % 8).
+    const int r0 = wv * PER_T;
+    const bool has_halo = lane < PER_T * 8;
+    const int hk = lane >> 3, hc = 64 + (lane & 7);
+    float4* line = sLine[0][wv];
+    float4* line2 = sLine[DUAL ? 1 : 0][wv];
+    // lanes of one wave exchange data through `line` without a block barrier: DS operations of a wave execute in
+    // order, but the compiler must be told that other lanes' slots are read (per-thread alias analysis would let it
+    // hoist the loads above the store)
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    {
         Tap2 taps[PER_T], htap;
-        float fx = 0.0f, hfx = 0.0f, hfy = 0.0f, fy[PER_T];
-        if (pass == 0) {
-            int ax0, ax1, bx0, bx1;
-            tap1d<MODE>(x0 - 4 + lane, iw, ax0, ax1, fx);
-            tap1d<MODE>(x0 - 4 + hc, iw, bx0, bx1, hfx);
-#pragma unroll
-            for (int k = 0; k < PER_T; k++) {
-                int ay0, ay1;
-                tap1d<MODE>(clampi(y0 - 4 + wv + NW * k, 0, oh - 1), ih, ay0, ay1, fy[k]);
-                taps[k] = load_tap2<MODE>(in, iw, ax0, ax1, ay0, ay1);
-            }
-            if (has_halo) {
-                int ay0, ay1;
-                tap1d<MODE>(clampi(y0 - 4 + hr, 0, oh - 1), ih, ay0, ay1, hfy);
-                htap = load_tap2<MODE>(in, iw, bx0, bx1, ay0, ay1);
-            }
-        } else {   // the same-size input of bloom_upsample_add: exact texels
-            const int sx = clampi(x0 - 4 + lane, 0, ow - 1), shx = clampi(x0 - 4 + hc, 0, ow - 1);
-#pragma unroll
-            for (int k = 0; k < PER_T; k++)
-                taps[k].c00 = reinterpret_cast<const H4*>(in2)[(size_t)clampi(y0 - 4 + wv + NW * k, 0, oh - 1) * ow + sx];
-            if (has_halo) htap.c00 = reinterpret_cast<const H4*>(in2)[(size_t)clampi(y0 - 4 + hr, 0, oh - 1) * ow + shx];
-            __syncthreads();   // phase 2 of pass 0 has finished reading sS
-        }
-#pragma unroll
-        for (int k = 0; k < PER_T; k++)
-            sS[wv + NW * k][lane] = pass == 0 ? finish_tap2<MODE>(taps[k], fx, fy[k]) : to4(h4f(taps[k].c00));
-        if (has_halo) sS[hr][hc] = pass == 0 ? finish_tap2<MODE>(htap, hfx, hfy) : to4(h4f(htap.c00));
-        __syncthreads();
-        // ---- phase 2: H-gauss; lane = column, wave wv takes rows wv, wv + NW, ...
+        H4 up[DUAL ? PER_T : 1], hup;   // DUAL: the same-size input of bloom_upsample_add, exact texels
+        float fx, hfx, hfy = 0.0f, fy[PER_T];
+        int ax0, ax1, bx0, bx1;
+        tap1d<MODE>(x0 - 4 + lane, iw, ax0, ax1, fx);
+        tap1d<MODE>(x0 - 4 + hc, iw, bx0, bx1, hfx);
+        const int sx = clampi(x0 - 4 + lane, 0, ow - 1), shx = clampi(x0 - 4 + hc, 0, ow - 1);
 #pragma unroll
         for (int k = 0; k < PER_T; k++) {
-            const F4 g = gauss9(&sS[wv + NW * k][lane]);
-            hacc[k] = pass == 0 ? g : hacc[k] + g;   // bloom_upsample_add: lower first, then upper
+            const int jj = clampi(y0 - 4 + r0 + k, 0, oh - 1);
+            int ay0, ay1;
+            tap1d<MODE>(jj, ih, ay0, ay1, fy[k]);
+            taps[k] = load_tap2<MODE>(in, iw, ax0, ax1, ay0, ay1);
+            if (DUAL) up[k] = reinterpret_cast<const H4*>(in2)[(size_t)jj * ow + sx];
+        }
+        if (has_halo) {
+            const int jj = clampi(y0 - 4 + r0 + hk, 0, oh - 1);
+            int ay0, ay1;
+            tap1d<MODE>(jj, ih, ay0, ay1, hfy);
+            htap = load_tap2<MODE>(in, iw, bx0, bx1, ay0, ay1);
+            if (DUAL) hup = reinterpret_cast<const H4*>(in2)[(size_t)jj * ow + shx];
+        }
+#pragma unroll
+        for (int k = 0; k < PER_T; k++) {
+            line[lane] = finish_tap2<MODE>(taps[k], fx, fy[k]);
+            if (DUAL) line2[lane] = to4(h4f(up[k]));
+            if (has_halo && hk == k) {
+                line[hc] = finish_tap2<MODE>(htap, hfx, hfy);
+                if (DUAL) line2[hc] = to4(h4f(hup));
+            }
+            wave_sync();
+            F4 g = gauss9(line + lane);
+            if (DUAL) g = g + gauss9(line2 + lane);   // bloom_upsample_add: lower first, then upper
+            wave_sync();
+            store_h4(reinterpret_cast<pbr_half*>(&sT[r0 + k][lane]), g);   // the H pass's fp16 store
         }
     }
-#pragma unroll
-    for (int k = 0; k < PER_T; k++) store_h4(reinterpret_cast<pbr_half*>(&sT[wv + NW * k][lane]), hacc[k]);   // the H pass's fp16 store
     __syncthreads();
     // ---- phase 3: V-gauss + tail
 #pragma unroll
@@ -453,6 +464,8 @@ __global__ __launch_bounds__(NT) void k_blur_hv(const pbr_half* __restrict__ in,
                     atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.x, (float)o.y, (float)o.z, min_log, inv_range)], 1u);
             }
         }
+    }
+    if (tile + (int)gridDim.x < n_tiles) __syncthreads();   // the next tile overwrites sT
     }
     if (TAIL == 2) {
         __syncthreads();
@@ -485,13 +498,19 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
     const int hx1 = rect ? (int)(rect[0] + rect[2]) : 0, hy1 = rect ? (int)(rect[1] + rect[3]) : 0;
     // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 (256) below
     static const int forced = getenv("PBR_BLOOM_TILE") ? atoi(getenv("PBR_BLOOM_TILE")) : 0;
-    const bool big = forced ? forced == 32 : (uint64_t)((ow + 63) / 64) * ((oh + 31) / 32) >= 1024;
+    const bool big = forced ? forced == 32 : (uint64_t)((ow + 63) / 64) * ((oh + 31) / 32) >= 900;
+    static const int hist_blocks = getenv("PBR_BLOOM_HIST_BLOCKS") ? atoi(getenv("PBR_BLOOM_HIST_BLOCKS")) : 768;
+    const int tiles_x = (int)((ow + 63) / 64);
     if (big) {
-        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 32, 512>), dim3((ow + 63) / 64, (oh + 31) / 32), dim3(512), 0, ctx->stream,
-                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
+        const int n_tiles = tiles_x * (int)((oh + 31) / 32);
+        const int blocks = TAIL == 2 && n_tiles > hist_blocks ? hist_blocks : n_tiles;
+        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 32, 512>), dim3(blocks), dim3(512), 0, ctx->stream,
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
     } else {
-        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 16, 256>), dim3((ow + 63) / 64, (oh + 15) / 16), dim3(256), 0, ctx->stream,
-                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
+        const int n_tiles = tiles_x * (int)((oh + 15) / 16);
+        const int blocks = TAIL == 2 && n_tiles > hist_blocks ? hist_blocks : n_tiles;
+        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 16, 256>), dim3(blocks), dim3(256), 0, ctx->stream,
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
     }
     return launched(ctx, "k_blur_hv");
 }

@@ -30,4 +30,8 @@ for _ in range(3):
     e1.synchronize()
     best = min(best, e0.elapsed_time(e1) / 50)
 frame = bench.time_stage(fr.render, 30)
+fr.shade()
+b_nohist = bench.time_stage(fr.bloom, 30, pre=fr.shade)
+b_hist = bench.time_stage(fr.bloom_histogram, 30, pre=fr.shade)
+print(f"   bloom {b_nohist:.4f} ms, bloom+histogram {b_hist:.4f} ms (each incl. nothing else; shade re-run before every sample)", flush=True)
 print(f"{sys.argv[1] if len(sys.argv) > 1 else ''}: shade isolated {iso:.4f} ms, back-to-back {best:.4f} ms, frame {frame:.4f} ms", flush=True)
