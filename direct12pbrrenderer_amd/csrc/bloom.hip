@@ -499,16 +499,19 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
     // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 (256) below
     static const int forced = getenv("PBR_BLOOM_TILE") ? atoi(getenv("PBR_BLOOM_TILE")) : 0;
     const bool big = forced ? forced == 32 : (uint64_t)((ow + 63) / 64) * ((oh + 31) / 32) >= 900;
-    static const int hist_blocks = getenv("PBR_BLOOM_HIST_BLOCKS") ? atoi(getenv("PBR_BLOOM_HIST_BLOCKS")) : 768;
+    // histogram instance: ~1024 blocks that each walk the same number of tiles (an uneven split leaves the chip
+    // half empty for the last round; one block per tile costs 256 contended global atomics per tile)
+    static const int hist_blocks = getenv("PBR_BLOOM_HIST_BLOCKS") ? atoi(getenv("PBR_BLOOM_HIST_BLOCKS")) : 1024;
+    auto even_blocks = [](int n_tiles) { const int per = (n_tiles + hist_blocks - 1) / hist_blocks; return (n_tiles + per - 1) / per; };
     const int tiles_x = (int)((ow + 63) / 64);
     if (big) {
         const int n_tiles = tiles_x * (int)((oh + 31) / 32);
-        const int blocks = TAIL == 2 && n_tiles > hist_blocks ? hist_blocks : n_tiles;
+        const int blocks = TAIL == 2 ? even_blocks(n_tiles) : n_tiles;
         hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 32, 512>), dim3(blocks), dim3(512), 0, ctx->stream,
                            in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
     } else {
         const int n_tiles = tiles_x * (int)((oh + 15) / 16);
-        const int blocks = TAIL == 2 && n_tiles > hist_blocks ? hist_blocks : n_tiles;
+        const int blocks = TAIL == 2 ? even_blocks(n_tiles) : n_tiles;
         hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 16, 256>), dim3(blocks), dim3(256), 0, ctx->stream,
                            in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
     }

@@ -13,6 +13,7 @@
 //    so their L2/MALL latency hides under ~2 000 VALU instructions; the env chain is sampled from
 //    its padded layout (pbr_env_pad): no seam branches, each bilinear row is one 16-byte load;
 //  * with 256 lights the kernel is FP32-VALU-bound (~60 VALU per pixel-light), not HBM-bound.
+#include <type_traits>
 #include "pbr_internal.hpp"
 #include "pbr_device.hpp"
 
@@ -100,6 +101,15 @@ __device__ __forceinline__ f2 max2(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmax
 __device__ __forceinline__ f2 rsq2(f2 a) { return f2{rsq(a.x), rsq(a.y)}; }
 __device__ __forceinline__ f2 rcp2(f2 a) { return f2{rcp(a.x), rcp(a.y)}; }
 
+// v_pk_mul_f32 with the clamp output modifier: clamp(a * b, 0, 1) on both halves, free of charge.  Used for the
+// cosines N.L and N.H, which the shader clamps from below with max(., 0) and which cannot exceed 1 except by a
+// rounding error of normalised vectors (1 + 1e-7 becomes 1).
+__device__ __forceinline__ f2 mul2_sat(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 struct alignas(8) H4x2 { H4 a, b; };   // two x-adjacent half4 texels (16 bytes, 8-byte aligned)
 struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-byte aligned)
 
@@ -115,7 +125,7 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 //   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
 template <bool STAGED_LISTS, int LSTRIDE>
 __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint16_t* lists, const uint32_t* mip_off,
-                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, uint32_t px, uint32_t py) {
+                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, bool q_safe, uint32_t px, uint32_t py) {
     const size_t gi = (size_t)py * p.pitch + px;
     if (p.stencil[gi] == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
     const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
@@ -170,7 +180,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // occupancy, v_pk_{fma,mul,add}_f32 every ~5.4 with >= 6 resident waves — 1.5x per flop.  The SoA
         // light planes put the same component of both lights into an adjacent VGPR pair with no moves.
         f2 a1x = f2s(0.0f), a1y = f2s(0.0f), a1z = f2s(0.0f), a2x = f2s(0.0f), a2y = f2s(0.0f), a2z = f2s(0.0f), a3x = f2s(0.0f), a3y = f2s(0.0f), a3z = f2s(0.0f);
-        auto light2 = [&](int liA, int liB, float wB) {
+        auto light2 = [&](auto q_safe, int liA, int liB) {
+            constexpr bool QSAFE = decltype(q_safe)::value;
             const float* la = llds + liA;   // indices were clamped to the staged table when the lists were staged
             const float* lb = llds + liB;
             auto comp = [&](int c) { return f2{la[c * LSTRIDE], lb[c * LSTRIDE]}; };
@@ -178,20 +189,24 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const f2 d2 = dx * dx + dy * dy + dz * dz;
             const f2 invd = rsq2(d2);
             const f2 dist = d2 * invd;
-            const f2 NdL = (dx * n.x + dy * n.y + dz * n.z) * invd;
-            const f2 NdotL = max2(NdL, f2s(0.0f));
+            const f2 dn = dx * n.x + dy * n.y + dz * n.z;
+            const f2 NdL = dn * invd;
+            const f2 NdotL = mul2_sat(dn, invd);   // max(N.L, 0)
             const f2 LdV = (dx * view.x + dy * view.y + dz * view.z) * invd;
             // |L + V|^2 = 2 + 2 L.V ; N.H = (N.L + N.V) / |L + V|
             // (|.| is a free source modifier of v_rsq: rounding can push 2+2 L.V a hair below 0; at exactly 0, L = -V,
             //  N.L + N.V is 0 too and max(NaN, 0) = 0)
             const f2 h2 = LdV * 2.0f + f2s(2.0f);
-            const f2 NdotH = max2((NdL + f2s(NdV)) * f2{rsq(__builtin_fabsf(h2.x)), rsq(__builtin_fabsf(h2.y))}, f2s(0.0f));
+            const f2 NdotH = mul2_sat(NdL + f2s(NdV), f2{rsq(__builtin_fabsf(h2.x)), rsq(__builtin_fabsf(h2.y))});
             const f2 t = (NdotH * NdotH) * a4m1 + f2s(1.0f);
             const f2 T = max2(t * t, f2s(t_floor));
             const f2 A = NdotL * one_k + f2s(k);
             const f2 B = max2(NdotL * ndv4, f2s(0.0001f));
-            const f2 Q = max2(comp(6) + comp(7) * dist + comp(8) * d2, f2s(EPSILON_F));
-            const f2 X = (NdotL * rcp2(Q)) * f2{1.0f, wB};   // attenuation * NdotL (light B masked off on an odd tail)
+            // attenuation(): max(C0 + C1 d + C2 d^2, 1e-6).  QSAFE: every staged light has C0 >= 1e-6 and C1, C2 >= 0,
+            // so the floor never binds (checked once per block while the table is staged)
+            f2 Q = comp(6) + comp(7) * dist + comp(8) * d2;
+            if constexpr (!QSAFE) Q = max2(Q, f2s(EPSILON_F));
+            const f2 X = NdotL * rcp2(Q);   // attenuation * NdotL
             // fresnel on NdotL (Q3).  The shader's max(1-NdotL, 1e-6) only matters within 1e-6 of NdotL = 1, where it
             // changes f5 by < 1e-30: dropped.
             const f2 fm = f2s(1.0f) - NdotL;
@@ -207,20 +222,20 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         };
         if (STAGED_LISTS) {
             const uint16_t* my = lists + (((sy - tile_y0) * tiles_x + (sx - tile_x0)) * PBR_CLUSTER_Z + sz) * LIST_STRIDE_U16;
+            // staged lists are padded to an even count with the null light (black, far away): no odd tail
             const int nl = my[0];
-            int i = 0;
-            for (; i + 1 < nl; i += 2) {   // two indices per LDS read
-                const uint32_t pair = *reinterpret_cast<const uint32_t*>(my + 2 + i);   // i even -> 4-byte aligned
-                light2((int)(pair & 0xFFFFu), (int)(pair >> 16), 1.0f);
-            }
-            if (i < nl) light2((int)my[2 + i], (int)my[2 + i], 0.0f);
+            auto walk = [&](auto qs) {
+                for (int i = 0; i < nl; i += 2) {   // two indices per LDS read
+                    const uint32_t pair = *reinterpret_cast<const uint32_t*>(my + 2 + i);   // i even -> 4-byte aligned
+                    light2(qs, (int)(pair & 0xFFFFu), (int)(pair >> 16));
+                }
+            };
+            if (q_safe) walk(std::true_type{}); else walk(std::false_type{});
         } else {
             const pbr_cluster* cl = p.clusters + (sz + sx * PBR_CLUSTER_Z + sy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
             const int nl = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
-            int i = 0;
-            auto idx = [&](int q) { return min(max(cl->LightIndex[q], 0), n_lights - 1); };
-            for (; i + 1 < nl; i += 2) light2(idx(i), idx(i + 1), 1.0f);
-            if (i < nl) light2(idx(i), idx(i), 0.0f);
+            auto idx = [&](int q) { return q < nl ? min(max(cl->LightIndex[q], 0), n_lights - 1) : n_lights; };   // n_lights = the null light
+            for (int i = 0; i < nl; i += 2) light2(std::false_type{}, idx(i), idx(i + 1));
         }
         s1x = a1x.x + a1x.y; s1y = a1y.x + a1y.y; s1z = a1z.x + a1z.y;
         s2x = a2x.x + a2x.y; s2y = a2y.x + a2y.y; s2z = a2z.x + a2z.y;
@@ -345,8 +360,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
     float* llds = reinterpret_cast<float*>(lds_raw);
     uint16_t* lists = reinterpret_cast<uint16_t*>(llds + LIGHT_PLANES * LSTRIDE);
+    int my_safe = 1;
+    if (threadIdx.x == 0) {   // the null light: pads odd lists; black, so its pair lane contributes exactly 0
+        llds[0 * LSTRIDE + n_lights] = 1.0e15f; llds[1 * LSTRIDE + n_lights] = 1.0e15f; llds[2 * LSTRIDE + n_lights] = 1.0e15f;
+        llds[3 * LSTRIDE + n_lights] = 0.0f; llds[4 * LSTRIDE + n_lights] = 0.0f; llds[5 * LSTRIDE + n_lights] = 0.0f;
+        llds[6 * LSTRIDE + n_lights] = 1.0f; llds[7 * LSTRIDE + n_lights] = 0.0f; llds[8 * LSTRIDE + n_lights] = 0.0f;
+    }
     for (int i = threadIdx.x; i < n_lights; i += SHADE_BLOCK) {
         const pbr_light l = p.lights[i];
+        my_safe &= (l.C0 >= EPSILON_F) & (l.C1 >= 0.0f) & (l.C2 >= 0.0f);
         llds[0 * LSTRIDE + i] = l.Position[0];
         llds[1 * LSTRIDE + i] = l.Position[1];
         llds[2 * LSTRIDE + i] = l.Position[2];
@@ -382,16 +404,17 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
             const int z = c % PBR_CLUSTER_Z, t = c / PBR_CLUSTER_Z;
             const int cx = tile_x0 + t % tiles_x, cy = tile_y0 + t / tiles_x;
             const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+            const int cnt = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
             int val = 0;
-            if (j == 0) val = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
-            else if (j >= 2) val = min(max(cl->LightIndex[j - 2], 0), n_lights - 1);   // never index past the staged light table
+            if (j == 0) val = (cnt + 1) & ~1;   // padded to even with the null light
+            else if (j >= 2) val = (j - 2) < cnt ? min(max(cl->LightIndex[j - 2], 0), n_lights - 1) : n_lights;   // never index past the staged table
             lists[e] = (uint16_t)val;
         }
     }
-    __syncthreads();
+    const bool q_safe = __syncthreads_and(my_safe) != 0;
     const uint32_t px = bx0 + threadIdx.x;
     if (px >= p.w) return;
-    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, px, py);
+    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py);
 }
 
 extern "C" {

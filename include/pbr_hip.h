@@ -240,11 +240,12 @@ pbr_status pbr_bloom_upsample_add(pbr_ctx* ctx, const pbr_half* upper, uint32_t 
 /* bloom_merge.hlsl:7-11: hdr += in (both w x h; hdr pitch in pixels). */
 pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pbr_half* in,
                            uint32_t w, uint32_t h);
-/* BloomPass::Execute (DeferredPipeline.cpp:400-570), all 16 dispatches.  chain_a / chain_b:
- * pbr_bloom_chain_texels(w,h) half4 texels each (BloomMipchain / BloomTempTexture).  The last
- * three dispatches (V blur of B[0], merge) run as ONE kernel: level 0 of chain_a is an
- * intermediate nobody reads afterwards and is NOT written; hdr is bit-identical to the unfused
- * sequence of stage calls. */
+/* BloomPass::Execute (DeferredPipeline.cpp:400-570), all 16 dispatches: hdr is bit-identical to the sequence of
+ * stage calls above.  chain_a / chain_b: pbr_bloom_chain_texels(w,h) half4 texels each (BloomMipchain /
+ * BloomTempTexture) — SCRATCH: their contents after the call are unspecified.  (When every level is exactly half
+ * the one above and the image is at most 8192 wide/high, the H and V pass of a level run as one kernel and the
+ * H results are never written; otherwise the staged kernels run and only level 0 of chain_a — the V blur the
+ * merge consumes — stays unwritten.) */
 pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                      pbr_half* chain_a, pbr_half* chain_b, float threshold, float knee);
 

@@ -271,7 +271,9 @@ def test_bloom_chain_vs_golden_every_mip(ctx, orc, golden):
     for l in range(5):
         la, lb = _levels(ga, 128, 72)[l], _levels(gb_, 128, 72)[l]
         wa, wb = _levels(golden["bloom_chain_a"], 128, 72)[l], _levels(golden["bloom_chain_b"], 128, 72)[l]
-        if l > 0:   # pbr_bloom fuses V(B0) + merge: A[0] is an intermediate it never materialises
+        # (128x72 is not an exact 2x pyramid — 9 >> 1 = 4 — so pbr_bloom takes the staged kernels here and the chains
+        #  hold the staged intermediates; in general they are scratch, see pbr_hip.h)
+        if l > 0:   # the staged tail fuses V(B0) + merge: A[0] is an intermediate it never materialises
             assert np.array_equal(la.view(np.uint16), wa.view(np.uint16)), f"chain A level {l}"
         assert np.array_equal(lb.view(np.uint16), wb.view(np.uint16)), f"chain B level {l}"
     assert np.array_equal(to_np_half(hdr).view(np.uint16), golden["bloom_hdr"].view(np.uint16))
@@ -549,3 +551,22 @@ def test_bloom_fused_exact_pyramid_bit_exact(ctx, orc, w, h):
     hdr2 = dev_half(ctx, img)
     ctx.bloom(hdr2, w, h, w, ca, cb)
     assert np.array_equal(to_np_half(hdr2).view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.gpu
+def test_deferred_shade_attenuation_floor_and_odd_lists(ctx, orc, ibl):
+    """Lights whose attenuation polynomial can drop below the shader's 1e-6 floor (C0 = 0: the floor binds near the
+    light) take the kernel's unhoisted-floor path; 7 lights give odd per-cluster lists (padded with the null light)."""
+    sky, env, lut, sh = ibl
+    cam, g, lights, gb, tile = common.shade_scene(256, 144, 256, sh, rough_min=48)
+    lights = lights[:7].copy()
+    lights["C0"][::2] = 0.0
+    lights["C1"][::2] = 0.0
+    lights["C2"][::2] = 1e-9
+    lights["Intensity"][::2] = 1e-7          # keeps the radiance finite where 1/max(Q, 1e-6) = 1e6
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    assert (cl["NumLights"] % 2 == 1).any()
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+    _check_shade(got, want, want_f32, gb["stencil"], "attenuation floor / odd lists")
