@@ -4,9 +4,9 @@ import sys
 
 d = json.load(open(sys.argv[1]))
 for k, v in d.items():
-    wc = v.get("SQ_WAVE_CYCLES", 0)
-    if k.startswith("_") or not wc:
+    if k.startswith("_") or not isinstance(v, dict) or not v.get("SQ_WAVE_CYCLES", 0):
         continue
+    wc = v["SQ_WAVE_CYCLES"]
     waves = max(v.get("SQ_WAVES", 1), 1)
     busy = max(v.get("SQ_BUSY_CYCLES", 1), 1)
     print(f"{k.replace('void ', '')[:40]:40s} waves {waves:8.0f} VALU/wave {v.get('SQ_INSTS_VALU', 0) / waves:7.0f} LDS/wave {v.get('SQ_INSTS_LDS', 0) / waves:6.0f} "
