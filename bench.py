@@ -2,11 +2,11 @@
 """bench.py — shaded Mpixel/s of the full deferred frame on synthetic 4K G-buffers (BASELINE.json).
 
 A "step" is one frame of the hot path over one rank's tile: cluster build + cull, deferred shade
-(256 clustered lights + IBL), the 16-dispatch bloom chain, luminance histogram (+ RCCL all-reduce
-when N > 1), average, ACES tone-map — i.e. BASELINE.json configs[3] at N = 1.  Inputs (G-buffer,
+(256 clustered lights + IBL), the bloom chain (16 reference dispatches, 8 fused launches) with the luminance
+histogram in its last kernel (+ RCCL all-reduce when N > 1), average, ACES tone-map — i.e. BASELINE.json configs[3] at N = 1.  Inputs (G-buffer,
 lights, LUT, prefiltered env, SH) are resident in HBM before the timed region.  Weak scaling: each
-rank owns one 3840x2160 tile of a (cols x rows)-tile frame and shades a 256-px apron towards its
-neighbours so bloom needs no halo exchange; `value` counts interior pixels only.
+rank owns one 3840x2160 tile of an N x 1 tile frame (tiles side by side: short edges shared) and shades a
+256-px apron towards its neighbours so bloom needs no halo exchange; `value` counts interior pixels only.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...

@@ -98,8 +98,9 @@ def test_synthetic_tile_equals_region_of_full_frame():
 
 
 def test_tile_specs_cover_the_frame_once():
-    for world in (1, 2, 4, 8):
-        cols, rows = grid_for_world(world)
+    for world in (1, 2, 3, 4, 8):
+        cols, rows = grid_for_world(world, 64, 48)
+        assert (cols, rows) == (world, 1)                   # landscape tiles side by side: short edges shared
         cover = np.zeros((rows * 48, cols * 64), dtype=np.int32)
         for r in range(world):
             s = tile_for_rank(r, world, 64, 48, apron=16)
@@ -109,10 +110,14 @@ def test_tile_specs_cover_the_frame_once():
             assert (s.apron == 0) == (world == 1)
             assert s.ex0 % 16 == 0 and s.ey0 % 16 == 0      # extended origin stays on the coarsest mip grid
         assert np.all(cover == 1)
+    assert grid_for_world(4, 48, 64) == (1, 4)              # portrait tiles stack
     with pytest.raises(ValueError):
-        grid_for_world(6)
+        grid_for_world(0)
     with pytest.raises(ValueError):
         tile_for_rank(0, 2, 64, 40, apron=16)
+    # the busiest rank of 8 shades 13.3 % more pixels than its 3840x2160 tile (27 % in a 4x2 arrangement)
+    s8 = tile_for_rank(3, 8, 3840, 2160)
+    assert (s8.ew, s8.eh) == (3840 + 512, 2160) and abs(s8.ew * s8.eh / (3840 * 2160) - 1.1333) < 1e-3
     s = TileSpec(0, 0, 64, 40, 128, 40, 16)
     assert (s.ew, s.eh) == (80, 40)
 
