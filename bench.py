@@ -253,7 +253,7 @@ def main():
             frame.hist.zero_()
         dom = max(("shade", "bloom+histogram", "tonemap"), key=lambda k: kern[k]["ms"])
         achieved = kern[dom]["GB/s"]
-        out["roofline"] = {"bound": "hbm", "kernel": {"shade": "k_deferred_shade", "bloom+histogram": "bloom chain (14 launches, histogram fused)",
+        out["roofline"] = {"bound": "hbm", "kernel": {"shade": "k_deferred_shade", "bloom+histogram": "bloom chain (8 launches, histogram fused)",
                                                      "tonemap": "k_tonemap"}[dom],
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": pmc_traffic("k_deferred_shade", spec.ew * spec.eh) if dom == "shade" else None, "stage_ms": {k: v["ms"] for k, v in kern.items()},

@@ -37,6 +37,7 @@ SIGNATURES = {
     "pbr_sh9_project": (_int, [_vp, C.POINTER(CubeF32), _vp]),
     "pbr_cluster_build": (_int, [_vp, C.POINTER(Global), _vp]),
     "pbr_cluster_cull": (_int, [_vp, C.POINTER(Global), _vp, _int, _vp]),
+    "pbr_clustered": (_int, [_vp, C.POINTER(Global), _vp, _int, _vp]),
     "pbr_deferred_shade": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer),
                                   _vp, _u32, _vp, _u32, _u32, _vp, _vp, _int, _vp, _u32]),
     "pbr_skybox": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(CubeF32), _vp, _u32, _vp, _u32]),

@@ -126,6 +126,10 @@ class PbrContext:
     def cluster_cull(self, g: Global, lights, n, clusters):
         self._check(self.lib.pbr_cluster_cull(self.h, C.byref(g), _ptr(lights), int(n), _ptr(clusters)))
 
+    def clustered(self, g: Global, lights, n, clusters):
+        """cluster_build + cluster_cull in one launch (ClusteredPass::Execute)."""
+        self._check(self.lib.pbr_clustered(self.h, C.byref(g), _ptr(lights), int(n), _ptr(clusters)))
+
     def deferred_shade(self, g: Global, tile: Tile, gb, pitch, lut, lut_res, env, env_size, env_mips,
                        clusters, lights, num_lights, hdr, hdr_pitch):
         """gb: dict with device tensors A,B,C,depth,stencil; env: the PADDED chain from env_pad()."""

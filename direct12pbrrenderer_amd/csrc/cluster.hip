@@ -20,10 +20,8 @@ __device__ __forceinline__ int cluster_index3(int x, int y, int z) {   // cluste
     return z + x * PBR_CLUSTER_Z + y * PBR_CLUSTER_X * PBR_CLUSTER_Z;
 }
 
-// grid 12 x block 256: one thread per cluster (3 072)
-__global__ __launch_bounds__(256) void k_cluster_build(ClusterParams p, pbr_cluster* __restrict__ clusters) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= PBR_NUM_CLUSTERS) return;
+// view-space AABB of cluster t (clustered_compute.hlsl:8-42)
+__device__ __forceinline__ void cluster_bounds(const ClusterParams& p, int t, float mn[3], float mx[3]) {
     const int z = t % PBR_CLUSTER_Z, tx = (t / PBR_CLUSTER_Z) % PBR_CLUSTER_X, ty = t / (PBR_CLUSTER_Z * PBR_CLUSTER_X);
     const float htan = tanf(p.Fov / 2.0f);
     const float znear = p.Near * powf(p.Far / p.Near, (float)z / (float)PBR_CLUSTER_Z);
@@ -38,9 +36,19 @@ __global__ __launch_bounds__(256) void k_cluster_build(ClusterParams p, pbr_clus
     };
     V3 min_near = zplane(minx, miny, znear), min_far = zplane(minx, miny, zfar);
     V3 max_near = zplane(maxx, maxy, znear), max_far = zplane(maxx, maxy, zfar);
-    pbr_cluster* c = clusters + cluster_index3(tx, ty, z);
-    c->MinBound[0] = fminf(min_near.x, min_far.x); c->MinBound[1] = fminf(min_near.y, min_far.y); c->MinBound[2] = fminf(min_near.z, min_far.z);
-    c->MaxBound[0] = fmaxf(max_near.x, max_far.x); c->MaxBound[1] = fmaxf(max_near.y, max_far.y); c->MaxBound[2] = fmaxf(max_near.z, max_far.z);
+    mn[0] = fminf(min_near.x, min_far.x); mn[1] = fminf(min_near.y, min_far.y); mn[2] = fminf(min_near.z, min_far.z);
+    mx[0] = fmaxf(max_near.x, max_far.x); mx[1] = fmaxf(max_near.y, max_far.y); mx[2] = fmaxf(max_near.z, max_far.z);
+}
+
+// grid 12 x block 256: one thread per cluster (3 072); cluster t sits at index t (cluster_index3 is the same order)
+__global__ __launch_bounds__(256) void k_cluster_build(ClusterParams p, pbr_cluster* __restrict__ clusters) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= PBR_NUM_CLUSTERS) return;
+    float mn[3], mx[3];
+    cluster_bounds(p, t, mn, mx);
+    pbr_cluster* c = clusters + t;
+    c->MinBound[0] = mn[0]; c->MinBound[1] = mn[1]; c->MinBound[2] = mn[2];
+    c->MaxBound[0] = mx[0]; c->MaxBound[1] = mx[1]; c->MaxBound[2] = mx[2];
     c->NumLights = 0;
 }
 
@@ -58,17 +66,26 @@ __device__ __forceinline__ bool light_hits(const ClusterParams& p, const pbr_lig
     return (dx * dx + dy * dy) + dz * dz < radius * radius;
 }
 
-// grid 3072/4 x block 256 (4 waves, one cluster per wave)
+// grid 3072/4 x block 256 (4 waves, one cluster per wave).  BUILD: both dispatches of ClusteredPass::Execute in one
+// launch — the wave computes its cluster's bounds itself (every lane the same values) instead of reading them back.
+template <bool BUILD>
 __global__ __launch_bounds__(256) void k_cluster_cull(ClusterParams p, const pbr_light* __restrict__ lights, int n,
                                                         pbr_cluster* __restrict__ clusters) {
     const int lane = threadIdx.x & 63;
     const int ci = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ci >= PBR_NUM_CLUSTERS) return;   // wave-uniform
     pbr_cluster* c = clusters + ci;
-    float mn[3] = {c->MinBound[0], c->MinBound[1], c->MinBound[2]};
-    float mx[3] = {c->MaxBound[0], c->MaxBound[1], c->MaxBound[2]};
-    int count = c->NumLights;   // continues a partially filled list like the reference loop condition
-    count = min(max(count, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
+    float mn[3], mx[3];
+    int count = 0;
+    if (BUILD) {
+        cluster_bounds(p, ci, mn, mx);
+        if (lane < 3) { c->MinBound[lane] = mn[lane]; c->MaxBound[lane] = mx[lane]; }
+    } else {
+        mn[0] = c->MinBound[0]; mn[1] = c->MinBound[1]; mn[2] = c->MinBound[2];
+        mx[0] = c->MaxBound[0]; mx[1] = c->MaxBound[1]; mx[2] = c->MaxBound[2];
+        count = c->NumLights;   // continues a partially filled list like the reference loop condition
+        count = min(max(count, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
+    }
     for (int base = 0; base < n && count < PBR_MAX_LIGHTS_PER_CLUSTER; base += 64) {   // wave-uniform loop
         const int i = base + lane;
         bool hit = false;
@@ -105,8 +122,18 @@ pbr_status pbr_cluster_cull(pbr_ctx* ctx, const pbr_global* g, const pbr_light* 
     PBR_REQUIRE(ctx, n >= 0 && n <= PBR_MAX_SCENE_LIGHTS, "pbr_cluster_cull: light count out of [0, 1024]");
     PBR_REQUIRE(ctx, n == 0 || lights != nullptr, "pbr_cluster_cull: null lights");
     if (n == 0) return PBR_OK;
-    hipLaunchKernelGGL(k_cluster_cull, dim3(PBR_NUM_CLUSTERS / 4), dim3(256), 0, ctx->stream, make_params(g), lights, n, clusters);
+    hipLaunchKernelGGL(k_cluster_cull<false>, dim3(PBR_NUM_CLUSTERS / 4), dim3(256), 0, ctx->stream, make_params(g), lights, n, clusters);
     return launched(ctx, "k_cluster_cull");
+}
+
+pbr_status pbr_clustered(pbr_ctx* ctx, const pbr_global* g, const pbr_light* lights, int n, pbr_cluster* clusters) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, g && clusters, "pbr_clustered: null pointer");
+    PBR_REQUIRE(ctx, g->Near > 0.0f && g->Far > g->Near, "pbr_clustered: need 0 < Near < Far");
+    PBR_REQUIRE(ctx, n >= 0 && n <= PBR_MAX_SCENE_LIGHTS, "pbr_clustered: light count out of [0, 1024]");
+    PBR_REQUIRE(ctx, n == 0 || lights != nullptr, "pbr_clustered: null lights");
+    hipLaunchKernelGGL(k_cluster_cull<true>, dim3(PBR_NUM_CLUSTERS / 4), dim3(256), 0, ctx->stream, make_params(g), lights, n, clusters);
+    return launched(ctx, "k_cluster_cull<build>");
 }
 
 }  // extern "C"

@@ -57,19 +57,19 @@ __global__ __launch_bounds__(256) void k_lum_histogram(const pbr_half* __restric
 }
 
 // hdr_average_histogram.hlsl:26-73 — one 256-thread group, the same LDS tree (fixed fp32 order).
-__global__ __launch_bounds__(256) void k_lum_average(uint32_t* __restrict__ hist, uint32_t pixel_count, float min_log, float range,
-                                                       float delta_time, float* __restrict__ avg) {
+// hdr_average_histogram.hlsl:26-73 for a 256-thread block: thread 0 returns the adapted luminance (others 0)
+__device__ __forceinline__ float adapted_luminance(float* sh, const uint32_t* __restrict__ hist, uint32_t pixel_count, float min_log, float range,
+                                                   float delta_time, float prev) {
 #pragma clang fp contract(off)
-    __shared__ float sh[PBR_HISTOGRAM_BINS];
     const uint32_t index = threadIdx.x;
     const uint32_t num_pixels = hist[index];
     sh[index] = (float)(uint32_t)(num_pixels * index);   // uint32 product (Q15)
     __syncthreads();
-    hist[index] = 0u;   // clear for the next frame
     for (uint32_t step = PBR_HISTOGRAM_BINS >> 1; step > 0; step >>= 1) {
         if (index < step) sh[index] += sh[index + step];
         __syncthreads();
     }
+    float result = 0.0f;
     if (index == 0) {
         const float sum_value = sh[0];
         const float average_bin = sum_value / (float)(pixel_count - num_pixels);   // Q14
@@ -78,10 +78,18 @@ __global__ __launch_bounds__(256) void k_lum_average(uint32_t* __restrict__ hist
                            ? (average_bin >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)average_bin) : 0u;
         const float log_l = ((float)bin - 1.0f) / 254.0f;
         const float lum = exp2f(log_l * range + min_log);
-        const float prev = avg[0];
         const float tt = saturatef(1.0f - expf(-delta_time * 1.6f));   // SMOOTH_TIME 1.6
-        avg[0] = prev + tt * (lum - prev);
+        result = prev + tt * (lum - prev);
     }
+    return result;
+}
+
+__global__ __launch_bounds__(256) void k_lum_average(uint32_t* __restrict__ hist, uint32_t pixel_count, float min_log, float range,
+                                                       float delta_time, float* __restrict__ avg) {
+    __shared__ float sh[PBR_HISTOGRAM_BINS];
+    const float r = adapted_luminance(sh, hist, pixel_count, min_log, range, delta_time, avg[0]);
+    hist[threadIdx.x] = 0u;   // clear for the next frame (every thread read its bin before the first barrier above)
+    if (threadIdx.x == 0) avg[0] = r;
 }
 
 // hdr_tone_mapping.hlsl:27-36.  The result is quantised to 8 bits (tolerance 1 LSB), so the fast
@@ -104,9 +112,9 @@ __device__ __forceinline__ uint32_t tonemap_px(float r, float g, float b, float 
 }
 
 // persistent grid (<= 2048 blocks of 256), two pixels per lane per trip: 16-byte load, 8-byte store
-__global__ __launch_bounds__(256) void k_tonemap(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
-                                                   const float* __restrict__ avg, uint32_t* __restrict__ out, uint32_t out_pitch, bool aligned) {
-    const float l_max = 9.6f * avg[0];
+__device__ __forceinline__ void tonemap_pixels(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                               float avg_lum, uint32_t* __restrict__ out, uint32_t out_pitch, bool aligned) {
+    const float l_max = 9.6f * avg_lum;
     const float inv_den = 1.0f / (l_max + 0.001f);
     const uint32_t wp = (w + 1) >> 1;   // pixel pairs per row
     const size_t n = (size_t)wp * h;
@@ -127,6 +135,11 @@ __global__ __launch_bounds__(256) void k_tonemap(const pbr_half* __restrict__ hd
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_tonemap(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                                   const float* __restrict__ avg, uint32_t* __restrict__ out, uint32_t out_pitch, bool aligned) {
+    tonemap_pixels(hdr, w, h, pitch, avg[0], out, out_pitch, aligned);
 }
 
 extern "C" {

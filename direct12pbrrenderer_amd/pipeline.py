@@ -129,8 +129,7 @@ class DeferredFrame:
         return self.hdr.data_ptr() + 8 * (s.iy * s.ew + s.ix)
 
     def clustered(self):
-        self.ctx.cluster_build(self.g, self.clusters)
-        self.ctx.cluster_cull(self.g, self.lights, self.n_lights, self.clusters)
+        self.ctx.clustered(self.g, self.lights, self.n_lights, self.clusters)
 
     def skybox(self):
         s = self.spec

@@ -193,6 +193,10 @@ pbr_status pbr_cluster_build(pbr_ctx* ctx, const pbr_global* g, pbr_cluster* clu
 /* clustered_culling.hlsl:18-41 (DeferredPipeline.cpp:256).  lights: device, n <= 1024. */
 pbr_status pbr_cluster_cull(pbr_ctx* ctx, const pbr_global* g, const pbr_light* lights, int n,
                             pbr_cluster* clusters);
+/* both dispatches of ClusteredPass::Execute (DeferredPipeline.cpp:253-256) in one launch: bounds + light lists;
+ * same results as pbr_cluster_build followed by pbr_cluster_cull */
+pbr_status pbr_clustered(pbr_ctx* ctx, const pbr_global* g, const pbr_light* lights, int num_lights,
+                         pbr_cluster* clusters);
 
 /* deferred_shading.hlsl:91-192 full-screen pass, stencil-masked (DeferredPipeline.cpp:187-206).
  * gb: HOST struct of device planes.  lut: res x res half2.  env_padded: the PADDED half4 cube chain
@@ -265,7 +269,6 @@ pbr_status pbr_lum_average(pbr_ctx* ctx, uint32_t* hist256, uint32_t pixel_count
 /* hdr_tone_mapping.hlsl:9-52 (DeferredPipeline.cpp:320-336): hdr -> RGBA8 UNORM. */
 pbr_status pbr_tonemap(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                        const float* avg, uint32_t* rgba8, uint32_t out_pitch);
-
 /* ---- multi-GPU (new) -------------------------------------------------------------- */
 /* RCCL communicator over the ranks of one node.  unique_id: 128 bytes from
  * pbr_comm_unique_id() on rank 0, broadcast by the caller (e.g. torch.distributed store). */

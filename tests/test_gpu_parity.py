@@ -570,3 +570,27 @@ def test_deferred_shade_attenuation_floor_and_odd_lists(ctx, orc, ibl):
     want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
     _check_shade(got, want, want_f32, gb["stencil"], "attenuation floor / odd lists")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_lights", [0, 5, 256, 1024])
+def test_clustered_single_launch_equals_build_then_cull(ctx, ibl, n_lights):
+    sky, env, lut, sh = ibl
+    cam = scene.Camera.reference_default(1280, 720)
+    g = scene.make_global(cam, 1280, 720, sh_pack=sh)
+    lights = synth.lights_in_view_box(max(n_lights, 1), cam)[:n_lights]
+    dl = ctx.upload(lights) if n_lights else None
+    a, b = ctx.alloc_clusters(), ctx.alloc_clusters()
+    a.fill_(0x55)                       # stale contents must not leak into the single-launch result
+    ctx.clustered(g, dl, n_lights, a)
+    ctx.cluster_build(g, b)
+    ctx.cluster_cull(g, dl, n_lights, b)
+    ctx.sync()
+    ca = np.frombuffer(a.cpu().numpy().tobytes(), dtype=CLUSTER_DTYPE)
+    cb = np.frombuffer(b.cpu().numpy().tobytes(), dtype=CLUSTER_DTYPE)
+    assert np.array_equal(ca["MinBound"].view(np.uint32), cb["MinBound"].view(np.uint32))
+    assert np.array_equal(ca["MaxBound"].view(np.uint32), cb["MaxBound"].view(np.uint32))
+    assert np.array_equal(ca["NumLights"], cb["NumLights"])
+    for k in range(32):
+        used = ca["NumLights"] > k
+        assert np.array_equal(ca["LightIndex"][used, k], cb["LightIndex"][used, k])

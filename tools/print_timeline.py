@@ -1,10 +1,10 @@
-"""Prints the last frame (from the last k_cluster_build on) of a rocprofv3 kernel_trace.csv: duration and gap per launch."""
+"""Prints the last frame (from the last clustered launch on) of a rocprofv3 kernel_trace.csv: duration and gap per launch."""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_cluster_build")]
+idx = [i for i, r in enumerate(rows) if "k_cluster_cull<true>" in r["Kernel_Name"] or r["Kernel_Name"].startswith("k_cluster_build")]
 s = idx[-1]
 prev_end = None
 t0 = int(rows[s]["Start_Timestamp"])
