@@ -347,6 +347,33 @@ __device__ __forceinline__ half4v round_h4(F4 v) {
     return r;
 }
 
+// rgb-only variants: inside pbr_bloom the alpha of every chain level is one constant per level (the prefilter writes
+// 1, and every later pass filters a constant field with clamp addressing), so the fused kernels filter three
+// channels per pixel and push the constant through the same fp32 operations once per thread.
+__device__ __forceinline__ V3 h3f(H4 h) { return v3((float)h.x, (float)h.y, (float)h.z); }
+__device__ __forceinline__ V3 fma3(V3 a, float s, V3 b) { return v3(__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z)); }
+template <int MODE>
+__device__ __forceinline__ float4 finish_tap2_rgb(const Tap2& t, float fx, float fy) {
+    if (MODE == M_SAME) return make_float4((float)t.c00.x, (float)t.c00.y, (float)t.c00.z, 0.0f);
+    const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;   // weights 1/4, 1/2, 3/4: never 0 (see finish_tap2)
+    const V3 top = fma3(h3f(t.c10), fx, h3f(t.c00) * wx0);
+    const V3 bot = fma3(h3f(t.c11), fx, h3f(t.c01) * wx0);
+    const V3 r = fma3(bot, fy, top * wy0);
+    return make_float4(r.x, r.y, r.z, 0.0f);
+}
+__device__ __forceinline__ V3 gauss9_rgb(const float4* c) {
+    V3 v = v3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { const float4 e = c[i]; v = fma3(v3(e.x, e.y, e.z), c_gauss[i], v); }
+    return v;
+}
+__device__ __forceinline__ float gauss9_const(float c) {   // the nine fused mads of gauss9 on a constant field
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) v = __builtin_fmaf(c, c_gauss[i], v);
+    return v;
+}
+
 // H pass (+ optional second, same-size input: bloom_upsample_add) + V pass [+ merge + histogram] of one level.
 // One block = one 64 x TH tile of outputs:
 //   1+2. every wave owns (TH+8)/NW of the TH+8 rows the V pass will tap (rows outside the image repeat the edge).
@@ -375,6 +402,11 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
     if (TAIL == 2) {
         for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += NT) (&sh_hist[0][0])[i] = 0u;
     }
+    // the level's constant alpha through the H pass (+ the second input's), its fp16 store, and the V pass
+    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[0].w);
+    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[0].w);
+    const h16 alpha_t = to_half_rn(alpha_h);
+    const float alpha_v = gauss9_const((float)alpha_t);
     // 1-D grid over tiles; the histogram instance is launched with fewer blocks than tiles (each walks several) so
     // that the per-block flush of 256 global atomics stays rare
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -429,17 +461,19 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
         }
 #pragma unroll
         for (int k = 0; k < PER_T; k++) {
-            line[lane] = finish_tap2<MODE>(taps[k], fx, fy[k]);
-            if (DUAL) line2[lane] = to4(h4f(up[k]));
+            line[lane] = finish_tap2_rgb<MODE>(taps[k], fx, fy[k]);
+            if (DUAL) line2[lane] = make_float4((float)up[k].x, (float)up[k].y, (float)up[k].z, 0.0f);
             if (has_halo && hk == k) {
-                line[hc] = finish_tap2<MODE>(htap, hfx, hfy);
-                if (DUAL) line2[hc] = to4(h4f(hup));
+                line[hc] = finish_tap2_rgb<MODE>(htap, hfx, hfy);
+                if (DUAL) line2[hc] = make_float4((float)hup.x, (float)hup.y, (float)hup.z, 0.0f);
             }
             wave_sync();
-            F4 g = gauss9(line + lane);
-            if (DUAL) g = g + gauss9(line2 + lane);   // bloom_upsample_add: lower first, then upper
+            V3 g = gauss9_rgb(line + lane);
+            if (DUAL) g = g + gauss9_rgb(line2 + lane);   // bloom_upsample_add: lower first, then upper
             wave_sync();
-            store_h4(reinterpret_cast<pbr_half*>(&sT[r0 + k][lane]), g);   // the H pass's fp16 store
+            H4 th;   // the H pass's fp16 store
+            th.x = to_half_rn(g.x); th.y = to_half_rn(g.y); th.z = to_half_rn(g.z); th.w = alpha_t;
+            sT[r0 + k][lane] = th;
         }
     }
     __syncthreads();
@@ -448,9 +482,10 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
     for (int k = 0; k < PER_O; k++) {
         const int r = wv + NW * k, y = y0 + r;
         if (x >= ow || y >= oh) continue;
-        F4 a = f4(0.0f, 0.0f, 0.0f, 0.0f);
+        V3 a3 = v3(0.0f, 0.0f, 0.0f);
 #pragma unroll
-        for (int i = 0; i < 9; i++) a = fma4(h4f(sT[r + i][lane]), c_gauss[i], a);
+        for (int i = 0; i < 9; i++) a3 = fma3(h3f(sT[r + i][lane]), c_gauss[i], a3);
+        const F4 a = f4(a3.x, a3.y, a3.z, alpha_v);
         if (TAIL == 0) {
             store_h4(out + 4 * ((size_t)y * out_pitch + x), a);
         } else {
