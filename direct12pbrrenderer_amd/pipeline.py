@@ -162,12 +162,20 @@ class DeferredFrame:
         s = self.spec
         self.ctx.tonemap(self._hdr_interior_ptr(), s.w, s.h, s.ew, self.avg, self.ldr, s.w)
 
-    def render(self):
-        """One frame: every per-frame dispatch of the reference, in the frame graph's order."""
+    def render(self, shade_events=None):
+        """One frame: every per-frame dispatch of the reference, in the frame graph's order.
+        shade_events: optional list; a (start, end) pair of torch events bracketing the shade launch is appended."""
         self.clustered()
         if self.sky is not None:
             self.skybox()
-        self.shade()
+        if shade_events is None:
+            self.shade()
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.shade()
+            e1.record()
+            shade_events.append((e0, e1))
         self.bloom_histogram()
         if self.allreduce is not None:
             self.allreduce(self.hist)
