@@ -179,14 +179,16 @@ def _shade_on_gpu(ctx, g, tile, gb, lut, env, env_size, env_mips, clusters_np, l
     return to_np_half(hdr)
 
 
-def _check_shade(got, want, want_f32, stencil, what):
+def _check_shade(got, want, want_f32, stencil, what, hard_ulp=64):
     on = stencil > 0
     scale = np.abs(want_f32[on][:, :3]).max()
     err = np.abs(got.astype(np.float32) - want.astype(np.float32))[on][:, :3]
     # the kernel only exposes the fp16 target: one fp16 ulp of the largest value (scale * 2^-10) is the
     # storage granularity, the 1e-4 relative L-inf bound of SURVEY 8c sits on top of it
     assert err.max() <= 1e-4 * scale + scale * 2.0 ** -10, f"{what}: L-inf {err.max()} vs scale {scale}"
-    assert_half_close(got[on], want[on], 2, what, frac_over=1e-3, hard_ulp=64)
+    # hard_ulp bounds the RELATIVE error of every channel; on a million-texel band a near-black channel (absolute error
+    # still inside the L-inf bound above) can exceed it, so the full-size tests pass None
+    assert_half_close(got[on], want[on], 2, what, frac_over=1e-3, hard_ulp=hard_ulp)
     assert np.all(got[on][:, 3] == 1.0)
 
 
@@ -594,3 +596,56 @@ def test_clustered_single_launch_equals_build_then_cull(ctx, ibl, n_lights):
     for k in range(32):
         used = ca["NumLights"] > k
         assert np.array_equal(ca["LightIndex"][used, k], cb["LightIndex"][used, k])
+
+
+@pytest.mark.gpu
+def test_frame_4k_256_lights_full_size_properties_tiles_and_oracle_band(ctx, orc, ibl):
+    """BASELINE cfg4 size (3840x2160, 256 clustered lights + IBL) through the frame's own entry points (fused bloom,
+    histogram in the bloom tail): an oracle comparison on a 64-row band of the shade, size-independent properties of the
+    whole frame, and the cfg5 construction at full tile size — the frame cut into two 1920x2160 tiles with a 256-px
+    apron reproduces the single-frame interior (HDR to <= 2 fp16 ulp, identical summed histogram up to boundary flips)."""
+    from direct12pbrrenderer_amd.pipeline import DeferredFrame, TileSpec
+    sky, env, lut, sh = ibl
+    W, H = 3840, 2160
+    cam, g, lights, gb, tile = common.shade_scene(W, H, 256, sh, rough_min=48, coverage_mask=False)
+    dlut, denv = dev_half(ctx, lut), dev_half(ctx, env)
+
+    def frame(spec):
+        fr = DeferredFrame(ctx, spec, g, lights, dlut, lut.shape[0], denv, common.ENV_SIZE, common.ENV_MIPS)
+        fr.upload_gbuffer({k: np.ascontiguousarray(v[spec.ey0:spec.ey1, spec.ex0:spec.ex1]) for k, v in gb.items()})
+        fr.set_prev_luminance(0.18)
+        return fr
+
+    full = frame(TileSpec(0, 0, W, H, W, H, 0))
+    full.clustered()
+    full.shade()
+    shaded = to_np_half(full.hdr).copy()
+    assert np.isfinite(shaded.astype(np.float32)).all()
+    y0, rows = 1040, 64
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    band = {k: np.ascontiguousarray(v[y0:y0 + rows]) for k, v in gb.items()}
+    want, want_f32 = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "4K band", hard_ulp=None)
+    full.bloom_histogram()
+    hist_full = full.hist.cpu().numpy().view(np.uint32).copy()
+    assert hist_full.sum() == W * H
+    full.average()
+    full.tonemap()
+    hdr_full = to_np_half(full.hdr)
+    assert np.all(hdr_full.astype(np.float32)[..., :3] >= shaded.astype(np.float32)[..., :3] - 1e-3)   # bloom only adds light
+    assert np.all(full.ldr_numpy() >> 24 == 255)
+    # two tiles + apron
+    hist_sum = np.zeros(256, np.int64)
+    for x0 in (0, 1920):
+        spec = TileSpec(x0, 0, 1920, H, W, H, 256)
+        assert (spec.ew, spec.eh) == (1920 + 256, H)
+        t = frame(spec)
+        t.clustered()
+        t.shade()
+        t.bloom_histogram()
+        hist_sum += t.hist.cpu().numpy().view(np.uint32)
+        got = to_np_half(t.hdr)[:, spec.ix:spec.ix + 1920]
+        d = common.half_ulp_diff(got[..., :3], hdr_full[:, x0:x0 + 1920, :3])
+        assert d.max() <= 2, (x0, d.max())
+    assert hist_sum.sum() == W * H and np.abs(hist_sum - hist_full.astype(np.int64)).sum() <= 64
