@@ -212,12 +212,21 @@ __global__ __launch_bounds__(256) void k_sh9_partial(const float* __restrict__ s
     }
 }
 
-__global__ __launch_bounds__(64) void k_sh9_finish(const float* __restrict__ partial, int nblocks, float* __restrict__ out_pack) {
+// 27 coefficients x 8 interleaved fp64 partial sums (rows j, j+8, ...), combined in a fixed tree: deterministic, and
+// eight times shorter than one serial chain of dependent loads per coefficient
+__global__ __launch_bounds__(256) void k_sh9_finish(const float* __restrict__ partial, int nblocks, float* __restrict__ out_pack) {
     __shared__ float c[27];
+    __shared__ double part[8][27];
     const int t = threadIdx.x;
-    if (t < 27) {
+    if (t < 216) {
+        const int coef = t % 27, j = t / 27;
         double s = 0.0;
-        for (int b = 0; b < nblocks; b++) s += (double)partial[(size_t)b * 27 + t];
+        for (int b = j; b < nblocks; b += 8) s += (double)partial[(size_t)b * 27 + coef];
+        part[j][coef] = s;
+    }
+    __syncthreads();
+    if (t < 27) {
+        const double s = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) + ((part[4][t] + part[5][t]) + (part[6][t] + part[7][t]));
         const int n = t % 9;
         const int l = n == 0 ? 0 : (n < 4 ? 1 : 2);
         // SH.cpp:140-151: c = InvPI * K * A * L, then * basis constant (SH.cpp:204-209)
@@ -306,7 +315,7 @@ pbr_status pbr_sh9_project(pbr_ctx* ctx, const pbr_cube_f32* sky, float* out_pac
     hipLaunchKernelGGL(k_sh9_partial, dim3(blocks), dim3(256), 0, ctx->stream, sky->data, sky->size, partial);
     pbr_status r = launched(ctx, "k_sh9_partial");
     if (r) return r;
-    hipLaunchKernelGGL(k_sh9_finish, dim3(1), dim3(64), 0, ctx->stream, partial, blocks, out_pack);
+    hipLaunchKernelGGL(k_sh9_finish, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, out_pack);
     return launched(ctx, "k_sh9_finish");
 }
 
