@@ -85,10 +85,9 @@ __global__ __launch_bounds__(256) void k_cube_downsample(const float* __restrict
 // One launch per output mip.  grid ceil(6*s*s/256), block 256, one thread per output texel.
 // LDS table per block: tangent-space h_i (x,y,z) and the source LOD of sample i (with N = V the
 // pdf — hence the LOD — depends only on i and the roughness: pdf = D(h.z)*h.z / (4 h.z + 1e-4)).
-__global__ __launch_bounds__(256) void k_prefilter_env(const float* __restrict__ sky, uint32_t sky_size, uint32_t sky_mips,
-                                                         uint32_t size, uint32_t s, float roughness,
-                                                         pbr_half* __restrict__ out) {
-    __shared__ float4 tab[PBR_SAMPLE_COUNT];
+__device__ __forceinline__ void prefilter_block(float4* tab, const float* __restrict__ sky, uint32_t sky_size, uint32_t sky_mips,
+                                                uint32_t size, uint32_t s, float roughness, pbr_half* __restrict__ out,
+                                                uint32_t block_in_mip) {
     for (uint32_t i = threadIdx.x; i < PBR_SAMPLE_COUNT; i += 256) {
         float xi_x = (float)i / (float)PBR_SAMPLE_COUNT;
         float xi_y = radical_inverse_vdc(i);
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(256) void k_prefilter_env(const float* __restrict__
     }
     __syncthreads();
     const size_t n = (size_t)6 * s * s;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t t = (size_t)block_in_mip * 256 + threadIdx.x;
     if (t >= n) return;
     const uint32_t x = (uint32_t)(t % s), y = (uint32_t)((t / s) % s), face = (uint32_t)(t / ((size_t)s * s));
     const float u = (float)x / (float)s, v = (float)y / (float)s;   // texel corner (Q8)
@@ -150,6 +149,33 @@ __global__ __launch_bounds__(256) void k_prefilter_env(const float* __restrict__
     }
     const float inv = 1.0f / wsum;   // wsum == 0 -> NaN like the reference's 0/0
     store_h4(out + 4 * t, f4(cr * inv, cg * inv, cb * inv, 1.0f));
+}
+
+// one output mip (one dispatch of PreFilterEnvMapPass::Execute)
+__global__ __launch_bounds__(256) void k_prefilter_env(const float* __restrict__ sky, uint32_t sky_size, uint32_t sky_mips,
+                                                         uint32_t size, uint32_t s, float roughness,
+                                                         pbr_half* __restrict__ out) {
+    __shared__ float4 tab[PBR_SAMPLE_COUNT];
+    prefilter_block(tab, sky, sky_size, sky_mips, size, s, roughness, out, blockIdx.x);
+}
+
+// All mips in ONE launch.  A thread walks its 1 024 samples one after the other (the reference's running sum), so a
+// dispatch lasts as long as that serial chain whatever the mip's size — five dispatches in a row cost five chains
+// with a mostly idle chip (mip 4 is 96 waves).  Run together the mips overlap: blocks are ordered mip 1, 2, ..,
+// mips-1, then mip 0 (roughness 0: one fetch per texel) so the long chains start first.  Same arithmetic per texel.
+__global__ __launch_bounds__(256) void k_prefilter_env_all(const float* __restrict__ sky, uint32_t sky_size, uint32_t sky_mips,
+                                                             uint32_t size, uint32_t mips, pbr_half* __restrict__ out) {
+    __shared__ float4 tab[PBR_SAMPLE_COUNT];
+    uint32_t b = blockIdx.x, mip = 0;
+    for (uint32_t k = 0; k < mips; k++) {
+        const uint32_t m = (k + 1 < mips) ? k + 1 : 0;   // order 1, 2, .., mips-1, 0
+        const uint32_t sm = size >> m;
+        const uint32_t nb = (uint32_t)(((size_t)6 * sm * sm + 255) / 256);
+        if (b < nb) { mip = m; break; }
+        b -= nb;
+    }
+    const float roughness = mips > 1 ? (float)mip / (float)(mips - 1) : 0.0f;   // DeferredPipeline.cpp:99
+    prefilter_block(tab, sky, sky_size, sky_mips, size, size >> mip, roughness, out + 4 * cube_mip_offset(size, mip), b);
 }
 
 // ============================================================================ SH9 (a5)
@@ -295,12 +321,13 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, out != nullptr, "pbr_prefilter_env: null pointer");
     PBR_REQUIRE(ctx, size >= 1 && mips >= 1 && mips <= 16 && (size >> (mips - 1)) >= 1, "pbr_prefilter_env: bad output size/mips");
-    for (uint32_t m = 0; m < mips; m++) {
-        const float roughness = mips > 1 ? (float)m / (float)(mips - 1) : 0.0f;   // DeferredPipeline.cpp:99
-        pbr_status r = pbr_prefilter_env_mip(ctx, sky, size, m, roughness, out + 4 * cube_mip_offset(size, m));
-        if (r) return r;
-    }
-    return PBR_OK;
+    PBR_REQUIRE(ctx, sky && sky->data && sky->size >= 1 && sky->mips >= 1 && (sky->size >> (sky->mips - 1)) >= 1, "pbr_prefilter_env: bad sky cube");
+    PBR_REQUIRE(ctx, size <= 8192, "pbr_prefilter_env: bad output size/mips");
+    size_t blocks = 0;
+    for (uint32_t m = 0; m < mips; m++) blocks += ((size_t)6 * (size >> m) * (size >> m) + 255) / 256;
+    PBR_REQUIRE(ctx, blocks <= 0x7FFFFFFFull, "pbr_prefilter_env: cube too large");
+    hipLaunchKernelGGL(k_prefilter_env_all, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sky->data, sky->size, sky->mips, size, mips, out);
+    return launched(ctx, "k_prefilter_env_all");
 }
 
 pbr_status pbr_sh9_project(pbr_ctx* ctx, const pbr_cube_f32* sky, float* out_pack) {
