@@ -7,15 +7,13 @@ stages bit-exact (the bloom TU is built -ffp-contract=off in the oracle's operat
 histogram exact up to boundary flips <= 1e-5 N; average luminance exact given an equal histogram;
 RGBA8 <= 1 LSB; SH <= 1e-5 relative.
 """
-import ctypes as C
-
 import numpy as np
 import pytest
 import torch
 
 import common
 from direct12pbrrenderer_amd import scene, synth
-from direct12pbrrenderer_amd.structs import (CLUSTER_DTYPE, NUM_CLUSTERS, Tile, bloom_level_offset, cube_mip_offset)
+from direct12pbrrenderer_amd.structs import CLUSTER_DTYPE, Tile, bloom_level_offset, cube_mip_offset
 
 pytestmark = pytest.mark.gpu
 

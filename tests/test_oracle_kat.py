@@ -7,8 +7,7 @@ import numpy as np
 import pytest
 
 from direct12pbrrenderer_amd import scene, synth
-from direct12pbrrenderer_amd.structs import (CLUSTER_X, CLUSTER_Y, CLUSTER_Z, INV_LOG_LUMINANCE_RANGE,
-                                             MIN_LOG_LUMINANCE, ShPack)
+from direct12pbrrenderer_amd.structs import CLUSTER_X, CLUSTER_Y, CLUSTER_Z, INV_LOG_LUMINANCE_RANGE, MIN_LOG_LUMINANCE
 
 
 def test_radical_inverse(orc):

@@ -3,7 +3,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
 
 import bench  # noqa: E402
 from direct12pbrrenderer_amd import synth  # noqa: E402

@@ -1,6 +1,6 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
 from direct12pbrrenderer_amd import scene, synth
 from direct12pbrrenderer_amd.api import PbrContext
 from direct12pbrrenderer_amd.pipeline import DeferredFrame, tile_for_rank
