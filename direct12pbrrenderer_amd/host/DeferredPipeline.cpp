@@ -85,6 +85,8 @@ GBufferPass::GBufferPass(RenderSize s) {
 
 void GBufferPass::Execute(FGContext* context) {
     GBufferSource& src = context->Scene->GBuffer();
+    if (!src.Dirty) return;   // the planes a rasterizer would have left in device memory are still there
+    src.Dirty = false;
     auto* a = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::GBufferA));
     if (src.Width != a->Width() || src.Height != a->Height()) throw HipException("GBufferPass: G-buffer source size != render size");
     const size_t n = (size_t)src.Width * src.Height;
@@ -178,6 +180,10 @@ void ClusteredPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:208-
     mClusteredCompute.SetConstantBuffer(ClusteredShaderConstant{i});
     mClusteredCulling.SetConstantBuffer(ClusteredShaderConstant{i});
     sw_point_light->Commit(lights.data(), lights.size() * sizeof(pbr_light));
+    if (context->CommandList->FusedPasses()) {
+        context->CommandList->Clustered(sw_cluster, sw_point_light, i);
+        return;
+    }
     context->CommandList->Dispatch(&mClusteredCompute, 1, 1, 1);
     context->CommandList->Dispatch(&mClusteredCulling, 1, 1, 1);
 }
@@ -250,6 +256,10 @@ void BloomPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:400-570,
     auto* temp_tex = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::BloomTempTexture));
     HipCommandList* cmd = context->CommandList;
     auto texel = [](uint32 w, uint32 h) { return Vector2{1.0f / (float)w, 1.0f / (float)h}; };
+    if (cmd->FusedPasses()) {   // the sixteen dispatches below as one call: same HDR result
+        cmd->Bloom(original_tex, mip_chain, temp_tex, 1.0f, 0.5f);
+        return;
+    }
 
     mPrefilter.SetConstantBuffer(BloomPrefilterConstant{texel(original_tex->Width() >> 1, original_tex->Height() >> 1), 1.0f, 0.5f});
     mPrefilter.SetTexture("InputTexture", original_tex);

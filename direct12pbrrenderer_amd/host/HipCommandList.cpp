@@ -254,6 +254,22 @@ void HipCommandList::DrawScreen(ShadingState* s) {
     }
 }
 
+void HipCommandList::Clustered(DeviceStructuredBuffer* clusters, DeviceStructuredBuffer* point_lights, int32 num_lights) {
+    if (!clusters || !point_lights) throw HipException("Clustered: null buffer");
+    mDispatchCount++;
+    mNumLights = num_lights;
+    Check(pbr_clustered(mCtx, &mGlobal, (const pbr_light*)point_lights->DevicePtr(), num_lights, (pbr_cluster*)clusters->DevicePtr()), "pbr_clustered");
+}
+
+void HipCommandList::Bloom(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, DeviceTexture2D* temp, float threshold, float knee) {
+    if (!hdr || !mip_chain || !temp) throw HipException("Bloom: null texture");
+    if (mip_chain->Width() != hdr->Width() || mip_chain->Height() != hdr->Height() || temp->Width() != hdr->Width() || temp->Height() != hdr->Height())
+        throw HipException("Bloom: the mip chains must have the HDR target's size");
+    mDispatchCount++;
+    Check(pbr_bloom(mCtx, (pbr_half*)hdr->DevicePtr(), hdr->Width(), hdr->Height(), hdr->Width(), (pbr_half*)mip_chain->DevicePtr(),
+                    (pbr_half*)temp->DevicePtr(), threshold, knee), "pbr_bloom");
+}
+
 void HipCommandList::DrawMesh(ShadingState* s) {   // D3D12CommandList.cpp DrawMesh; SkyboxPass::Execute :59-75
     if (!s || s->IsCompute()) throw HipException("DrawMesh: graphics shading state expected");
     const std::string_view f = s->File();

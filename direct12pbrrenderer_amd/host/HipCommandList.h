@@ -44,6 +44,16 @@ public:
                        DeviceTexture2D* a, DeviceTexture2D* b, DeviceTexture2D* c);
     void Present(DeviceTexture2D* tex) { mPresented = tex; }
 
+    // Pass-level entry points (not in the reference): a pass whose Execute body is a fixed sequence of dispatches can
+    // hand the whole sequence over in one call — same results, fewer launches, intermediates kept on chip.  Passes use
+    // them when FusedPasses() is on; off (default) every reference dispatch is issued one by one.
+    void SetFusedPasses(bool on) { mFusedPasses = on; }
+    bool FusedPasses() const { return mFusedPasses; }
+    // ClusteredPass::Execute's two dispatches (pbr_clustered)
+    void Clustered(DeviceStructuredBuffer* clusters, DeviceStructuredBuffer* point_lights, int32 num_lights);
+    // BloomPass::Execute's sixteen dispatches (pbr_bloom); mip_chain / temp are scratch afterwards
+    void Bloom(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, DeviceTexture2D* temp, float threshold, float knee);
+
     pbr_ctx* Context() const { return mCtx; }
     uint32 DispatchCount() const { return mDispatchCount; }
     DeviceTexture2D* Presented() const { return mPresented; }
@@ -61,6 +71,7 @@ private:
     DeviceTexture2D* mPresented = nullptr;
     DeviceTexture2D* mRenderTarget = nullptr;
     DeviceTexture2D* mDepthStencil = nullptr;
+    bool mFusedPasses = false;
     pbr_tile mTile{};
     // padded copies of prefiltered env chains (pbr_env_pad), keyed by the plain texture; rebuilt after
     // env_map_gen.hlsl rewrites the texture

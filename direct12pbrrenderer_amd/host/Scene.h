@@ -100,6 +100,7 @@ struct GBufferSource {
     std::vector<float> Depth;
     std::vector<uint8_t> Stencil;
     bool HasMaterials() const { return !M0.empty(); }
+    bool Dirty = true;   // host copy changed since GBufferPass last uploaded / encoded it
 };
 
 class Scene {

@@ -2,6 +2,7 @@
 #include "pbr_host.h"
 #include "HdrImage.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -115,6 +116,7 @@ int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, con
         g.Width = r->width;
         g.Height = r->height;
         g.M0.clear(); g.M1.clear(); g.M2.clear();
+        g.Dirty = true;
         g.A.assign(A, A + n);
         g.B.assign(B, B + n);
         g.C.assign(C, C + n);
@@ -130,6 +132,7 @@ int pbrh_set_materials(pbrh_renderer* r, const float* m0, const float* m1, const
         g.Width = r->width;
         g.Height = r->height;
         g.A.clear(); g.B.clear(); g.C.clear();
+        g.Dirty = true;
         g.M0.assign(m0, m0 + 4 * n);
         g.M1.assign(m1, m1 + 4 * n);
         g.M2.assign(m2, m2 + 4 * n);
@@ -146,6 +149,24 @@ int pbrh_render(pbrh_renderer* r, float dt) {
     return guarded(r, [&] {
         r->time += dt;
         r->scheduler->ExecutePipeline(r->scene.get(), r->camera.get(), dt, r->time);
+    });
+}
+
+int pbrh_set_fused(pbrh_renderer* r, int on) {
+    return guarded(r, [&] { r->scheduler->CommandList()->SetFusedPasses(on != 0); });
+}
+
+// n frames through RenderScheduler::ExecutePipeline (each ends with the reference's per-frame fence wait); average
+// wall time per frame in milliseconds
+int pbrh_render_n(pbrh_renderer* r, int n, float dt, double* ms_per_frame) {
+    return guarded(r, [&] {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; i++) {
+            r->time += dt;
+            r->scheduler->ExecutePipeline(r->scene.get(), r->camera.get(), dt, r->time);
+        }
+        const auto t1 = std::chrono::steady_clock::now();
+        if (ms_per_frame) *ms_per_frame = std::chrono::duration<double, std::milli>(t1 - t0).count() / (n > 0 ? n : 1);
     });
 }
 

@@ -27,6 +27,11 @@ int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, con
  * pbr_gbuffer_encode in pbr_hip.h); GBufferPass encodes them on the GPU */
 int pbrh_set_materials(pbrh_renderer* r, const float* m0, const float* m1, const float* m2, const float* depth, const uint8_t* stencil);
 int pbrh_set_initial_luminance(pbrh_renderer* r, float v);
+/* on: ClusteredPass and BloomPass hand their fixed dispatch sequences over as one call each (pbr_clustered, pbr_bloom);
+ * off (default): every reference dispatch is issued one by one.  Same results. */
+int pbrh_set_fused(pbrh_renderer* r, int on);
+/* n frames; *ms_per_frame = average wall time per frame (every frame ends with the per-frame fence wait) */
+int pbrh_render_n(pbrh_renderer* r, int n, float delta_time, double* ms_per_frame);
 /* one frame through RenderScheduler::ExecutePipeline; blocks until the GPU is done */
 int pbrh_render(pbrh_renderer* r, float delta_time);
 /* "PreFilterEnvMap>PrecomputeBRDF>..." */
