@@ -1,4 +1,4 @@
-"""world_size-2 rehearsal of the multi-GPU path on CPU (gloo): tiling with aprons + the 256-bin
+"""world_size-2 and -3 rehearsal of the multi-GPU path on CPU (gloo): tiling with aprons + the 256-bin
 histogram all-reduce.  The per-rank arithmetic is the ORACLE here (no GPU in this
 container); what is under test is the host-side sharding logic that bench.py uses on the GPUs:
 tile_for_rank / TileSpec, global-pixel addressing, interior histogram, all-reduce, full-frame
@@ -62,19 +62,22 @@ def _worker(rank, world, port, outdir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_tiling_matches_single_frame(orc, ibl):
-    from direct12pbrrenderer_amd.pipeline import TileSpec
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])      # 3: the middle rank carries an apron on both sides (the N >= 3 layout of bench.py)
+def test_tiling_matches_single_frame(orc, ibl, world):
+    from direct12pbrrenderer_amd.pipeline import TileSpec, tile_for_rank
+    if world == 3:
+        mid = tile_for_rank(1, 3, TILE_W, TILE_H, APRON)
+        assert (mid.ex0, mid.ew, mid.ix) == (TILE_W - APRON, TILE_W + 2 * APRON, APRON)
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
         ranks = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
-    W, H = TILE_W * 2, TILE_H
+    W, H = TILE_W * world, TILE_H
     g, full, hist_full = _render_rank(orc, TileSpec(0, 0, W, H, W, H, 0), ibl)
     avg_full = orc.lum_average(hist_full.copy(), W * H, float(g.DeltaTime), 0.18)
     # every rank holds the same all-reduced histogram = sum of the per-rank ones, and the same average
-    assert np.array_equal(ranks[0]["hist_all"], ranks[1]["hist_all"])
-    assert np.array_equal(ranks[0]["hist_all"], ranks[0]["hist"] + ranks[1]["hist"])
-    assert ranks[0]["avg"] == ranks[1]["avg"]
+    for r in ranks[1:]:
+        assert np.array_equal(ranks[0]["hist_all"], r["hist_all"]) and ranks[0]["avg"] == r["avg"]
+    assert np.array_equal(ranks[0]["hist_all"], sum(r["hist"] for r in ranks))
     assert ranks[0]["hist_all"].sum() == W * H
     # apron sufficiency: interiors equal the single-frame result (fp32 uv rounding may flip an fp16 ulp)
     for r in ranks:
