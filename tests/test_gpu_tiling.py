@@ -1,4 +1,4 @@
-"""Tile + apron path on real hardware: two ranks (both on cuda:0 — the test box has one GPU; the
+"""Tile + apron path on real hardware: two and three ranks (all on cuda:0 — the test box has one GPU; the
 collective is gloo on the host copy of the 256-bin histogram) against the single-GPU frame.
 What runs on the GPU is exactly what bench.py runs per rank: DeferredFrame on an apron-extended
 tile with global-pixel addressing, interior histogram, full-frame PixelCount."""
@@ -71,17 +71,17 @@ def _worker(rank, world, port, outdir):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_with_apron_match_single_gpu_frame(ctx, ibl):
+@pytest.mark.parametrize("world", [2, 3])      # 3: the middle rank has a neighbour (and an apron) on both sides
+def test_ranks_with_apron_match_single_gpu_frame(ctx, ibl, world):
     from direct12pbrrenderer_amd.pipeline import TileSpec
-    world = 2
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
         ranks = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
-    W, H = TILE_W * 2, TILE_H
+    W, H = TILE_W * world, TILE_H
     fr = _frame(ctx, TileSpec(0, 0, W, H, W, H, 0), _ibl_dev(ctx, ibl), ibl[3])
     full_hdr = fr.hdr_interior()
     full_ldr = fr.ldr_numpy()
-    assert ranks[0]["avg"][0] == ranks[1]["avg"][0]                         # bit-identical exposure on every rank
+    assert all(r["avg"][0] == ranks[0]["avg"][0] for r in ranks)            # bit-identical exposure on every rank
     assert ranks[0]["avg"][0] == pytest.approx(float(fr.avg.cpu()[0]), rel=1e-6)
     for r in ranks:
         x0, y0, w, h = r["rect"]
