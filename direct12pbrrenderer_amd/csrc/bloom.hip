@@ -7,7 +7,13 @@
 // order (fused multiply-adds only where the oracle writes fmaf: sampler lerps and the blur's
 // multiply-accumulate), so every stage is bit-identical to the CPU oracle on the same input.
 //
-// Layout / mapping for MI355X:
+// Two sets of kernels, bit-identical to each other:
+//  * the STAGED kernels below, one per reference dispatch (pbr_bloom_prefilter, pbr_blur_h, pbr_blur_v,
+//    pbr_bloom_upsample_add, pbr_bloom_merge; any image size) — what the host pass graph issues one by one;
+//  * the FUSED kernels further down (k_bloom_prefilter_2x, k_blur_hv), which pbr_bloom / pbr_bloom_histogram use on
+//    an exact 2x pyramid: shared prefilter samples, H + V pass of a level in one kernel, merge + histogram in the last.
+//
+// Layout / mapping of the staged kernels for MI355X:
 //  * H passes keep the reference's 256-texel row groups (one 64-lane wave = 64 consecutive
 //    texels = one 512-byte half4 segment), the bilinear-sampled row is cached in LDS as float4
 //    (264 entries, ds_read_b128, conflict-free) exactly like blur.hlsli's Cache[].
