@@ -648,35 +648,38 @@ static pbr_status bloom_impl(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h
     auto H = [&](uint32_t l) { return h >> l; };
     pbr_status r;
     if ((r = pbr_bloom_prefilter(ctx, hdr, w, h, pitch, a(1), threshold, knee))) return r;
-    bool exact = !force_staged();
-    for (uint32_t l = 0; l + 1 < PBR_BLOOM_MIPS; l++) exact = exact && exact_half(W(l)) && exact_half(H(l));
-    if (exact) {
-        // exact 2x pyramid: H+V of every level fused (8 launches instead of 16 dispatches); the H results (chain B
-        // of the staged schedule) are never written.  Up-levels go to chain B so a block never overwrites what its
-        // neighbours still read; chain contents after the call are scratch.
-        for (uint32_t i = 0; i < PBR_BLOOM_STEP; i++) {
-            const uint32_t up = i + 1, lo = i + 2;
+    // Per level pair: where level l+1 is exactly half of level l (and both fit the fast path's size limit) the H and V
+    // pass run as one kernel and the H result (chain B of the reference schedule) is never written; elsewhere the two
+    // staged kernels run.  1920x1080, for instance, is exact down to 240x135 and staged for 135 -> 67.  Fused up-levels
+    // write chain B (a block must not overwrite what its neighbours still read), so `res` tracks where the finished
+    // level below lives.  Chain contents after the call are scratch.
+    auto exact = [&](uint32_t l) { return !force_staged() && exact_half(W(l)) && exact_half(H(l)); };
+    for (uint32_t i = 0; i < PBR_BLOOM_STEP; i++) {   // downsample
+        const uint32_t up = i + 1, lo = i + 2;
+        if (exact(up)) {
             if ((r = launch_hv<M_DOWN, false, 0>(ctx, a(up), W(up), H(up), nullptr, a(lo), W(lo), H(lo), W(lo), nullptr, 0.0f, 0.0f, nullptr))) return r;
+        } else {
+            if ((r = pbr_blur_h(ctx, a(up), W(up), H(up), b(lo), W(lo), H(lo)))) return r;
+            if ((r = pbr_blur_v(ctx, b(lo), W(lo), H(lo), a(lo), W(lo), H(lo)))) return r;
         }
-        for (int i = PBR_BLOOM_STEP - 1; i >= 0; i--) {
-            const uint32_t up = (uint32_t)i + 1;
-            const pbr_half* lower = (up + 1 == PBR_BLOOM_MIPS - 1) ? a(up + 1) : b(up + 1);
-            if ((r = launch_hv<M_UP, true, 0>(ctx, lower, W(up + 1), H(up + 1), a(up), b(up), W(up), H(up), W(up), nullptr, 0.0f, 0.0f, nullptr))) return r;
+    }
+    const pbr_half* res = a(PBR_BLOOM_MIPS - 1);
+    for (int i = PBR_BLOOM_STEP - 1; i >= 0; i--) {   // upsample: V(H(lower) + H(upper))
+        const uint32_t up = (uint32_t)i + 1;
+        if (exact(up)) {
+            if ((r = launch_hv<M_UP, true, 0>(ctx, res, W(up + 1), H(up + 1), a(up), b(up), W(up), H(up), W(up), nullptr, 0.0f, 0.0f, nullptr))) return r;
+            res = b(up);
+        } else {
+            if ((r = pbr_bloom_upsample_add(ctx, a(up), W(up), H(up), res, W(up + 1), H(up + 1), b(up)))) return r;
+            if ((r = pbr_blur_v(ctx, b(up), W(up), H(up), a(up), W(up), H(up)))) return r;
+            res = a(up);
         }
-        if (hist256) return launch_hv<M_UP, false, 2>(ctx, b(1), W(1), H(1), nullptr, hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
-        return launch_hv<M_UP, false, 1>(ctx, b(1), W(1), H(1), nullptr, hdr, w, h, pitch, nullptr, 0.0f, 0.0f, nullptr);
     }
-    for (uint32_t i = 0; i < PBR_BLOOM_STEP; i++) {
-        uint32_t up = i + 1, lo = i + 2;
-        if ((r = pbr_blur_h(ctx, a(up), W(up), H(up), b(lo), W(lo), H(lo)))) return r;
-        if ((r = pbr_blur_v(ctx, b(lo), W(lo), H(lo), a(lo), W(lo), H(lo)))) return r;
+    if (exact(0)) {   // H + V + merge (+ histogram) in one kernel
+        if (hist256) return launch_hv<M_UP, false, 2>(ctx, res, W(1), H(1), nullptr, hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
+        return launch_hv<M_UP, false, 1>(ctx, res, W(1), H(1), nullptr, hdr, w, h, pitch, nullptr, 0.0f, 0.0f, nullptr);
     }
-    for (int i = PBR_BLOOM_STEP - 1; i >= 0; i--) {
-        uint32_t up = (uint32_t)i + 1;
-        if ((r = pbr_bloom_upsample_add(ctx, a(up), W(up), H(up), a(up + 1), W(up + 1), H(up + 1), b(up)))) return r;
-        if ((r = pbr_blur_v(ctx, b(up), W(up), H(up), a(up), W(up), H(up)))) return r;
-    }
-    if ((r = pbr_blur_h(ctx, a(1), W(1), H(1), b(0), w, h))) return r;
+    if ((r = pbr_blur_h(ctx, res, W(1), H(1), b(0), w, h))) return r;
     // A0 = V(B0); S += A0 [; histogram(S)] in one pass — chain A level 0 is not materialised
     return bloom_final(ctx, b(0), hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
 }

@@ -246,10 +246,10 @@ pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pb
                            uint32_t w, uint32_t h);
 /* BloomPass::Execute (DeferredPipeline.cpp:400-570), all 16 dispatches: hdr is bit-identical to the sequence of
  * stage calls above.  chain_a / chain_b: pbr_bloom_chain_texels(w,h) half4 texels each (BloomMipchain /
- * BloomTempTexture) — SCRATCH: their contents after the call are unspecified.  (When every level is exactly half
- * the one above and the image is at most 8192 wide/high, the H and V pass of a level run as one kernel and the
- * H results are never written; otherwise the staged kernels run and only level 0 of chain_a — the V blur the
- * merge consumes — stays unwritten.) */
+ * BloomTempTexture) — SCRATCH: their contents after the call are unspecified.  (Wherever a level is exactly half
+ * the one above and at most 8192 wide/high, the H and V pass of that level pair run as one kernel and the H result
+ * is never written; elsewhere the staged kernels run.  Level 0 of chain_a — the V blur the merge consumes — is
+ * never written.) */
 pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                      pbr_half* chain_a, pbr_half* chain_b, float threshold, float knee);
 

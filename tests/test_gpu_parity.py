@@ -263,27 +263,42 @@ def test_blur_group_edges_wide_and_tall(ctx, orc):
 
 
 def test_bloom_chain_vs_golden_every_mip(ctx, orc, golden):
-    img = synth.hdr_noise_image(128, 72)
+    """The reference's 16 dispatches issued one by one through the stage-level entry points (what the host pass graph
+    does): every level of both chains equals the golden chain; pbr_bloom (which fuses level pairs where it can and
+    treats the chains as scratch) gives the same HDR."""
+    W, H = 128, 72
+    img = synth.hdr_noise_image(W, H)
     hdr = dev_half(ctx, img)
-    a, b = ctx.alloc_bloom_chain(128, 72), ctx.alloc_bloom_chain(128, 72)
-    ctx.bloom(hdr, 128, 72, 128, a, b)
+    a, b = ctx.alloc_bloom_chain(W, H), ctx.alloc_bloom_chain(W, H)
+
+    def lvl(t, l):   # device view of level l of a chain
+        off = bloom_level_offset(W, H, l)
+        return t.view(-1, 4)[off: off + (W >> l) * (H >> l)]
+
+    dims = [(W >> l, H >> l) for l in range(5)]
+    ctx.bloom_prefilter(hdr, W, H, W, lvl(a, 1))
+    for i in range(3):                                   # downsample: H into chain B, V back into chain A
+        up, lo = i + 1, i + 2
+        ctx.blur_h(lvl(a, up), *dims[up], lvl(b, lo), *dims[lo])
+        ctx.blur_v(lvl(b, lo), *dims[lo], lvl(a, lo), *dims[lo])
+    for i in (2, 1, 0):                                  # upsample: V(H(lower) + H(upper))
+        up = i + 1
+        ctx.bloom_upsample_add(lvl(a, up), *dims[up], lvl(a, up + 1), *dims[up + 1], lvl(b, up))
+        ctx.blur_v(lvl(b, up), *dims[up], lvl(a, up), *dims[up])
+    ctx.blur_h(lvl(a, 1), *dims[1], lvl(b, 0), W, H)
+    ctx.blur_v(lvl(b, 0), W, H, lvl(a, 0), W, H)
+    ctx.bloom_merge(hdr, W, lvl(a, 0), W, H)
     ga, gb_ = to_np_half(a), to_np_half(b)
     for l in range(5):
-        la, lb = _levels(ga, 128, 72)[l], _levels(gb_, 128, 72)[l]
-        wa, wb = _levels(golden["bloom_chain_a"], 128, 72)[l], _levels(golden["bloom_chain_b"], 128, 72)[l]
-        # (128x72 is not an exact 2x pyramid — 9 >> 1 = 4 — so pbr_bloom takes the staged kernels here and the chains
-        #  hold the staged intermediates; in general they are scratch, see pbr_hip.h)
-        if l > 0:   # the staged tail fuses V(B0) + merge: A[0] is an intermediate it never materialises
-            assert np.array_equal(la.view(np.uint16), wa.view(np.uint16)), f"chain A level {l}"
+        la, lb = _levels(ga, W, H)[l], _levels(gb_, W, H)[l]
+        wa, wb = _levels(golden["bloom_chain_a"], W, H)[l], _levels(golden["bloom_chain_b"], W, H)[l]
+        assert np.array_equal(la.view(np.uint16), wa.view(np.uint16)), f"chain A level {l}"
         assert np.array_equal(lb.view(np.uint16), wb.view(np.uint16)), f"chain B level {l}"
     assert np.array_equal(to_np_half(hdr).view(np.uint16), golden["bloom_hdr"].view(np.uint16))
-    # the unfused tail (stage calls) produces A[0] and the same HDR
+    # pbr_bloom: 128x72 halves exactly three times (72, 36, 18, 9 | 4): fused kernels for those level pairs, staged ones
+    # for 9 -> 4; same HDR
     hdr2 = dev_half(ctx, img)
-    a0 = ctx.zeros((72, 128, 4), torch.float16)
-    b0 = gb_[: 128 * 72].reshape(72, 128, 4)
-    ctx.blur_v(dev_half(ctx, b0), 128, 72, a0, 128, 72)
-    assert np.array_equal(to_np_half(a0).view(np.uint16), _levels(golden["bloom_chain_a"], 128, 72)[0].view(np.uint16))
-    ctx.bloom_merge(hdr2, 128, a0, 128, 72)
+    ctx.bloom(hdr2, W, H, W, ctx.alloc_bloom_chain(W, H), ctx.alloc_bloom_chain(W, H))
     assert np.array_equal(to_np_half(hdr2).view(np.uint16), golden["bloom_hdr"].view(np.uint16))
 
 
@@ -526,9 +541,11 @@ def test_rgbe_decode_bit_exact(ctx, orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h", [(2048, 64), (1040, 48), (512, 288), (304, 176)])
+@pytest.mark.parametrize("w,h", [(2048, 64), (1040, 48), (512, 288), (304, 176), (320, 180), (480, 270)])
 def test_bloom_fused_exact_pyramid_bit_exact(ctx, orc, w, h):
-    """Exact 2x pyramids take the fused path (shared-sample prefilter; H+V of a level in one kernel with the H
+    """(320x180: heights 180, 90, 45, 22, 11 — exact, exact, NOT exact, exact: fused and staged kernels alternate per
+    level pair; 480x270 = 1080p / 4: heights 270, 135, 67, 33, 16 — only the first pair is exact.)
+    Exact 2x pyramids take the fused path (shared-sample prefilter; H+V of a level in one kernel with the H
     result kept in registers; merge + histogram in the last one): final HDR bit-identical to the oracle's staged
     chain, histogram equal to the stand-alone pass.  Sizes cover 256- and 64-column blocks, ragged widths/heights."""
     img = synth.hdr_noise_image(w, h, seed=w + h)
