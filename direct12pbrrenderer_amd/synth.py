@@ -37,7 +37,7 @@ def _unit(h):
     return h.astype(np.float64) * (1.0 / 4294967296.0)
 
 
-def gbuffer_tile(x0, y0, w, h, full_w, full_h, near=0.1, far=1000.0, rough_min=48, coverage_mask=False):
+def gbuffer_tile(x0, y0, w, h, full_w, full_h, near=0.1, far=1000.0, rough_min=48, coverage_mask=False, cell=1):
     """Returns dict of A,B,C (uint32 [h,w]), depth (float32 [h,w]), stencil (uint8 [h,w]).
 
     albedo rgb u8 uniform; emission 255 with p = 1/128; octahedral normal (u8,u8) uniform (every pair
@@ -45,12 +45,19 @@ def gbuffer_tile(x0, y0, w, h, full_w, full_h, near=0.1, far=1000.0, rough_min=4
     AO uniform (unused by the shade); depth: view-space z log-uniform in [1, 60] mapped to NDC with
     the inverse of ViewSpaceDepth (deferred_shading.hlsl:74-77).
 
+    cell: 1 = the BASELINE workload (every pixel an independent surface sample: the worst case for the IBL gathers and
+    for clustered light lists); > 1 = piecewise-constant surfaces of cell x cell pixels (what rendered geometry looks
+    like to the caches).
+
     rough_min: SURVEY 8d asks for roughness uniform on [0,255] AND for radiance that stays below the
     fp16 maximum; with intensity-10 lights the GGX peak 1/(pi a^4) overflows half for roughness below
     ~0.17, so throughput frames clamp the range to [48,255] (tests that want the full range pass 0).
     """
     ys, xs = np.meshgrid(np.arange(y0, y0 + h, dtype=np.uint64), np.arange(x0, x0 + w, dtype=np.uint64), indexing="ij")
-    idx = (ys * np.uint64(full_w) + xs) & _M32
+    if cell > 1:   # spatially coherent variant: every cell x cell block of pixels shares one surface sample
+        idx = (((ys // np.uint64(cell)) * np.uint64(cell)) * np.uint64(full_w) + (xs // np.uint64(cell)) * np.uint64(cell)) & _M32
+    else:
+        idx = (ys * np.uint64(full_w) + xs) & _M32
     h0 = hash_stream(idx, SEED_GBUFFER, 0)
     h1 = hash_stream(idx, SEED_GBUFFER, 1)
     h2 = hash_stream(idx, SEED_GBUFFER, 2)

@@ -52,12 +52,12 @@ emit(config="cfg3", what="env_pad (padded copy of the prefiltered chain)", ms=ro
 lut, env, sh = bench.build_ibl(ctx)
 
 
-def frame_times(name, spec, n_lights, what):
+def frame_times(name, spec, n_lights, what, cell=1):
     cam = scene.Camera.reference_default(spec.full_w, spec.full_h)
     g = scene.make_global(cam, spec.full_w, spec.full_h, sh_pack=sh, delta_time=1.0 / 60.0)
     lights = synth.reference_scene_light() if n_lights == 1 else synth.lights_in_view_box(n_lights, cam)
     fr = DeferredFrame(ctx, spec, g, lights, lut, 512, env, 512, ENV_MIPS)
-    fr.upload_gbuffer(synth.gbuffer_tile(spec.ex0, spec.ey0, spec.ew, spec.eh, spec.full_w, spec.full_h))
+    fr.upload_gbuffer(synth.gbuffer_tile(spec.ex0, spec.ey0, spec.ew, spec.eh, spec.full_w, spec.full_h, cell=cell))
     fr.set_prev_luminance(0.18)
     fr.render()
     shade = bench.time_stage(fr.shade, 20)
@@ -70,6 +70,8 @@ def frame_times(name, spec, n_lights, what):
 
 frame_times("cfg2", TileSpec(0, 0, 1920, 1080, 1920, 1080, 0), 1, "1920x1080 G-buffer, 1 point light + IBL")
 frame_times("cfg4", TileSpec(0, 0, 3840, 2160, 3840, 2160, 0), 256, "3840x2160 G-buffer, 256 clustered lights + IBL (bench.py headline)")
+frame_times("cfg4-coherent", TileSpec(0, 0, 3840, 2160, 3840, 2160, 0), 256,
+            "3840x2160, 256 clustered lights + IBL, spatially coherent G-buffer (16x16-pixel surface patches) — NOT the BASELINE workload, for reference", cell=16)
 frame_times("cfg5", TileSpec(1920, 0, 1920, 2160, 7680, 4320, 256), 256, "one of 8 ranks of the 7680x4320 frame: 1920x2160 tile + 256-px apron")
 
 # ---- SURVEY 8f "next" rows at the headline size: G-buffer encode (48 B in + 12 B out per pixel) and a full-screen sky
