@@ -541,10 +541,11 @@ def test_rgbe_decode_bit_exact(ctx, orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h", [(2048, 64), (1040, 48), (512, 288), (304, 176), (320, 180), (480, 270)])
+@pytest.mark.parametrize("w,h", [(2048, 64), (1040, 48), (512, 288), (304, 176), (320, 180), (480, 270), (400, 300), (360, 192)])
 def test_bloom_fused_exact_pyramid_bit_exact(ctx, orc, w, h):
     """(320x180: heights 180, 90, 45, 22, 11 — exact, exact, NOT exact, exact: fused and staged kernels alternate per
-    level pair; 480x270 = 1080p / 4: heights 270, 135, 67, 33, 16 — only the first pair is exact.)
+    level pair; 480x270 = 1080p / 4: heights 270, 135, 67, 33, 16 — only the first pair is exact; 400x300: heights 300, 150,
+    75, 37, 18 — two exact pairs then two staged ones; 360x192: the WIDTH stops halving exactly at 45 -> 22.)
     Exact 2x pyramids take the fused path (shared-sample prefilter; H+V of a level in one kernel with the H
     result kept in registers; merge + histogram in the last one): final HDR bit-identical to the oracle's staged
     chain, histogram equal to the stand-alone pass.  Sizes cover 256- and 64-column blocks, ragged widths/heights."""
