@@ -69,6 +69,9 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `make -C direct12pbrrenderer_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback for the HIP path.")
+    # torch first: it brings its own copy of the HIP runtime, and a process that has already loaded the system one
+    # (through this library) cannot create streams on torch's device afterwards (hipStreamCreate fails)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the export is missing
