@@ -20,6 +20,7 @@ REFERENCE_ORDER = "PreFilterEnvMap>PrecomputeBRDF>Clustered>GBuffer>Skybox>Defer
 @pytest.fixture(scope="module")
 def host():
     assert os.path.exists(HOST_LIB), "build with make -C direct12pbrrenderer_amd/host"
+    import torch  # noqa: F401  (before the HIP runtime the library links: see direct12pbrrenderer_amd/_lib.py)
     L = C.CDLL(HOST_LIB)
     L.pbrh_create.restype = C.c_void_p
     L.pbrh_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
