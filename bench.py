@@ -3,17 +3,28 @@
 
 A "step" is one frame of the hot path over one rank's tile: cluster build + cull, deferred shade
 (256 clustered lights + IBL), the bloom chain (16 reference dispatches, 8 fused launches) with the luminance
-histogram in its last kernel (+ RCCL all-reduce when N > 1), average, ACES tone-map — i.e. BASELINE.json configs[3] at N = 1.  Inputs (G-buffer,
-lights, LUT, prefiltered env, SH) are resident in HBM before the timed region.  Weak scaling: each
-rank owns one 3840x2160 tile of an N x 1 tile frame (tiles side by side: short edges shared) and shades a
-256-px apron towards its neighbours so bloom needs no halo exchange; `value` counts interior pixels only.
+histogram in its last kernel (+ RCCL all-reduce when N > 1), average, ACES tone-map — i.e. BASELINE.json configs[3]
+at N = 1.  Inputs (G-buffer, lights, LUT, prefiltered env, SH) are resident in HBM before the timed region.
+
+Multi-GPU (one process per GPU; `--gpus N` from a bare shell starts its own ranks through torch.distributed.run):
+  * default = WEAK scaling of the cfg4 scene: the same camera, lights and cluster grid rendered at a 16:9 frame of
+    N x 8.3 Mpixel, cut into the most square tile grid (2x1, 2x2, 4x2 ...), one 4K-equivalent tile per GPU — per-pixel
+    light lists are identical at every N because the scene is fixed in uv;
+  * `--frame 7680x4320 --layout 2x4` = BASELINE cfg5 (STRONG scaling: 2 rows x 4 cols of 1920x2160 tiles).
+Bloom across tile borders: `--mode halo` (default) shades interior + 4 px and exchanges prefiltered half-res strips
+(pbr_halo_exchange: RCCL send/recv over xGMI); `--mode apron` shades a 256-px apron instead (no data-path collective).
+The only other collective is the 256-bin histogram all-reduce.  `value` counts interior pixels only.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,11 +36,13 @@ sys.path.insert(0, ROOT)
 
 from direct12pbrrenderer_amd import scene, synth  # noqa: E402
 from direct12pbrrenderer_amd.api import PbrContext  # noqa: E402
-from direct12pbrrenderer_amd.pipeline import DeferredFrame, tile_for_rank  # noqa: E402
-from direct12pbrrenderer_amd.structs import ENV_MIPS, Tile  # noqa: E402
+from direct12pbrrenderer_amd.pipeline import (DeferredFrame, HaloTransport, grid_for_world, parse_layout,  # noqa: E402
+                                              tile_for_rank, tile_of_frame)
+from direct12pbrrenderer_amd.structs import CLUSTER_DTYPE, CLUSTER_X, CLUSTER_Y, CLUSTER_Z, ENV_MIPS, Tile  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec; the measured streaming-read rate is reported beside it
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (packed FMA on every lane every cycle)
+N_SIMD, CLOCK_HZ = 1024, 2.4e9
 # algorithmic bytes per pixel: unique bytes a reference pass must read + write once
 BYTES_PER_PX = {"shade": 25.0, "bloom": 75.75, "histogram": 8.0, "tonemap": 12.0}
 ENV_SIZE, LUT_RES, N_LIGHTS = 512, 512, 256
@@ -40,11 +53,36 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--width", type=int, default=3840)
+    p.add_argument("--width", type=int, default=3840, help="single-GPU frame / per-GPU tile budget (weak scaling)")
     p.add_argument("--height", type=int, default=2160)
+    p.add_argument("--frame", default=None, help="WxH: strong scaling of this frame over the ranks (cfg5: 7680x4320)")
+    p.add_argument("--layout", default=None, help="RxC tile grid, rows x cols (cfg5: 2x4); default: most square")
+    p.add_argument("--mode", choices=["halo", "apron"], default="halo", help="bloom across tile borders (N > 1)")
+    p.add_argument("--transport", choices=["capi", "torch"], default="capi",
+                   help="collectives through the C ABI's own RCCL communicator or through torch.distributed (also RCCL)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     return p.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes BEFORE anything here touches the GPU
+    (never re-exec a process that has), relay their output, return their exit code.  With fewer than N devices on the
+    box the ranks share cuda:0 in rehearsal mode (gloo + host copies): a functional run, not a measurement."""
+    n_dev = torch.cuda.device_count()   # does not initialise the GPU
+    env = dict(os.environ)
+    if n_dev < a.gpus:
+        if n_dev < 1 or a.gpus > 6:
+            print(f"bench.py: --gpus {a.gpus} but {n_dev} device(s) visible (a rehearsal on one GPU takes at most 6 ranks)", file=sys.stderr)
+            return 2
+        env["PBR_BENCH_REHEARSAL"] = "1"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def build_ibl(ctx):
@@ -59,36 +97,39 @@ def build_ibl(ctx):
     return lut, env, sh.cpu().numpy()
 
 
+def src_stamp():
+    """sha1 of the sources the committed counter profiles describe; a profile with another stamp is stale."""
+    h = hashlib.sha1()
+    for f in ("shade.hip", "pbr_device.hpp"):
+        h.update(open(os.path.join(ROOT, "direct12pbrrenderer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def load_profile(name, workload_px):
+    """A committed rocprofv3 --pmc summary (tools/summarize_pmc.py), or None when it describes another workload or
+    another version of the shade kernel."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+    if d.get("_workload_pixels") != workload_px or d.get("_src_stamp") != src_stamp():
+        return None
+    return d
+
+
+def kernel_entry(d, prefix, need):
+    for k, v in (d or {}).items():
+        if isinstance(v, dict) and prefix in k and all(n in v for n in need):
+            return v
+    return None
+
+
 def pmc_traffic(kernel_prefix, workload_px):
-    """HBM-side bytes per launch of `kernel_prefix` from the committed rocprofv3 --pmc summary
-    (profiles/pmc_traffic_latest.json, produced by tools/summarize_pmc.py from separate FETCH_SIZE and
-    WRITE_SIZE passes).  Unit/correction per MI355X_MICROARCH.md: both counters are in KiB and gfx950's
-    FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled.  None if no matching profile."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None
-    if d.get("_workload_pixels") != workload_px:
-        return None
-    for k, v in d.items():
-        if isinstance(v, dict) and kernel_prefix in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
-    return None
-
-
-def pmc_valu(kernel_prefix, workload_px):
-    """VALU wave-instructions per launch of `kernel_prefix` from the committed SQ counter summary."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq_latest.json")))
-    except Exception:
-        return None
-    if d.get("_workload_pixels") != workload_px:
-        return None
-    for k, v in d.items():
-        if isinstance(v, dict) and kernel_prefix in k and "SQ_INSTS_VALU" in v:
-            return v["SQ_INSTS_VALU"]
-    return None
+    """HBM-side bytes per launch from separate FETCH_SIZE and WRITE_SIZE passes.  Unit/correction per
+    MI355X_MICROARCH.md: both counters are in KiB and gfx950's FETCH_SIZE tallies 128-B requests at 64 B, so reads
+    are doubled.  None if no matching profile."""
+    v = kernel_entry(load_profile("pmc_traffic_latest.json", workload_px), kernel_prefix, ("FETCH_SIZE", "WRITE_SIZE"))
+    return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024) if v else None
 
 
 def time_stage(fn, iters, pre=None):
@@ -111,46 +152,95 @@ def time_stage(fn, iters, pre=None):
     return total / iters
 
 
-def cpu_baseline(g, lights, lut_np, env_np, width, height, budget_s=12.0):
-    """The oracle ("port") on a bounded band of the same workload, all host threads.  A 64-row probe
-    sizes the band so the timed sample costs about `budget_s` seconds of CPU work (<= the whole frame)."""
+def measure_hbm_read(ctx):
+    """Streaming-read bandwidth of this device (GB/s): pbr_membench_read over a 2 GiB buffer (8 x the Infinity Cache),
+    best of 5 launches, HIP events.  Not part of the timed step."""
+    n = 2 << 30
+    buf = torch.empty(n // 4, dtype=torch.int32, device=ctx.torch_device)
+    buf.fill_(0x01020304)
+    blocks = 256 * 16
+    sink = torch.zeros(blocks, dtype=torch.int32, device=ctx.torch_device)
+    best = 0.0
+    for i in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ctx.membench_read(buf, sink, blocks)
+        e1.record()
+        e1.synchronize()
+        if i >= 2:
+            best = max(best, n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del buf
+    return best
+
+
+def mean_lights_per_pixel(g, gb_np, spec, clusters_dev):
+    """Mean length of the light list a pixel of this rank's interior walks (ClusterIndex of clustered.hlsli:45-60 on
+    the synthetic depth + the culled cluster table): the per-pixel work statistic that must not drift with N."""
+    cl = clusters_dev.cpu().numpy().view(CLUSTER_DTYPE)
+    depth = gb_np["depth"][spec.siy:spec.siy + spec.h, spec.six:spec.six + spec.w].astype(np.float64)
+    near, far = float(g.Near), float(g.Far)
+    z_vs = near * far / (far - depth * (far - near))
+    sz = np.clip((CLUSTER_Z * np.log(np.clip(z_vs, near, far) / near) / np.log(far / near)).astype(np.int64), 0, CLUSTER_Z - 1)
+    xs = (np.arange(spec.x0, spec.x0 + spec.w) + 0.5) / spec.full_w
+    ys = (np.arange(spec.y0, spec.y0 + spec.h) + 0.5) / spec.full_h
+    sx = np.clip(np.floor(xs * CLUSTER_X).astype(np.int64), 0, CLUSTER_X - 1)[None, :]
+    sy = np.clip(np.floor((1.0 - ys) * CLUSTER_Y).astype(np.int64), 0, CLUSTER_Y - 1)[:, None]
+    idx = sz + sx * CLUSTER_Z + sy * CLUSTER_X * CLUSTER_Z
+    return float(np.minimum(cl["NumLights"], 32)[idx].mean())
+
+
+def cpu_baseline(g, lights, lut_np, env_np, width, height, budget_s=2.5, reps=5):
+    """The oracle ("port") on a bounded band of the single-GPU frame, all host threads: a 64-row probe sizes the band
+    so one repetition costs about `budget_s` seconds (<= the whole frame); inputs are synthesised ONCE outside the
+    clock; the timed region is the oracle calls only (cluster build + cull, shade, bloom, histogram, average, tone-map);
+    value = median of `reps` repetitions after one warm-up."""
     from oracle import binding as orc
 
-    def run(rows):
+    def band(rows):
         rows = max(16, min(height, rows) // 16 * 16)
         y0 = (height - rows) // 2
-        gb = synth.gbuffer_tile(0, y0, width, rows, width, height)
+        return rows, y0, synth.gbuffer_tile(0, y0, width, rows, width, height)
+
+    def run(rows, y0, gb):
+        t0 = time.perf_counter()
         cl = orc.cluster_build(g)
         orc.cluster_cull(g, lights, cl)
-        t0 = time.perf_counter()
         hdr, _ = orc.deferred_shade(g, Tile(0, y0, width, rows, width, height), gb, lut_np, env_np, ENV_SIZE, ENV_MIPS, cl, lights)
         orc.bloom(hdr)
         hist = orc.lum_histogram(hdr)
         avg = orc.lum_average(hist, width * rows, 1.0 / 60.0, 0.18)
         orc.tonemap(hdr, avg)
-        return rows, y0, time.perf_counter() - t0
+        return time.perf_counter() - t0
 
-    rows, _, dt = run(64)
-    rows, y0, dt = run(int(rows * budget_s / max(dt, 1e-3)))
-    reps = 1
-    if rows >= height // 16 * 16 and dt < 0.7 * budget_s:   # many-core host: the whole frame is too short a sample, repeat it
-        reps = max(1, min(32, int(budget_s / max(dt, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            run(rows)
-        dt = (time.perf_counter() - t0) / reps
+    rows, y0, gb = band(64)
+    dt = run(rows, y0, gb)
+    rows, y0, gb = band(int(rows * budget_s / max(dt, 1e-3)))
+    run(rows, y0, gb)
+    times = sorted(run(rows, y0, gb) for _ in range(reps))
+    dt = times[len(times) // 2]
     return {"value": round(width * rows / dt / 1e6, 4), "unit": "Mpixel/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{width}x{rows} band (rows {y0}..{y0 + rows - 1}) of the {width}x{height} frame: shade(256 lights+IBL)"
-                      f"+bloom+histogram+average+tonemap, oracle/pbr_oracle.cpp with OpenMP on {orc.num_threads()} threads, "
-                      f"{reps} x {dt:.2f} s (input synthesis included)"}
+            "sample": f"{width}x{rows} band (rows {y0}..{y0 + rows - 1}) of the {width}x{height} frame: cluster build+cull, shade(256 lights+IBL), "
+                      f"bloom, histogram, average, tonemap — oracle/pbr_oracle.cpp, OpenMP on {orc.num_threads()} threads, median of {reps} x {dt:.2f} s "
+                      f"(inputs synthesised outside the clock)"}
+
+
+def weak_tile(world, cols, rows, base_w, base_h):
+    """Per-rank tile of the weak-scaling frame: a 16:9 frame of world x (base_w x base_h) pixels cut cols x rows,
+    rounded to the multiple of 16 the bloom pyramid needs (N = 2, 8: 2720 x 3056 = 8.31 Mpixel vs 8.29 at N = 1, 4)."""
+    if world == 1:
+        return base_w, base_h
+    s = math.sqrt(world)
+    return int(round(base_w * s / cols / 16)) * 16, int(round(base_h * s / rows / 16)) * 16
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # PBR_BENCH_REHEARSAL=1: every rank on cuda:0 with a gloo collective — exercises this file's
+    # PBR_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives + host copies — exercises this file's
     # multi-rank path on a one-GPU box; not a measurement
     rehearsal = os.environ.get("PBR_BENCH_REHEARSAL", "0") == "1"
     if world > 1:
@@ -166,36 +256,149 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = local_rank if world > 1 else 0
     ctx = PbrContext(dev)
+    flag_dev = "cpu" if rehearsal else f"cuda:{dev}"
 
-    spec = tile_for_rank(rank, world, a.width, a.height)
+    def all_agree(ok):
+        """True iff every rank says ok (the fallback decisions below must be taken by all ranks together)."""
+        if not dist:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    # ---- workload: which frame, which tile grid
+    layout = parse_layout(a.layout) if a.layout else None
+    cols, rows = grid_for_world(world, layout)
+    if a.frame:
+        fw, fh = (int(v) for v in a.frame.lower().split("x"))
+        scaling = "strong"
+
+        def make_spec(r, halo):
+            return tile_of_frame(r, world, fw, fh, layout=(cols, rows), halo=halo)
+    else:
+        tw, th = weak_tile(world, cols, rows, a.width, a.height)
+        scaling = "weak"
+
+        def make_spec(r, halo):
+            return tile_for_rank(r, world, tw, th, layout=(cols, rows), halo=halo)
+
     lut, env, sh = build_ibl(ctx)
-    cam = scene.Camera.reference_default(spec.full_w, spec.full_h)
-    g = scene.make_global(cam, spec.full_w, spec.full_h, sh_pack=sh, delta_time=1.0 / 60.0)
+    spec0 = make_spec(rank, False)
+    cam = scene.Camera.reference_default(spec0.full_w, spec0.full_h)
+    g = scene.make_global(cam, spec0.full_w, spec0.full_h, sh_pack=sh, delta_time=1.0 / 60.0)
     lights = synth.lights_in_view_box(N_LIGHTS, cam)
 
-    use_capi_rccl = os.environ.get("PBR_ALLREDUCE", "torch") == "capi"
-    allreduce = None
-    if world > 1:
-        if use_capi_rccl:
+    # ---- collectives: the C ABI's own RCCL communicator first, torch.distributed (also RCCL) as the fallback
+    notes = []
+    capi_comm = False
+    if world > 1 and not rehearsal and a.transport == "capi":
+        ok = True
+        try:
             from direct12pbrrenderer_amd.api import comm_unique_id
             ids = [comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             ctx.comm_init(world, rank, ids[0])
-            allreduce = ctx.allreduce_hist
-        elif rehearsal:
-            def allreduce(h):
+        except Exception as e:   # noqa: BLE001 — any failure here means "use the other RCCL transport"
+            ok = False
+            notes.append(f"pbr_comm_init failed on rank {rank}: {e}")
+        capi_comm = all_agree(ok)
+        if not capi_comm:
+            notes.append("C-ABI RCCL communicator unavailable: collectives through torch.distributed")
+
+    def make_allreduce(kind):
+        if world == 1:
+            return None
+        if kind == "capi":
+            return ctx.allreduce_hist
+        if rehearsal:
+            def f(h):
+                ctx.sync()
                 t = h.cpu()
                 dist.all_reduce(t)
                 h.copy_(t)
-        else:
-            allreduce = lambda h: dist.all_reduce(h)   # RCCL, int32 sum == uint32 sum bit for bit  # noqa: E731
+            return f
+        return lambda h: dist.all_reduce(h)   # RCCL, int32 sum == uint32 sum bit for bit
 
-    frame = DeferredFrame(ctx, spec, g, lights, lut, LUT_RES, env, ENV_SIZE, ENV_MIPS, allreduce=allreduce)
-    frame.upload_gbuffer(synth.gbuffer_tile(spec.ex0, spec.ey0, spec.ew, spec.eh, spec.full_w, spec.full_h))
-    frame.set_prev_luminance(0.18)
+    def setup(mode, transport):
+        """Build this rank's frame for (mode, transport), render one verification frame and check it:
+        the all-reduced histogram must count every pixel of the whole frame exactly once, and in halo mode every
+        level-1 texel of E must have arrived, with the sender's checksum.  Returns (frame, gb_np) or raises."""
+        halo = mode == "halo" and world > 1
+        specs = [make_spec(r, halo) for r in range(world)]
+        spec = specs[rank]
+        ht = None
+        if halo:
+            ht = HaloTransport("host" if rehearsal else transport, dist)
+        fr = DeferredFrame(ctx, spec, g, lights, lut, LUT_RES, env, ENV_SIZE, ENV_MIPS, allreduce=make_allreduce(transport),
+                           all_specs=specs, rank=rank, halo_transport=ht)
+        gb_np = synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h)
+        fr.upload_gbuffer(gb_np)
+        fr.set_prev_luminance(0.18)
+        if halo:
+            fr.level1.fill_(777.0)
+        fr.clustered()
+        fr.shade()
+        fr.bloom_histogram()
+        if fr.allreduce is not None:
+            fr.allreduce(fr.hist)
+        ctx.sync()
+        counted = int(fr.hist.cpu().to(torch.int64).sum())
+        if counted != spec.full_w * spec.full_h:
+            raise RuntimeError(f"histogram counts {counted} pixels, frame has {spec.full_w * spec.full_h}")
+        if halo:
+            if bool((fr.level1 == 777.0).any()):
+                raise RuntimeError("halo exchange left level-1 texels of the extended tile unfilled")
+            pw = spec.ew // 2
+            l1 = fr.level1.view(spec.eh // 2, pw, 4).view(torch.int16).to(torch.int64)
+
+            def csum(r):
+                return int(l1[r[1]:r[1] + r[3], r[0]:r[0] + r[2]].sum())
+            mine = {}
+            for peer, snd, rcv in fr.halo_plan_local:
+                if snd:
+                    mine[("s", rank, peer)] = csum(snd)
+                if rcv:
+                    mine[("r", peer, rank)] = csum(rcv)
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            sent = {k[1:]: v for d in every for k, v in d.items() if k[0] == "s"}
+            for k, v in mine.items():
+                if k[0] == "r" and sent.get(k[1:]) != v:
+                    raise RuntimeError(f"halo strip {k[1]} -> {k[2]} arrived with another checksum")
+        fr.hist.zero_()
+        fr.set_prev_luminance(0.18)
+        return fr, gb_np
+
+    if world == 1:
+        candidates = [("single", "none")]
+    elif rehearsal:
+        candidates = [(a.mode, "torch")] + ([("apron", "torch")] if a.mode == "halo" else [])
+    else:
+        first = "capi" if capi_comm else "torch"
+        candidates = [(a.mode, first)]
+        if first == "capi":
+            candidates.append((a.mode, "torch"))
+        if a.mode == "halo":
+            candidates.append(("apron", "torch"))
+    frame = None
+    for mode, transport in candidates:
+        ok, err = True, None
+        try:
+            frame, gb_np = setup(mode, transport)
+        except Exception as e:   # noqa: BLE001
+            ok, err = False, f"{mode}/{transport} failed verification on rank {rank}: {e}"
+        if all_agree(ok):
+            break
+        notes.append(err or f"{mode}/{transport} failed on another rank")
+        frame = None
+        torch.cuda.synchronize()
+    if frame is None:
+        raise SystemExit("bench.py: no multi-GPU configuration passed its verification frame: " + "; ".join(notes))
+    spec = frame.spec
+    lights_px = mean_lights_per_pixel(g, gb_np, spec, frame.clusters)
     torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -217,65 +420,108 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{dev}")
+        t = torch.tensor([dt], dtype=torch.float64, device=flag_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        lp = [None] * world
+        dist.all_gather_object(lp, round(lights_px, 3))
+    else:
+        lp = [round(lights_px, 3)]
     ms_per_step = dt / a.steps * 1e3
     total_px = spec.full_w * spec.full_h
     value = total_px / (ms_per_step * 1e-3) / 1e6
 
+    shaded_px = spec.sw * spec.sh
+    if world == 1:
+        workload = f"{spec.full_w}x{spec.full_h} G-buffer"
+    elif scaling == "weak":
+        workload = (f"weak scaling of the cfg4 scene: {spec.full_w}x{spec.full_h} frame (16:9, {world} x 8.3 Mpixel) as {rows} rows x {cols} cols of "
+                    f"{spec.w}x{spec.h} tiles, one per GPU")
+    else:
+        workload = f"strong scaling: {spec.full_w}x{spec.full_h} frame as {rows} rows x {cols} cols of {spec.w}x{spec.h} tiles, one per GPU"
+    workload += (f"; {N_LIGHTS} clustered lights + IBL (env {ENV_SIZE}^2 x{ENV_MIPS} mips, LUT {LUT_RES}^2, SH9), auto-exposure + ACES + 9-tap bloom")
     out = {
         "metric": "shaded Mpixel/s at 4K G-buffer (full deferred frame: clustered shade + bloom + auto-exposure + ACES)",
         "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{a.width}x{a.height} G-buffer per GPU ({spec.full_w}x{spec.full_h} frame), {N_LIGHTS} clustered "
-                               f"lights + IBL (env {ENV_SIZE}^2 x{ENV_MIPS} mips, LUT {LUT_RES}^2, SH9), auto-exposure + ACES + 9-tap bloom",
-                   "tile": [spec.x0, spec.y0, spec.w, spec.h], "apron": spec.apron,
-                   "allreduce": ("none" if world == 1 else ("gloo-rehearsal" if rehearsal else ("rccl-capi" if use_capi_rccl else "rccl-torch")))},
+        "config": {"workload": workload, "frame": [spec.full_w, spec.full_h], "layout_rows_x_cols": f"{rows}x{cols}",
+                   "tile": [spec.x0, spec.y0, spec.w, spec.h], "shaded_rect": [spec.sx0, spec.sy0, spec.sw, spec.sh],
+                   "bloom_rect": [spec.ex0, spec.ey0, spec.ew, spec.eh],
+                   "bloom_borders": "none" if world == 1 else mode, "collectives": "none" if world == 1 else ("gloo-rehearsal" if rehearsal else f"rccl-{transport}"),
+                   "mean_lights_per_pixel_by_rank": lp},
     }
+    if rehearsal:
+        out["rehearsal"] = "all ranks share cuda:0 (gloo + host copies): functional run, not a measurement"
+    if notes:
+        out["config"]["notes"] = notes
 
-    if rank == 0 and not a.no_kernel_timing:
+    if not a.no_kernel_timing:   # every rank runs the same stage sequence (halo stages are collective); rank 0 reports
         iters = max(5, min(a.steps, 20))
         ext_px = spec.ew * spec.eh
+        int_px = spec.w * spec.h
         # bloom and the luminance histogram run fused in the frame (pbr_bloom_histogram); the two
         # un-fused stage calls are timed as well for reference
         stages = {
             "cluster": (frame.clustered, None, 0.0),
-            "shade": (frame.shade, None, BYTES_PER_PX["shade"] * ext_px),
-            "bloom+histogram": (frame.bloom_histogram, None, BYTES_PER_PX["bloom"] * ext_px + BYTES_PER_PX["histogram"] * spec.w * spec.h),
-            "bloom": (frame.bloom, None, BYTES_PER_PX["bloom"] * ext_px),
-            "histogram": (frame.histogram, None, BYTES_PER_PX["histogram"] * spec.w * spec.h),
+            "shade": (frame.shade, None, BYTES_PER_PX["shade"] * shaded_px),
+            "bloom+histogram": (frame.bloom_histogram, None, BYTES_PER_PX["bloom"] * (int_px if spec.halo else ext_px) + BYTES_PER_PX["histogram"] * int_px),
+            "histogram": (frame.histogram, None, BYTES_PER_PX["histogram"] * int_px),
             "average": (frame.average, frame.histogram, 0.0),
-            "tonemap": (frame.tonemap, None, BYTES_PER_PX["tonemap"] * spec.w * spec.h),
+            "tonemap": (frame.tonemap, None, BYTES_PER_PX["tonemap"] * int_px),
         }
+        if spec.halo:
+            stages["halo prefilter"] = (frame.halo_prefilter, None, 0.0)
+            stages["halo exchange"] = (frame.halo_exchange, None, 0.0)
+            stages["halo pyramid+merge"] = (frame.halo_pyramid, None, 0.0)
+        else:
+            stages["bloom"] = (frame.bloom, None, BYTES_PER_PX["bloom"] * ext_px)
         frame.hist.zero_()
         kern = {}
         for name, (fn, pre, nbytes) in stages.items():
             ms = time_stage(fn, iters, pre)
             kern[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1) if nbytes else None}
             frame.hist.zero_()
+        hbm_meas = measure_hbm_read(ctx)
+    if rank == 0 and not a.no_kernel_timing:
         # dominant kernel: the shade.  Its launch duration is the mean over the frames of the timed region; the
         # per-stage figures below come from separate isolated launches after it
         shade_ms_in_frame = sum(e0.elapsed_time(e1) for e0, e1 in shade_events) / max(len(shade_events), 1)
-        kern["shade(in frame)"] = {"ms": round(shade_ms_in_frame, 4), "GB/s": round(BYTES_PER_PX["shade"] * ext_px / (shade_ms_in_frame * 1e-3) / 1e9, 1)}
-        dom = "shade"
+        kern["shade(in frame)"] = {"ms": round(shade_ms_in_frame, 4), "GB/s": round(BYTES_PER_PX["shade"] * shaded_px / (shade_ms_in_frame * 1e-3) / 1e9, 1)}
         achieved = kern["shade(in frame)"]["GB/s"]
-        out["roofline"] = {"bound": "hbm", "kernel": {"shade": "k_deferred_shade", "bloom+histogram": "bloom chain (8 launches, histogram fused)",
-                                                     "tonemap": "k_tonemap"}[dom],
+        out["roofline"] = {"bound": "hbm", "kernel": "k_deferred_shade",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                           "traffic": pmc_traffic("k_deferred_shade", spec.ew * spec.eh) if dom == "shade" else None, "stage_ms": {k: v["ms"] for k, v in kern.items()},
+                           "traffic": pmc_traffic("k_deferred_shade", shaded_px),
+                           "hbm_measured_GBps": round(hbm_meas, 1), "frac_of_measured": round(achieved / hbm_meas, 5),
+                           "stage_ms": {k: v["ms"] for k, v in kern.items()},
                            "stage_GBps": {k: v["GB/s"] for k, v in kern.items()},
-                           "note": "shade with 256 clustered lights is FP32-VALU-bound (SURVEY D6): its HBM fraction is structurally low; "
-                                   "traffic (when present) is the committed rocprofv3 PMC figure for this workload, IBL gathers served by L2/MALL included"}
-        nv = pmc_valu("k_deferred_shade", spec.ew * spec.eh)
-        if nv:
-            # supplementary compute roofline for the VALU-bound shade: measured issue cost of a plain fp32 VALU
-            # instruction on gfx950 is ~4 cycles per SIMD (tools/valu_rate2.hip); 1024 SIMDs at the 2.4 GHz max clock
-            peak = 1024 * 2.4e9 / 4.0
-            out["roofline"]["valu"] = {"wave_insts_per_launch": nv, "achieved_Ginst_s": round(nv / (shade_ms_in_frame * 1e-3) / 1e9, 1),
-                                       "peak_Ginst_s": round(peak / 1e9, 1), "frac": round(nv / (shade_ms_in_frame * 1e-3) / peak, 3),
-                                       "source": "profiles/pmc_sq_latest.json (rocprofv3 SQ_INSTS_VALU) + tools/valu_rate2.hip"}
+                           "stage_frac_of_measured": {k: round(v["GB/s"] / hbm_meas, 4) for k, v in kern.items() if v["GB/s"]},
+                           "note": "algorithmic bytes (SURVEY 8d) / HIP-event duration; hbm_measured_GBps = pbr_membench_read streaming 2 GiB on this device; "
+                                   "the shade with 256 clustered lights is FP32-VALU-bound (SURVEY D6): its HBM fraction is structurally low; "
+                                   "traffic (when present) is the committed rocprofv3 PMC figure for this workload and this version of shade.hip, "
+                                   "IBL gathers served by L2/MALL included"}
+        sq = kernel_entry(load_profile("pmc_sq_latest.json", shaded_px), "k_deferred_shade", ("SQ_INSTS_VALU",))
+        if sq:
+            # supplementary compute roofline for the VALU-bound shade, against BOTH ceilings: the guide's spec issue
+            # rate (a wave64 fp32 op every 2 cycles per SIMD; 157.3 TFLOP/s when every op is a packed FMA) and the
+            # issue rate tools/valu_rate2.hip measures on this part (profiles/r02_valu_rate.txt: ~4 cycles per plain
+            # fp32 op whatever the occupancy)
+            nv = sq["SQ_INSTS_VALU"]
+            rate = nv / (shade_ms_in_frame * 1e-3)
+            valu = {"wave_insts_per_launch": nv, "achieved_Ginst_s": round(rate / 1e9, 1),
+                    "spec_peak_Ginst_s": round(N_SIMD * CLOCK_HZ / 2.0 / 1e9, 1), "frac_of_spec": round(rate / (N_SIMD * CLOCK_HZ / 2.0), 3),
+                    "measured_peak_Ginst_s": round(N_SIMD * CLOCK_HZ / 4.0 / 1e9, 1), "frac_of_measured": round(rate / (N_SIMD * CLOCK_HZ / 4.0), 3),
+                    "source": "profiles/pmc_sq_latest.json (rocprofv3 SQ_INSTS_VALU, same shade.hip) + tools/valu_rate2.hip -> profiles/r02_valu_rate.txt"}
+            mix = kernel_entry(load_profile("pmc_shade_issue_latest.json", shaded_px), "k_deferred_shade",
+                               ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32"))
+            if mix:
+                # upper bound: every FMA/MUL/ADD wave-instruction counted as PACKED (2 results per lane): 64 lanes x 2 x (2 | 1 | 1) flop
+                flop = 64.0 * 2.0 * (2.0 * mix["SQ_INSTS_VALU_FMA_F32"] + mix["SQ_INSTS_VALU_MUL_F32"] + mix["SQ_INSTS_VALU_ADD_F32"])
+                tf = flop / (shade_ms_in_frame * 1e-3) / 1e12
+                valu["flop_per_launch_upper_bound"] = flop
+                valu["TFLOPs_upper_bound"] = round(tf, 1)
+                valu["frac_of_fp32_peak_upper_bound"] = round(tf / FP32_VALU_PEAK_TFLOPS, 3)
+            out["roofline"]["valu"] = valu
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(g, lights, lut.cpu().view(torch.int16).numpy().view(np.float16),

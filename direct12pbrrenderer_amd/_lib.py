@@ -6,7 +6,7 @@ symbol cannot be resolved this module raises — it never substitutes another im
 import ctypes as C
 import os
 
-from .structs import CubeF32, GBuffer, Global, Tile
+from .structs import CubeF32, GBuffer, Global, HaloPeer, Tile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB", os.path.join(_HERE, "libpbr_hip.so"))   # override = experiments only
@@ -40,6 +40,8 @@ SIGNATURES = {
     "pbr_clustered": (_int, [_vp, C.POINTER(Global), _vp, _int, _vp]),
     "pbr_deferred_shade": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer),
                                   _vp, _u32, _vp, _u32, _u32, _vp, _vp, _int, _vp, _u32]),
+    "pbr_deferred_shade_f32": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer),
+                                      _vp, _u32, _vp, _u32, _u32, _vp, _vp, _int, _vp, _u32]),
     "pbr_skybox": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(CubeF32), _vp, _u32, _vp, _u32]),
     "pbr_gbuffer_encode": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "pbr_bloom_prefilter": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _f32, _f32]),
@@ -48,6 +50,8 @@ SIGNATURES = {
     "pbr_bloom_upsample_add": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp]),
     "pbr_bloom_merge": (_int, [_vp, _vp, _u32, _vp, _u32, _u32]),
     "pbr_bloom": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32]),
+    "pbr_bloom_prefilter_rect": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _u32, _u32, C.POINTER(_u32 * 4), _f32, _f32]),
+    "pbr_bloom_tiled": (_int, [_vp, _vp, _u32, C.POINTER(_u32 * 4), _u32, _u32, _vp, _vp, C.POINTER(_u32 * 4), _f32, _f32, _vp]),
     "pbr_bloom_histogram": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, C.POINTER(_u32 * 4), _f32, _f32, _vp]),
     "pbr_lum_histogram": (_int, [_vp, _vp, _u32, _u32, _u32, _f32, _f32, _vp]),
     "pbr_lum_average": (_int, [_vp, _vp, _u32, _f32, _f32, _f32, _vp]),
@@ -55,6 +59,11 @@ SIGNATURES = {
     "pbr_comm_unique_id": (_int, [_vp]),
     "pbr_comm_init": (_int, [_vp, _int, _int, _vp]),
     "pbr_allreduce_hist": (_int, [_vp, _vp]),
+    "pbr_halo_staging_bytes": (_sz, [C.POINTER(HaloPeer), _u32]),
+    "pbr_halo_exchange": (_int, [_vp, _vp, _u32, _u32, C.POINTER(HaloPeer), _u32, _vp, _sz]),
+    "pbr_halo_pack": (_int, [_vp, _vp, _u32, _u32, C.POINTER(HaloPeer), _u32, _vp, _sz, _int]),
+    "pbr_runtime_error": (C.c_char_p, []),
+    "pbr_membench_read": (_int, [_vp, _vp, _sz, _vp, _u32]),
 }
 
 _lib = None

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from .structs import (BLOOM_KNEE, BLOOM_THRESHOLD, CLUSTER_DTYPE, ENV_MIPS, HISTOGRAM_BINS,
                       INV_LOG_LUMINANCE_RANGE, LIGHT_DTYPE, LOG_LUMINANCE_RANGE, MIN_LOG_LUMINANCE,
-                      NUM_CLUSTERS, CubeF32, GBuffer, Global, Tile, bloom_chain_texels, cube_texels, env_padded_texels)
+                      NUM_CLUSTERS, CubeF32, GBuffer, Global, HaloPeer, Tile, bloom_chain_texels, cube_texels, env_padded_texels)
 
 
 class PbrError(RuntimeError):
@@ -139,6 +139,15 @@ class PbrContext:
                                                 _ptr(env), env_size, env_mips, _ptr(clusters), _ptr(lights),
                                                 int(num_lights), _ptr(hdr), hdr_pitch))
 
+    def deferred_shade_f32(self, g: Global, tile: Tile, gb, pitch, lut, lut_res, env, env_size, env_mips,
+                           clusters, lights, num_lights, hdr_f32, hdr_pitch):
+        """Parity probe: deferred_shade with a float32 [h, w, 4] output (the colour before the fp16 store)."""
+        s = GBuffer(gb["A"].data_ptr(), gb["B"].data_ptr(), gb["C"].data_ptr(), gb["depth"].data_ptr(),
+                    gb["stencil"].data_ptr(), pitch)
+        self._check(self.lib.pbr_deferred_shade_f32(self.h, C.byref(g), C.byref(tile), C.byref(s), _ptr(lut), lut_res,
+                                                    _ptr(env), env_size, env_mips, _ptr(clusters), _ptr(lights),
+                                                    int(num_lights), _ptr(hdr_f32), hdr_pitch))
+
     def rgbe_decode(self, rgbe, out):
         """rgbe: uint8 device tensor [..., 4] (Radiance texels); out: float32 [..., 4]."""
         self._check(self.lib.pbr_rgbe_decode(self.h, _ptr(rgbe), rgbe.numel() // 4, _ptr(out)))
@@ -182,6 +191,20 @@ class PbrContext:
         self._check(self.lib.pbr_bloom_histogram(self.h, _ptr(hdr), w, h, pitch, _ptr(chain_a), _ptr(chain_b), threshold, knee,
                                                  C.byref(r), min_log, inv_range, _ptr(hist)))
 
+    def bloom_prefilter_rect(self, hdr, w, h, pitch, out, out_pitch, out_x, out_y, rect, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE):
+        """bloom_prefilter on the half-res outputs rect=(x,y,w,h) of the image, stored at (out_x + x, out_y + y) of `out`."""
+        r = (C.c_uint32 * 4)(*[int(v) for v in rect])
+        self._check(self.lib.pbr_bloom_prefilter_rect(self.h, _ptr(hdr), w, h, pitch, _ptr(out), out_pitch, out_x, out_y,
+                                                      C.byref(r), threshold, knee))
+
+    def bloom_tiled(self, hdr, hdr_pitch, hdr_rect, ew, eh, chain_a, chain_b, merge_rect, hist=None,
+                    min_log=MIN_LOG_LUMINANCE, inv_range=INV_LOG_LUMINANCE_RANGE):
+        """Bloom levels 1..4 on the extended tile (level 1 of chain_a already complete) + merge/histogram of merge_rect."""
+        hr = (C.c_uint32 * 4)(*[int(v) for v in hdr_rect])
+        mr = (C.c_uint32 * 4)(*[int(v) for v in merge_rect])
+        self._check(self.lib.pbr_bloom_tiled(self.h, _ptr(hdr), hdr_pitch, C.byref(hr), ew, eh, _ptr(chain_a), _ptr(chain_b),
+                                             C.byref(mr), min_log, inv_range, _ptr(hist)))
+
     def lum_histogram(self, hdr, w, h, pitch, hist, min_log=MIN_LOG_LUMINANCE, inv_range=INV_LOG_LUMINANCE_RANGE):
         self._check(self.lib.pbr_lum_histogram(self.h, _ptr(hdr), w, h, pitch, min_log, inv_range, _ptr(hist)))
 
@@ -191,6 +214,10 @@ class PbrContext:
     def tonemap(self, hdr, w, h, pitch, avg, out, out_pitch):
         self._check(self.lib.pbr_tonemap(self.h, _ptr(hdr), w, h, pitch, _ptr(avg), _ptr(out), out_pitch))
 
+    def membench_read(self, buf, sink, blocks):
+        """One streaming-read pass over `buf` (measurement aid: the device's achievable HBM-read bandwidth)."""
+        self._check(self.lib.pbr_membench_read(self.h, _ptr(buf), buf.numel() * buf.element_size(), _ptr(sink), blocks))
+
     # ---- multi-GPU --------------------------------------------------------------------------------
     def comm_init(self, world, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
@@ -198,6 +225,27 @@ class PbrContext:
 
     def allreduce_hist(self, hist):
         self._check(self.lib.pbr_allreduce_hist(self.h, _ptr(hist)))
+
+    @staticmethod
+    def halo_peers(plan):
+        """plan: [(rank, send_rect, recv_rect)] with rect = (x, y, w, h) in plane texels or None -> pbr_halo_peer array."""
+        arr = (HaloPeer * max(len(plan), 1))()
+        for i, (rank, send, recv) in enumerate(plan):
+            arr[i].rank = int(rank)
+            arr[i].send = (C.c_uint32 * 4)(*(send or (0, 0, 0, 0)))
+            arr[i].recv = (C.c_uint32 * 4)(*(recv or (0, 0, 0, 0)))
+        return arr, len(plan)
+
+    def halo_staging_bytes(self, peers, n):
+        return int(self.lib.pbr_halo_staging_bytes(peers, n))
+
+    def halo_exchange(self, plane, pitch, rows, peers, n, staging):
+        """RCCL send/recv of the plan's rectangles on the ctx communicator (pbr_comm_init first)."""
+        self._check(self.lib.pbr_halo_exchange(self.h, _ptr(plane), pitch, rows, peers, n, _ptr(staging), staging.numel() * staging.element_size()))
+
+    def halo_pack(self, plane, pitch, rows, peers, n, staging, unpack=False):
+        self._check(self.lib.pbr_halo_pack(self.h, _ptr(plane), pitch, rows, peers, n, _ptr(staging),
+                                           staging.numel() * staging.element_size(), 1 if unpack else 0))
 
 
 def comm_unique_id() -> bytes:

@@ -32,12 +32,16 @@ __device__ __forceinline__ F4 from4(float4 v) { return f4(v.x, v.y, v.z, v.w); }
 
 // ---------------------------------------------------------------- bloom_prefilter.hlsl:17-60
 // grid (ceil(ow/64), ceil(oh/4)), block (64,4): one thread per half-res texel
+// OutRect: the outputs [x0,x1) x [y0,y1) (half-res texels of this image) are computed and stored at
+// out[(y + oy) * out_pitch + (x + ox)] — the whole image into a dense plane is {0,0,ow,oh}, pitch ow, offset 0;
+// a tile's interior into the level-1 plane of its extended rectangle is the multi-GPU halo path.
+struct OutRect { int x0, y0, x1, y1, ox, oy, pitch; };
 __global__ __launch_bounds__(256) void k_bloom_prefilter(const pbr_half* __restrict__ hdr, int w, int h, int pitch,
-                                                           pbr_half* __restrict__ out, int ow, int oh,
+                                                           pbr_half* __restrict__ out, int ow, int oh, OutRect rc,
                                                            float tx, float ty, float threshold, float knee) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= ow || y >= oh) return;
+    const int x = rc.x0 + blockIdx.x * 64 + threadIdx.x;
+    const int y = rc.y0 + blockIdx.y * 4 + threadIdx.y;
+    if (x >= rc.x1 || y >= rc.y1) return;
     const float u = (float)x * tx, v = (float)y * ty;   // no +0.5 (Q9)
     const float ox[5] = {0.0f, -1.0f, -1.0f, 1.0f, 1.0f};
     const float oy[5] = {0.0f, -1.0f, 1.0f, -1.0f, 1.0f};
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void k_bloom_prefilter(const pbr_half* __restr
         tw += wgt;
     }
     if (tw > 0.0f) { tr /= tw; tg /= tw; tb /= tw; }
-    store_h4(out + 4 * ((size_t)y * ow + x), f4(tr, tg, tb, 1.0f));
+    store_h4(out + 4 * ((size_t)(y + rc.oy) * rc.pitch + (x + rc.ox)), f4(tr, tg, tb, 1.0f));
 }
 
 // ---------------------------------------------------------------- blur.hlsli:24-55
@@ -275,10 +279,11 @@ __global__ __launch_bounds__(256) void k_bloom_merge(pbr_half* __restrict__ hdr,
 
 constexpr int PF_TW = 64, PF_TH = 16;
 __global__ __launch_bounds__(256) void k_bloom_prefilter_2x(const pbr_half* __restrict__ hdr, int w, int h, int pitch,
-                                                              pbr_half* __restrict__ out, int ow, int oh, float threshold, float knee) {
+                                                              pbr_half* __restrict__ out, int ow, int oh, OutRect rc, float threshold, float knee) {
     __shared__ float4 pos[PF_TH + 2][PF_TW + 2];   // (colour * weight, weight) of every sample position the tile touches
     const int tid = threadIdx.x;
-    const int px0 = blockIdx.x * PF_TW - 1, py0 = blockIdx.y * PF_TH - 1;
+    const int bx0 = rc.x0 + blockIdx.x * PF_TW, by0 = rc.y0 + blockIdx.y * PF_TH;   // tiles are laid over the output rect
+    const int px0 = bx0 - 1, py0 = by0 - 1;
     for (int e = tid; e < (PF_TH + 2) * (PF_TW + 2); e += 256) {
         const int r = e / (PF_TW + 2), c = e - r * (PF_TW + 2);
         const int p = px0 + c, q = py0 + r;
@@ -296,12 +301,12 @@ __global__ __launch_bounds__(256) void k_bloom_prefilter_2x(const pbr_half* __re
         pos[r][c] = make_float4(cr * wgt, cg * wgt, cb * wgt, wgt);
     }
     __syncthreads();
-    const int lx = tid & 63, x = blockIdx.x * PF_TW + lx;
-    if (x >= ow) return;
+    const int lx = tid & 63, x = bx0 + lx;
+    if (x >= rc.x1) return;
 #pragma unroll
     for (int k = 0; k < PF_TH / 4; k++) {
-        const int ly = (tid >> 6) + 4 * k, y = blockIdx.y * PF_TH + ly;
-        if (y >= oh) break;
+        const int ly = (tid >> 6) + 4 * k, y = by0 + ly;
+        if (y >= rc.y1) break;
         // the shader's order: centre, (-1,-1), (-1,+1), (+1,-1), (+1,+1)
         const float4 e0 = pos[ly + 1][lx + 1], e1 = pos[ly][lx], e2 = pos[ly + 2][lx], e3 = pos[ly][lx + 2], e4 = pos[ly + 2][lx + 2];
         float tr = (((e0.x + e1.x) + e2.x) + e3.x) + e4.x;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256) void k_bloom_prefilter_2x(const pbr_half* __re
         float tb = (((e0.z + e1.z) + e2.z) + e3.z) + e4.z;
         const float tw = (((e0.w + e1.w) + e2.w) + e3.w) + e4.w;
         if (tw > 0.0f) { tr /= tw; tg /= tw; tb /= tw; }
-        store_h4(out + 4 * ((size_t)y * ow + x), f4(tr, tg, tb, 1.0f));
+        store_h4(out + 4 * ((size_t)(y + rc.oy) * rc.pitch + (x + rc.ox)), f4(tr, tg, tb, 1.0f));
     }
 }
 
@@ -388,12 +393,21 @@ __device__ __forceinline__ float gauss9_const(float c) {   // the nine fused mad
 //        fp16 exactly where the H pass stores — no block barrier: LDS operations of one wave execute in order;
 //   3.   after the only barrier, V-gauss down each column from the shared fp16 tile, then store / merge into the
 //        HDR buffer / histogram.
+// TAIL instances: which part of the ow x oh level is merged, and where the HDR buffer sits inside it.
+//   tiles  : the 64 x TH tiles (tx0 + i, ty0 + j), i < tiles_x, are walked (the whole level: tx0 = ty0 = 0);
+//   merge  : only HDR texels inside [mx0,mx1) x [my0,my1) are read and updated;
+//   buffer : level texel (x, y) lives at hdr[(y - by) * pitch + (x - bx)] (a whole-level buffer: bx = by = 0);
+//   hist   : texels inside [hx0,hx1) x [hy0,hy1) are counted (TAIL 2).
+// A single-GPU frame merges everything; a multi-GPU tile in halo mode merges (and counts) only its interior, which
+// is all its HDR buffer covers beyond a 4-pixel rim.
+struct TailRect { int tx0, ty0, mx0, my0, mx1, my1, bx, by, hx0, hy0, hx1, hy1; };
+
 template <int MODE, bool DUAL, int TAIL, int TH, int NT>   // TAIL 0: store; 1: merge into hdr; 2: merge + histogram
 __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ in, int iw, int ih,
                                                  const pbr_half* __restrict__ in2,   // DUAL: ow x oh, same-size
                                                  pbr_half* __restrict__ out, int ow, int oh, int out_pitch,
                                                  int tiles_x, int n_tiles,
-                                                 int hx0, int hy0, int hx1, int hy1, float min_log, float inv_range,
+                                                 TailRect tr, float min_log, float inv_range,
                                                  uint32_t* __restrict__ hist) {
     constexpr int TW = 64, SW = TW + 8, SR = TH + 8;
     constexpr int NW = NT / 64;
@@ -416,15 +430,16 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
     // 1-D grid over tiles; the histogram instance is launched with fewer blocks than tiles (each walks several) so
     // that the per-block flush of 256 global atomics stays rare
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
+    const int x0 = (TAIL != 0 ? tr.tx0 + tile % tiles_x : tile % tiles_x) * TW, y0 = (TAIL != 0 ? tr.ty0 + tile / tiles_x : tile / tiles_x) * TH;
     const int x = x0 + lane;
     // the HDR texels the merge will need: in flight from the start
     H4 hdr_in[PER_O];
+    const bool in_mx = TAIL != 0 && x >= tr.mx0 && x < tr.mx1;   // merge rect lies inside the level: implies x < ow
     if (TAIL != 0) {
 #pragma unroll
         for (int k = 0; k < PER_O; k++) {
             const int y = y0 + wv + NW * k;
-            if (x < ow && y < oh) hdr_in[k] = *reinterpret_cast<const H4*>(out + 4 * ((size_t)y * out_pitch + x));
+            if (in_mx && y >= tr.my0 && y < tr.my1) hdr_in[k] = *reinterpret_cast<const H4*>(out + 4 * ((size_t)(y - tr.by) * out_pitch + (x - tr.bx)));
         }
     }
     // positions: columns x0-4+c (c = 0..71), rows clamp(y0-4+r) (r = 0..SR-1).  Main tap of row k: c = lane; the halo
@@ -495,13 +510,14 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
         if (TAIL == 0) {
             store_h4(out + 4 * ((size_t)y * out_pitch + x), a);
         } else {
+            if (!(in_mx && y >= tr.my0 && y < tr.my1)) continue;
             const half4v a0 = round_h4(a);   // A0 texel as the separate V pass would have stored it
             const F4 s = h4f(hdr_in[k]);
             H4 o;
             o.x = to_half_rn(s.x + (float)a0.x); o.y = to_half_rn(s.y + (float)a0.y); o.z = to_half_rn(s.z + (float)a0.z); o.w = to_half_rn(s.w + (float)a0.w);
-            *reinterpret_cast<H4*>(out + 4 * ((size_t)y * out_pitch + x)) = o;
+            *reinterpret_cast<H4*>(out + 4 * ((size_t)(y - tr.by) * out_pitch + (x - tr.bx))) = o;
             if (TAIL == 2) {
-                if (x >= hx0 && x < hx1 && y >= hy0 && y < hy1)
+                if (x >= tr.hx0 && x < tr.hx1 && y >= tr.hy0 && y < tr.hy1)
                     atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.x, (float)o.y, (float)o.z, min_log, inv_range)], 1u);
             }
         }
@@ -534,48 +550,75 @@ static bool force_staged() { static const bool v = getenv("PBR_BLOOM_STAGED") !=
 template <int MODE, bool DUAL, int TAIL>
 static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih, const pbr_half* in2,
                             pbr_half* out, uint32_t ow, uint32_t oh, uint32_t out_pitch,
-                            const uint32_t* rect, float min_log, float inv_range, uint32_t* hist) {
-    const int hx0 = rect ? (int)rect[0] : 0, hy0 = rect ? (int)rect[1] : 0;
-    const int hx1 = rect ? (int)(rect[0] + rect[2]) : 0, hy1 = rect ? (int)(rect[1] + rect[3]) : 0;
+                            const uint32_t* rect, float min_log, float inv_range, uint32_t* hist,
+                            const uint32_t* merge_rect = nullptr, const uint32_t* buf_origin = nullptr) {
+    // rect: histogram rect {x,y,w,h}; merge_rect: HDR texels to merge (default: the whole level); buf_origin: level
+    // coordinates of out[0] (default 0,0)
+    TailRect tr;
+    tr.hx0 = rect ? (int)rect[0] : 0; tr.hy0 = rect ? (int)rect[1] : 0;
+    tr.hx1 = rect ? (int)(rect[0] + rect[2]) : 0; tr.hy1 = rect ? (int)(rect[1] + rect[3]) : 0;
+    tr.mx0 = merge_rect ? (int)merge_rect[0] : 0; tr.my0 = merge_rect ? (int)merge_rect[1] : 0;
+    tr.mx1 = merge_rect ? (int)(merge_rect[0] + merge_rect[2]) : (int)ow; tr.my1 = merge_rect ? (int)(merge_rect[1] + merge_rect[3]) : (int)oh;
+    tr.bx = buf_origin ? (int)buf_origin[0] : 0; tr.by = buf_origin ? (int)buf_origin[1] : 0;
     // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 (256) below
     static const int forced = getenv("PBR_BLOOM_TILE") ? atoi(getenv("PBR_BLOOM_TILE")) : 0;
-    const bool big = forced ? forced == 32 : (uint64_t)((ow + 63) / 64) * ((oh + 31) / 32) >= 900;
+    const bool big = forced ? forced == 32 : (uint64_t)((tr.mx1 + 63) / 64 - tr.mx0 / 64) * ((tr.my1 + 31) / 32 - tr.my0 / 32) >= 900;
     // histogram instance: ~1024 blocks that each walk the same number of tiles (an uneven split leaves the chip
     // half empty for the last round; one block per tile costs 256 contended global atomics per tile)
     static const int hist_blocks = getenv("PBR_BLOOM_HIST_BLOCKS") ? atoi(getenv("PBR_BLOOM_HIST_BLOCKS")) : 1024;
     auto even_blocks = [](int n_tiles) { const int per = (n_tiles + hist_blocks - 1) / hist_blocks; return (n_tiles + per - 1) / per; };
-    const int tiles_x = (int)((ow + 63) / 64);
+    // tiles that intersect the merge rect (TAIL 0 has no rect: every tile of the level)
+    const int th = big ? 32 : 16;
+    tr.tx0 = tr.mx0 / 64; tr.ty0 = tr.my0 / th;
+    const int tiles_x = (tr.mx1 + 63) / 64 - tr.tx0;
+    const int n_tiles = tiles_x * ((tr.my1 + th - 1) / th - tr.ty0);
+    const int blocks = TAIL == 2 ? even_blocks(n_tiles) : n_tiles;
     if (big) {
-        const int n_tiles = tiles_x * (int)((oh + 31) / 32);
-        const int blocks = TAIL == 2 ? even_blocks(n_tiles) : n_tiles;
         hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 32, 512>), dim3(blocks), dim3(512), 0, ctx->stream,
-                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, tr, min_log, inv_range, hist);
     } else {
-        const int n_tiles = tiles_x * (int)((oh + 15) / 16);
-        const int blocks = TAIL == 2 ? even_blocks(n_tiles) : n_tiles;
         hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 16, 256>), dim3(blocks), dim3(256), 0, ctx->stream,
-                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, hx0, hy0, hx1, hy1, min_log, inv_range, hist);
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, tr, min_log, inv_range, hist);
     }
     return launched(ctx, "k_blur_hv");
 }
 
 extern "C" {
 
+static pbr_status prefilter_launch(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                   pbr_half* out, const OutRect& rc, float threshold, float knee) {
+    const uint32_t ow = w >> 1, oh = h >> 1;
+    const uint32_t rw = (uint32_t)(rc.x1 - rc.x0), rh = (uint32_t)(rc.y1 - rc.y0);
+    const float tx = 1.0f / (float)ow, ty = 1.0f / (float)oh;   // DeferredPipeline.cpp:418
+    if (exact_half(w) && exact_half(h) && !force_staged()) {   // shared-sample kernel (bit-identical)
+        dim3 g2((rw + PF_TW - 1) / PF_TW, (rh + PF_TH - 1) / PF_TH);
+        hipLaunchKernelGGL(k_bloom_prefilter_2x, g2, dim3(256), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, rc, threshold, knee);
+        return launched(ctx, "k_bloom_prefilter_2x");
+    }
+    dim3 grid((rw + 63) / 64, (rh + 3) / 4);
+    hipLaunchKernelGGL(k_bloom_prefilter, grid, dim3(64, 4), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, rc, tx, ty, threshold, knee);
+    return launched(ctx, "k_bloom_prefilter");
+}
+
 pbr_status pbr_bloom_prefilter(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                                pbr_half* out, float threshold, float knee) {
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, hdr && out, "pbr_bloom_prefilter: null pointer");
     PBR_REQUIRE(ctx, (w >> 1) >= 1 && (h >> 1) >= 1 && w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom_prefilter: bad size");
-    const uint32_t ow = w >> 1, oh = h >> 1;
-    const float tx = 1.0f / (float)ow, ty = 1.0f / (float)oh;   // DeferredPipeline.cpp:418
-    if (exact_half(w) && exact_half(h) && !force_staged()) {   // shared-sample kernel (bit-identical)
-        dim3 g2((ow + PF_TW - 1) / PF_TW, (oh + PF_TH - 1) / PF_TH);
-        hipLaunchKernelGGL(k_bloom_prefilter_2x, g2, dim3(256), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, threshold, knee);
-        return launched(ctx, "k_bloom_prefilter_2x");
-    }
-    dim3 grid((ow + 63) / 64, (oh + 3) / 4);
-    hipLaunchKernelGGL(k_bloom_prefilter, grid, dim3(64, 4), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, tx, ty, threshold, knee);
-    return launched(ctx, "k_bloom_prefilter");
+    const OutRect rc{0, 0, (int)(w >> 1), (int)(h >> 1), 0, 0, (int)(w >> 1)};
+    return prefilter_launch(ctx, hdr, w, h, pitch, out, rc, threshold, knee);
+}
+
+pbr_status pbr_bloom_prefilter_rect(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                    pbr_half* out, uint32_t out_pitch, uint32_t out_x, uint32_t out_y,
+                                    const uint32_t rect[4], float threshold, float knee) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hdr && out && rect, "pbr_bloom_prefilter_rect: null pointer");
+    PBR_REQUIRE(ctx, (w >> 1) >= 1 && (h >> 1) >= 1 && w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom_prefilter_rect: bad size");
+    PBR_REQUIRE(ctx, rect[2] >= 1 && rect[3] >= 1 && rect[0] + rect[2] <= (w >> 1) && rect[1] + rect[3] <= (h >> 1), "pbr_bloom_prefilter_rect: rect outside the half-res image");
+    PBR_REQUIRE(ctx, out_pitch >= out_x + rect[0] + rect[2] && out_pitch <= 65535 && out_y <= 65535, "pbr_bloom_prefilter_rect: rect does not fit the output pitch");
+    const OutRect rc{(int)rect[0], (int)rect[1], (int)(rect[0] + rect[2]), (int)(rect[1] + rect[3]), (int)out_x, (int)out_y, (int)out_pitch};
+    return prefilter_launch(ctx, hdr, w, h, pitch, out, rc, threshold, knee);
 }
 
 pbr_status pbr_blur_h(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih, pbr_half* out, uint32_t ow, uint32_t oh) {
@@ -636,18 +679,14 @@ static pbr_status bloom_final(pbr_ctx* ctx, const pbr_half* b0, pbr_half* hdr, u
     return launched(ctx, "k_blur_v_merge");
 }
 
-static pbr_status bloom_impl(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch, pbr_half* A, pbr_half* B,
-                             float threshold, float knee, const uint32_t* hist_rect, float min_log, float inv_range, uint32_t* hist256) {
-    PBR_REQUIRE(ctx, hdr && A && B, "pbr_bloom: null pointer");
-    // BloomStep < CalculateMaxMipLevels (DeferredPipeline.cpp:343): every level must be >= 1 texel
-    PBR_REQUIRE(ctx, (w >> (PBR_BLOOM_MIPS - 1)) >= 1 && (h >> (PBR_BLOOM_MIPS - 1)) >= 1, "pbr_bloom: image too small for 5 mips");
-    PBR_REQUIRE(ctx, w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom: bad size");
+// Levels 1..4 of BloomPass::Execute from a filled level 1 of chain A: the three downsample pairs and the three
+// upsample-add pairs (DeferredPipeline.cpp:428-540).  *res = where the finished level 1 lives (chain A or B).
+static pbr_status bloom_pyramid(pbr_ctx* ctx, uint32_t w, uint32_t h, pbr_half* A, pbr_half* B, const pbr_half** res_out) {
     auto a = [&](uint32_t l) { return A + 4 * pbr_bloom_level_offset(w, h, l); };
     auto b = [&](uint32_t l) { return B + 4 * pbr_bloom_level_offset(w, h, l); };
     auto W = [&](uint32_t l) { return w >> l; };
     auto H = [&](uint32_t l) { return h >> l; };
     pbr_status r;
-    if ((r = pbr_bloom_prefilter(ctx, hdr, w, h, pitch, a(1), threshold, knee))) return r;
     // Per level pair: where level l+1 is exactly half of level l (and both fit the fast path's size limit) the H and V
     // pass run as one kernel and the H result (chain B of the reference schedule) is never written; elsewhere the two
     // staged kernels run.  1920x1080, for instance, is exact down to 240x135 and staged for 135 -> 67.  Fused up-levels
@@ -675,13 +714,28 @@ static pbr_status bloom_impl(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h
             res = a(up);
         }
     }
-    if (exact(0)) {   // H + V + merge (+ histogram) in one kernel
-        if (hist256) return launch_hv<M_UP, false, 2>(ctx, res, W(1), H(1), nullptr, hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
-        return launch_hv<M_UP, false, 1>(ctx, res, W(1), H(1), nullptr, hdr, w, h, pitch, nullptr, 0.0f, 0.0f, nullptr);
+    *res_out = res;
+    return PBR_OK;
+}
+
+static pbr_status bloom_impl(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch, pbr_half* A, pbr_half* B,
+                             float threshold, float knee, const uint32_t* hist_rect, float min_log, float inv_range, uint32_t* hist256) {
+    PBR_REQUIRE(ctx, hdr && A && B, "pbr_bloom: null pointer");
+    // BloomStep < CalculateMaxMipLevels (DeferredPipeline.cpp:343): every level must be >= 1 texel
+    PBR_REQUIRE(ctx, (w >> (PBR_BLOOM_MIPS - 1)) >= 1 && (h >> (PBR_BLOOM_MIPS - 1)) >= 1, "pbr_bloom: image too small for 5 mips");
+    PBR_REQUIRE(ctx, w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom: bad size");
+    pbr_status r;
+    if ((r = pbr_bloom_prefilter(ctx, hdr, w, h, pitch, A + 4 * pbr_bloom_level_offset(w, h, 1), threshold, knee))) return r;
+    const pbr_half* res = nullptr;
+    if ((r = bloom_pyramid(ctx, w, h, A, B, &res))) return r;
+    if (!force_staged() && exact_half(w) && exact_half(h)) {   // H + V + merge (+ histogram) in one kernel
+        if (hist256) return launch_hv<M_UP, false, 2>(ctx, res, w >> 1, h >> 1, nullptr, hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
+        return launch_hv<M_UP, false, 1>(ctx, res, w >> 1, h >> 1, nullptr, hdr, w, h, pitch, nullptr, 0.0f, 0.0f, nullptr);
     }
-    if ((r = pbr_blur_h(ctx, res, W(1), H(1), b(0), w, h))) return r;
+    pbr_half* b0 = B;   // level 0 of chain B
+    if ((r = pbr_blur_h(ctx, res, w >> 1, h >> 1, b0, w, h))) return r;
     // A0 = V(B0); S += A0 [; histogram(S)] in one pass — chain A level 0 is not materialised
-    return bloom_final(ctx, b(0), hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
+    return bloom_final(ctx, b0, hdr, w, h, pitch, hist_rect, min_log, inv_range, hist256);
 }
 
 // BloomPass::Execute (DeferredPipeline.cpp:400-570; schedule comment :379-399)
@@ -700,6 +754,31 @@ pbr_status pbr_bloom_histogram(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t
     PBR_REQUIRE(ctx, rect && hist256, "pbr_bloom_histogram: null pointer");
     PBR_REQUIRE(ctx, rect[2] >= 1 && rect[3] >= 1 && rect[0] + rect[2] <= w && rect[1] + rect[3] <= h, "pbr_bloom_histogram: rect outside the image");
     return bloom_impl(ctx, hdr, w, h, pitch, A, B, threshold, knee, rect, min_log, inv_range, hist256);
+}
+
+// Multi-GPU halo path (SURVEY 8e option 2): BloomPass::Execute minus the prefilter, on the extended rectangle E
+// (ew x eh) of a tile whose level 1 (chain A) is already filled — the interior by pbr_bloom_prefilter_rect, the
+// rest by the neighbours' level 1 — and with the final merge (+ histogram) restricted to merge_rect, the part of E
+// this rank owns.  hdr covers hdr_rect = {x, y, w, h} of E only (hdr[0] = texel (x, y), pitch hdr_pitch).
+pbr_status pbr_bloom_tiled(pbr_ctx* ctx, pbr_half* hdr, uint32_t hdr_pitch, const uint32_t hdr_rect[4],
+                           uint32_t ew, uint32_t eh, pbr_half* A, pbr_half* B, const uint32_t merge_rect[4],
+                           float min_log, float inv_range, uint32_t* hist256) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hdr && hdr_rect && A && B && merge_rect, "pbr_bloom_tiled: null pointer");
+    PBR_REQUIRE(ctx, ew <= 65535 && eh <= 65535 && (ew >> (PBR_BLOOM_MIPS - 1)) >= 1 && (eh >> (PBR_BLOOM_MIPS - 1)) >= 1, "pbr_bloom_tiled: bad size");
+    PBR_REQUIRE(ctx, hdr_rect[2] >= 1 && hdr_rect[3] >= 1 && hdr_rect[0] + hdr_rect[2] <= ew && hdr_rect[1] + hdr_rect[3] <= eh && hdr_pitch >= hdr_rect[2],
+                "pbr_bloom_tiled: hdr_rect outside the extended tile");
+    PBR_REQUIRE(ctx, merge_rect[2] >= 1 && merge_rect[3] >= 1 && merge_rect[0] >= hdr_rect[0] && merge_rect[1] >= hdr_rect[1] &&
+                     merge_rect[0] + merge_rect[2] <= hdr_rect[0] + hdr_rect[2] && merge_rect[1] + merge_rect[3] <= hdr_rect[1] + hdr_rect[3],
+                "pbr_bloom_tiled: merge_rect outside hdr_rect");
+    if (force_staged() || !exact_half(ew) || !exact_half(eh))
+        return pbr::fail(ctx, PBR_ERR_UNSUPPORTED, "pbr_bloom_tiled: the extended tile must be even and <= 8192 on a side");
+    const pbr_half* res = nullptr;
+    pbr_status r;
+    if ((r = bloom_pyramid(ctx, ew, eh, A, B, &res))) return r;
+    const uint32_t origin[2] = {hdr_rect[0], hdr_rect[1]};
+    if (hist256) return launch_hv<M_UP, false, 2>(ctx, res, ew >> 1, eh >> 1, nullptr, hdr, ew, eh, hdr_pitch, merge_rect, min_log, inv_range, hist256, merge_rect, origin);
+    return launch_hv<M_UP, false, 1>(ctx, res, ew >> 1, eh >> 1, nullptr, hdr, ew, eh, hdr_pitch, nullptr, 0.0f, 0.0f, nullptr, merge_rect, origin);
 }
 
 }  // extern "C"

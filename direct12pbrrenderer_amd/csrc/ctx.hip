@@ -2,7 +2,9 @@
 #include "pbr_internal.hpp"
 #include "pbr_device.hpp"
 #include <dlfcn.h>
+#include <link.h>
 #include <cstring>
+#include <vector>
 
 extern "C" {
 
@@ -19,9 +21,39 @@ size_t pbr_bloom_level_offset(uint32_t w, uint32_t h, uint32_t level) {
 }
 size_t pbr_bloom_chain_texels(uint32_t w, uint32_t h) { return pbr_bloom_level_offset(w, h, PBR_BLOOM_MIPS); }
 
+// A process that also hosts PyTorch must run ONE HIP runtime: torch ships its own libamdhip64 (same soname as
+// /opt/rocm's), and whichever copy is mapped first serves both.  If this library was loaded before torch, torch ends
+// up on the system runtime it was not built against and fails later in obscure ways (hipStreamCreate errors).  The
+// loader cannot be told to prefer "the copy torch will bring", so the mismatch is detected and reported instead.
+struct RuntimeScan { std::string hip_dir, torch_dir; };
+static int scan_cb(struct dl_phdr_info* info, size_t, void* data) {
+    RuntimeScan* s = (RuntimeScan*)data;
+    const char* name = info->dlpi_name;
+    if (!name || !*name) return 0;
+    const char* base = std::strrchr(name, '/');
+    const std::string dir = base ? std::string(name, (size_t)(base - name)) : std::string();
+    base = base ? base + 1 : name;
+    if (std::strncmp(base, "libamdhip64.so", 14) == 0 && s->hip_dir.empty()) s->hip_dir = dir;
+    if (std::strncmp(base, "libtorch_hip.so", 15) == 0) s->torch_dir = dir;
+    return 0;
+}
+static char g_runtime_err[512];
+static bool runtime_mismatch() {
+    RuntimeScan s;
+    dl_iterate_phdr(scan_cb, &s);
+    if (s.torch_dir.empty() || s.hip_dir.empty() || s.hip_dir == s.torch_dir) return false;
+    snprintf(g_runtime_err, sizeof(g_runtime_err),
+             "two ROCm installations in one process: the HIP runtime in use is %s/libamdhip64 but PyTorch (%s) ships its own; "
+             "load torch BEFORE libpbr_hip.so / libpbr_host.so (direct12pbrrenderer_amd._lib.load() does)", s.hip_dir.c_str(), s.torch_dir.c_str());
+    return true;
+}
+
+const char* pbr_runtime_error(void) { return runtime_mismatch() ? g_runtime_err : nullptr; }
+
 pbr_status pbr_ctx_create(int hip_device, pbr_ctx** out) {
     if (!out) return PBR_ERR_INVALID;
     *out = nullptr;
+    if (runtime_mismatch()) { fprintf(stderr, "pbr_ctx_create: %s\n", g_runtime_err); return PBR_ERR_UNSUPPORTED; }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || hip_device < 0 || hip_device >= n) return PBR_ERR_HIP;
     if (hipSetDevice(hip_device) != hipSuccess) return PBR_ERR_HIP;
@@ -83,8 +115,17 @@ typedef int (*nccl_init_rank_fn)(void**, int, nccl_uid, int);
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 enum { NCCL_UINT32 = 3, NCCL_SUM = 0 };
 
+typedef int (*nccl_p2p_fn)(void*, size_t, int, int, void*, hipStream_t);   // ncclSend / ncclRecv (buffer, count, type, peer, comm, stream)
+typedef int (*nccl_group_fn)(void);
+enum { NCCL_INT8 = 0 };
+
 static void* open_rccl() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // a copy that is already mapped (PyTorch brings its own librccl.so.1) is reused: one RCCL per process
+    for (const char* n : names) {
+        void* h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (h) return h;
+    }
     for (const char* n : names) {
         void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (h) return h;
@@ -109,8 +150,11 @@ pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_i
     PBR_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world, "pbr_comm_init: bad world/rank");
     ctx->world = world;
     ctx->rank = rank;
-    if (world == 1) return PBR_OK;
+    // world 1 needs no communicator; with a unique id one is created all the same (a 1-rank RCCL communicator is
+    // legal) so that the RCCL entry points can be exercised on a single GPU
+    if (world == 1 && unique_id_128_bytes == nullptr) return PBR_OK;
     PBR_REQUIRE(ctx, unique_id_128_bytes != nullptr, "pbr_comm_init: null unique id");
+    PBR_REQUIRE(ctx, ctx->comm == nullptr, "pbr_comm_init: the context already has a communicator");
     if (!ctx->rccl_lib) ctx->rccl_lib = open_rccl();
     if (!ctx->rccl_lib) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_comm_init: librccl not found");
     nccl_init_rank_fn f = (nccl_init_rank_fn)dlsym(ctx->rccl_lib, "ncclCommInitRank");
@@ -126,13 +170,169 @@ pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_i
 pbr_status pbr_allreduce_hist(pbr_ctx* ctx, uint32_t* hist256) {
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, hist256 != nullptr, "pbr_allreduce_hist: null histogram");
-    if (ctx->world <= 1) return PBR_OK;   // single GPU: the local histogram is the global one
+    if (ctx->world <= 1 && !ctx->comm) return PBR_OK;   // single GPU: the local histogram is the global one
     if (!ctx->comm) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_allreduce_hist: world > 1 but no communicator");
     nccl_allreduce_fn f = (nccl_allreduce_fn)dlsym(ctx->rccl_lib, "ncclAllReduce");
     if (!f) return pbr::fail(ctx, PBR_ERR_COMM, "ncclAllReduce missing");
     int r = f(hist256, hist256, PBR_HISTOGRAM_BINS, NCCL_UINT32, NCCL_SUM, ctx->comm, ctx->stream);
     if (r != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclAllReduce failed");
     return PBR_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------- HBM streaming-read probe
+// The "measured HBM-read roofline" bench.py reports next to the 8 TB/s nominal figure: every lane streams 16-byte
+// loads with a grid stride (one 1 KiB segment per wave and trip, 4 loads in flight per lane), folds them with xor so
+// the loads cannot be dropped, and a block writes one word.  Run on a buffer several times the 256 MiB Infinity Cache.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_membench_read(const u32x4* __restrict__ buf, size_t n16, uint32_t* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u32x4 a = {0, 0, 0, 0};
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 v0 = __builtin_nontemporal_load(buf + i), v1 = __builtin_nontemporal_load(buf + i + stride);
+        const u32x4 v2 = __builtin_nontemporal_load(buf + i + 2 * stride), v3 = __builtin_nontemporal_load(buf + i + 3 * stride);
+        a.x ^= v0.x ^ v1.x ^ v2.x ^ v3.x; a.y ^= v0.y ^ v1.y ^ v2.y ^ v3.y;
+        a.z ^= v0.z ^ v1.z ^ v2.z ^ v3.z; a.w ^= v0.w ^ v1.w ^ v2.w ^ v3.w;
+    }
+    for (; i < n16; i += stride) { const u32x4 v = buf[i]; a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w; }
+    uint32_t r = a.x ^ a.y ^ a.z ^ a.w;
+    for (int o = 32; o > 0; o >>= 1) r ^= __shfl_xor(r, o);
+    if ((threadIdx.x & 63) == 0) atomicXor(&sink[blockIdx.x], r);
+}
+
+extern "C" pbr_status pbr_membench_read(pbr_ctx* ctx, const void* buf, size_t bytes, uint32_t* sink, uint32_t blocks) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, buf && sink && bytes >= 16 && ((uintptr_t)buf & 15u) == 0 && blocks >= 1 && blocks <= 65535, "pbr_membench_read: bad arguments");
+    hipLaunchKernelGGL(k_membench_read, dim3(blocks), dim3(256), 0, ctx->stream, (const u32x4*)buf, bytes / 16, sink);
+    return pbr::launched(ctx, "k_membench_read");
+}
+
+// ------------------------------------------------------------------------------------------- halo exchange
+// Level-1 strips of the bloom pyramid between neighbouring tiles (SURVEY 8e option 2).  One pack launch gathers every
+// outgoing rectangle of the plane into a contiguous staging area, one ncclGroup sends / receives all strips, one
+// unpack launch scatters what arrived: three enqueues per frame however many neighbours a tile has.
+constexpr int HALO_MAX_PEERS = 16;
+struct HaloRects {
+    int n;
+    int x[HALO_MAX_PEERS], y[HALO_MAX_PEERS], w[HALO_MAX_PEERS], h[HALO_MAX_PEERS];
+    uint32_t off[HALO_MAX_PEERS];   // texel offset of the rectangle in the staging area
+};
+// grid (ceil(max_texels / 256), n): block row r copies rectangle r; TO_STAGING: plane -> staging, else staging -> plane
+template <bool TO_STAGING>
+__global__ __launch_bounds__(256) void k_halo_copy(uint2* __restrict__ plane, int pitch, uint2* __restrict__ staging, HaloRects rc) {
+    const int r = blockIdx.y;
+    const int w = rc.w[r], n = w * rc.h[r];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int yy = i / w, xx = i - yy * w;
+        const size_t p = (size_t)(rc.y[r] + yy) * pitch + (rc.x[r] + xx);
+        if (TO_STAGING) staging[rc.off[r] + i] = plane[p];
+        else plane[p] = staging[rc.off[r] + i];
+    }
+}
+
+extern "C" {
+
+size_t pbr_halo_staging_bytes(const pbr_halo_peer* peers, uint32_t n_peers) {
+    size_t t = 0;
+    for (uint32_t i = 0; peers && i < n_peers; i++) t += (size_t)peers[i].send[2] * peers[i].send[3] + (size_t)peers[i].recv[2] * peers[i].recv[3];
+    return t * 8;
+}
+
+pbr_status pbr_halo_exchange(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
+                             const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, plane && pitch >= 1 && rows >= 1, "pbr_halo_exchange: null plane");
+    if (n_peers == 0) return PBR_OK;
+    PBR_REQUIRE(ctx, peers && n_peers <= (uint32_t)HALO_MAX_PEERS, "pbr_halo_exchange: bad peer list");
+    PBR_REQUIRE(ctx, staging && staging_bytes >= pbr_halo_staging_bytes(peers, n_peers), "pbr_halo_exchange: staging area too small");
+    HaloRects snd{}, rcv{};
+    uint32_t off = 0;
+    int max_s = 0, max_r = 0;
+    int peer_of_s[HALO_MAX_PEERS], peer_of_r[HALO_MAX_PEERS];
+    for (uint32_t i = 0; i < n_peers; i++) {
+        const pbr_halo_peer& p = peers[i];
+        PBR_REQUIRE(ctx, p.send[0] + p.send[2] <= pitch && p.send[1] + p.send[3] <= rows && p.recv[0] + p.recv[2] <= pitch && p.recv[1] + p.recv[3] <= rows,
+                    "pbr_halo_exchange: rectangle outside the plane");
+        PBR_REQUIRE(ctx, p.rank >= 0 && p.rank < ctx->world && (p.rank != ctx->rank || ctx->world == 1), "pbr_halo_exchange: bad peer rank");
+        if (p.send[2] && p.send[3]) {
+            const int k = snd.n++;
+            snd.x[k] = (int)p.send[0]; snd.y[k] = (int)p.send[1]; snd.w[k] = (int)p.send[2]; snd.h[k] = (int)p.send[3]; snd.off[k] = off;
+            off += p.send[2] * p.send[3];
+            peer_of_s[k] = p.rank;
+            if (snd.w[k] * snd.h[k] > max_s) max_s = snd.w[k] * snd.h[k];
+        }
+    }
+    for (uint32_t i = 0; i < n_peers; i++) {
+        const pbr_halo_peer& p = peers[i];
+        if (p.recv[2] && p.recv[3]) {
+            const int k = rcv.n++;
+            rcv.x[k] = (int)p.recv[0]; rcv.y[k] = (int)p.recv[1]; rcv.w[k] = (int)p.recv[2]; rcv.h[k] = (int)p.recv[3]; rcv.off[k] = off;
+            off += p.recv[2] * p.recv[3];
+            peer_of_r[k] = p.rank;
+            if (rcv.w[k] * rcv.h[k] > max_r) max_r = rcv.w[k] * rcv.h[k];
+        }
+    }
+    if (!ctx->comm) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_halo_exchange: no communicator (pbr_comm_init)");
+    nccl_p2p_fn f_send = (nccl_p2p_fn)dlsym(ctx->rccl_lib, "ncclSend");
+    nccl_p2p_fn f_recv = (nccl_p2p_fn)dlsym(ctx->rccl_lib, "ncclRecv");
+    nccl_group_fn f_gs = (nccl_group_fn)dlsym(ctx->rccl_lib, "ncclGroupStart");
+    nccl_group_fn f_ge = (nccl_group_fn)dlsym(ctx->rccl_lib, "ncclGroupEnd");
+    if (!f_send || !f_recv || !f_gs || !f_ge) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_halo_exchange: ncclSend/ncclRecv/ncclGroup* missing");
+    uint2* st = (uint2*)staging;
+    if (snd.n) {
+        const int bx = (max_s + 255) / 256 > 256 ? 256 : (max_s + 255) / 256;
+        hipLaunchKernelGGL(k_halo_copy<true>, dim3(bx, snd.n), dim3(256), 0, ctx->stream, (uint2*)plane, (int)pitch, st, snd);
+        pbr_status r = pbr::launched(ctx, "k_halo_copy<pack>");
+        if (r) return r;
+    }
+    if (f_gs() != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclGroupStart failed");
+    int rc = 0;
+    for (int k = 0; k < snd.n && rc == 0; k++) rc = f_send(st + snd.off[k], (size_t)snd.w[k] * snd.h[k] * 8, NCCL_INT8, peer_of_s[k], ctx->comm, ctx->stream);
+    for (int k = 0; k < rcv.n && rc == 0; k++) rc = f_recv(st + rcv.off[k], (size_t)rcv.w[k] * rcv.h[k] * 8, NCCL_INT8, peer_of_r[k], ctx->comm, ctx->stream);
+    const int ge = f_ge();
+    if (rc != 0 || ge != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclSend/ncclRecv group failed");
+    if (rcv.n) {
+        const int bx = (max_r + 255) / 256 > 256 ? 256 : (max_r + 255) / 256;
+        hipLaunchKernelGGL(k_halo_copy<false>, dim3(bx, rcv.n), dim3(256), 0, ctx->stream, (uint2*)plane, (int)pitch, st, rcv);
+        pbr_status r = pbr::launched(ctx, "k_halo_copy<unpack>");
+        if (r) return r;
+    }
+    return PBR_OK;
+}
+
+// The two halves of pbr_halo_exchange as separate calls, for transports other than the context's RCCL communicator
+// (tests, torch.distributed): pack = every send rectangle -> staging; unpack = staging -> every recv rectangle.  The
+// staging layout is the one pbr_halo_exchange uses: all send rectangles in peer order, then all recv rectangles.
+pbr_status pbr_halo_pack(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
+                         const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes, int unpack) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, plane && pitch >= 1 && rows >= 1, "pbr_halo_pack: null plane");
+    if (n_peers == 0) return PBR_OK;
+    PBR_REQUIRE(ctx, peers && n_peers <= (uint32_t)HALO_MAX_PEERS, "pbr_halo_pack: bad peer list");
+    PBR_REQUIRE(ctx, staging && staging_bytes >= pbr_halo_staging_bytes(peers, n_peers), "pbr_halo_pack: staging area too small");
+    HaloRects rc{};
+    uint32_t off = 0;
+    int mx = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        for (uint32_t i = 0; i < n_peers; i++) {
+            const uint32_t* q = pass == 0 ? peers[i].send : peers[i].recv;
+            PBR_REQUIRE(ctx, q[0] + q[2] <= pitch && q[1] + q[3] <= rows, "pbr_halo_pack: rectangle outside the plane");
+            if (!(q[2] && q[3])) continue;
+            if ((pass == 1) == (unpack != 0)) {
+                const int k = rc.n++;
+                rc.x[k] = (int)q[0]; rc.y[k] = (int)q[1]; rc.w[k] = (int)q[2]; rc.h[k] = (int)q[3]; rc.off[k] = off;
+                if (rc.w[k] * rc.h[k] > mx) mx = rc.w[k] * rc.h[k];
+            }
+            off += q[2] * q[3];
+        }
+    }
+    if (!rc.n) return PBR_OK;
+    const int bx = (mx + 255) / 256 > 256 ? 256 : (mx + 255) / 256;
+    if (unpack) hipLaunchKernelGGL(k_halo_copy<false>, dim3(bx, rc.n), dim3(256), 0, ctx->stream, (uint2*)plane, (int)pitch, (uint2*)staging, rc);
+    else hipLaunchKernelGGL(k_halo_copy<true>, dim3(bx, rc.n), dim3(256), 0, ctx->stream, (uint2*)plane, (int)pitch, (uint2*)staging, rc);
+    return pbr::launched(ctx, "k_halo_copy");
 }
 
 }  // extern "C"

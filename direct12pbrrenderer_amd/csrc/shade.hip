@@ -42,6 +42,7 @@ struct ShadeParams {
     const pbr_light* lights;
     pbr_half* hdr;
     uint32_t hdr_pitch;
+    float* hdr_f32;        // F32OUT instantiations only (pbr_deferred_shade_f32): the colour BEFORE the fp16 store
 };
 
 __device__ __forceinline__ float sign_custom(float x) { return x < 0.0f ? -1.0f : 1.0f; }   // global.hlsli:85-88 (Q22)
@@ -123,7 +124,7 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 //        S1_c = sum col_c X (1-f5), S2_c = sum col_c X s, S3_c = sum col_c X s f5,   s = NdotL/(T A B)
 //   3. material: re-reads the A/C planes (L2 hits) and folds the sums;
 //   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
-template <bool STAGED_LISTS, int LSTRIDE>
+template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint16_t* lists, const uint32_t* mip_off,
                                             int tile_x0, int tile_y0, int tiles_x, int n_lights, bool q_safe, uint32_t px, uint32_t py) {
     const size_t gi = (size_t)py * p.pitch + px;
@@ -344,12 +345,13 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         out.z += envc.z * (F0.z * la + lb);
     }
 #endif
-    store_h4(p.hdr + 4 * ((size_t)py * p.hdr_pitch + px), f4(out.x, out.y, out.z, 1.0f));
+    if (F32OUT) *reinterpret_cast<float4*>(p.hdr_f32 + 4 * ((size_t)py * p.hdr_pitch + px)) = make_float4(out.x, out.y, out.z, 1.0f);
+    else store_h4(p.hdr + 4 * ((size_t)py * p.hdr_pitch + px), f4(out.x, out.y, out.z, 1.0f));
 }
 
 // grid (ceil(w/256), ceil(h/SHADE_ROWS)), block 256.
 // dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 68 B of light lists.
-template <bool STAGED_LISTS, int LSTRIDE>
+template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 5   // 96 VGPRs, no spills: best of 4..8 measured (tools/probe_shade.py)
 #endif
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     const bool q_safe = __syncthreads_and(my_safe) != 0;
     const uint32_t px = bx0 + threadIdx.x;
     if (px >= p.w) return;
-    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py);
+    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py);
 }
 
 extern "C" {
@@ -434,13 +436,16 @@ pbr_status pbr_env_pad(pbr_ctx* ctx, const pbr_half* env, uint32_t size, uint32_
     return PBR_OK;
 }
 
-pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
-                              const pbr_half* lut, uint32_t lut_res,
-                              const pbr_half* env, uint32_t env_size, uint32_t env_mips,
-                              const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
-                              pbr_half* hdr, uint32_t hdr_pitch) {
+}  // extern "C"
+
+template <bool F32OUT>
+static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
+                               const pbr_half* lut, uint32_t lut_res,
+                               const pbr_half* env, uint32_t env_size, uint32_t env_mips,
+                               const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
+                               pbr_half* hdr, float* hdr_f32, uint32_t hdr_pitch) {
     if (!ctx) return PBR_ERR_INVALID;
-    PBR_REQUIRE(ctx, g && tile && gb && lut && env && clusters && hdr, "pbr_deferred_shade: null pointer");
+    PBR_REQUIRE(ctx, g && tile && gb && lut && env && clusters && (F32OUT ? (const void*)hdr_f32 : (const void*)hdr), "pbr_deferred_shade: null pointer");
     PBR_REQUIRE(ctx, gb->A && gb->B && gb->C && gb->depth && gb->stencil, "pbr_deferred_shade: null G-buffer plane");
     PBR_REQUIRE(ctx, tile->w >= 1 && tile->h >= 1 && tile->w <= 65535 && tile->h <= 65535, "pbr_deferred_shade: bad tile size");
     PBR_REQUIRE(ctx, tile->x0 + tile->w <= tile->full_w && tile->y0 + tile->h <= tile->full_h, "pbr_deferred_shade: tile outside frame");
@@ -463,7 +468,7 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
     p.A = gb->A; p.B = gb->B; p.C = gb->C; p.depth = gb->depth; p.stencil = gb->stencil; p.pitch = gb->pitch;
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
     for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)env_padded_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
-    p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch;
+    p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch; p.hdr_f32 = hdr_f32;
     // schedule (see the kernel): long blocks first, short ones for the tail
     static const float big_frac = getenv("PBR_SHADE_BIGFRAC") ? (float)atof(getenv("PBR_SHADE_BIGFRAC")) : 0.85f;
     static const uint32_t rows_small_cfg = getenv("PBR_SHADE_ROWS_SMALL") ? (uint32_t)atoi(getenv("PBR_SHADE_ROWS_SMALL")) : 2u;
@@ -480,11 +485,32 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
     const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
     const size_t lds = (size_t)LIGHT_PLANES * lstride * sizeof(float) + (size_t)max_clusters * LIST_STRIDE_U16 * sizeof(uint16_t);
     const dim3 blk(SHADE_BLOCK);
-    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, nb_big, rows_small);
-    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, nb_big, rows_small);
-    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257>), grid, blk, lds, ctx->stream, p, num_lights, 0, nb_big, rows_small);
-    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1>), grid, blk, lds, ctx->stream, p, num_lights, 0, nb_big, rows_small);
+    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, nb_big, rows_small);
+    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, nb_big, rows_small);
+    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, nb_big, rows_small);
+    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, nb_big, rows_small);
     return launched(ctx, "k_deferred_shade");
+}
+
+extern "C" {
+
+pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
+                              const pbr_half* lut, uint32_t lut_res,
+                              const pbr_half* env, uint32_t env_size, uint32_t env_mips,
+                              const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
+                              pbr_half* hdr, uint32_t hdr_pitch) {
+    return shade_launch<false>(ctx, g, tile, gb, lut, lut_res, env, env_size, env_mips, clusters, lights, num_lights, hdr, nullptr, hdr_pitch);
+}
+
+// Parity probe: the same kernel body, storing float4 instead of rounding to the R16G16B16A16_FLOAT target — what the
+// <= 1e-4 relative L-inf bound of the shaded buffer is stated on.  Not a product path.
+pbr_status pbr_deferred_shade_f32(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
+                                  const pbr_half* lut, uint32_t lut_res,
+                                  const pbr_half* env, uint32_t env_size, uint32_t env_mips,
+                                  const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
+                                  float* hdr_f32, uint32_t hdr_pitch) {
+    if (ctx && hdr_f32 && ((uintptr_t)hdr_f32 & 15u) != 0) return pbr::fail(ctx, PBR_ERR_INVALID, "pbr_deferred_shade_f32: output must be 16-byte aligned");
+    return shade_launch<true>(ctx, g, tile, gb, lut, lut_res, env, env_size, env_mips, clusters, lights, num_lights, nullptr, hdr_f32, hdr_pitch);
 }
 
 }  // extern "C"

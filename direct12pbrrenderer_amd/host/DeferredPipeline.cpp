@@ -34,7 +34,7 @@ std::vector<IRenderPass*> DeferredRenderPipeline::Setup() {
 
 // ----------------------------------------------------------------------------------- IBL precompute
 PreFilterEnvMapPass::PreFilterEnvMapPass(uint32 size) : mSize(size), mReady(false) {
-    if ((size >> (PreFilterEnvMapMipsLevel - 1)) % DispatchGroupSize != 0 && (size >> (PreFilterEnvMapMipsLevel - 1)) < 1)
+    if ((size >> (PreFilterEnvMapMipsLevel - 1)) < 1)   // the coarsest mip must still hold a texel
         throw HipException("PreFilterEnvMapPass: size too small for 5 mips");
     mPrefilterEnvMap = std::make_shared<DeviceTexture2DArray>(size, PreFilterEnvMapMipsLevel, ETextureFormat_R16G16B16A16_FLOAT);
     WritePersistentResource(DeferredPipelineResource::PrefilterEnvMap, mPrefilterEnvMap.get());

@@ -21,11 +21,19 @@ from .structs import (ENV_MIPS, HISTOGRAM_BINS, Global, Tile)
 # a 2x pyramid); 256 also keeps every mip of the extended tile on the full frame's texel grid
 # (multiple of 16 = 2^(BLOOM_MIPS-1)).
 DEFAULT_APRON = 256
+# halo mode: the bloom prefilter of a half-res texel reads full-res pixels 2x-3 .. 2x+2 (five taps one half-res
+# texel apart, each a 2x2 quad: bloom_prefilter.hlsl:17-60), so 4 shaded pixels beyond the interior make the
+# interior's level-1 texels exact; everything further out comes from the neighbours' level 1 (halo exchange).
+HALO_SHADE_APRON = 4
 
 
 @dataclass
 class TileSpec:
-    """Interior tile (x0,y0,w,h) of a full_w x full_h frame and its apron-extended rectangle."""
+    """Interior tile (x0,y0,w,h) of a full_w x full_h frame plus the two rectangles a rank works on:
+    E = interior + `apron` on every side that has a neighbour (clipped to the frame): where the bloom pyramid runs;
+    S = interior + `shade_apron` (clipped): what is shaded.  apron mode: S == E (shade_apron = None);
+    halo mode: shade_apron = HALO_SHADE_APRON and level 1 of the pyramid outside the interior comes from the
+    neighbours (SURVEY 8e option 2)."""
     x0: int
     y0: int
     w: int
@@ -33,7 +41,9 @@ class TileSpec:
     full_w: int
     full_h: int
     apron: int = 0
+    shade_apron: int = None
 
+    # ---- E: the bloom rectangle
     @property
     def ex0(self):
         return max(self.x0 - self.apron, 0)
@@ -59,43 +69,181 @@ class TileSpec:
         return self.ey1 - self.ey0
 
     @property
-    def ix(self):   # interior offset inside the extended rectangle
+    def ix(self):   # interior offset inside E
         return self.x0 - self.ex0
 
     @property
     def iy(self):
         return self.y0 - self.ey0
 
+    # ---- S: the shaded rectangle
+    @property
+    def halo(self):
+        return self.shade_apron is not None and self.apron > 0
 
-def grid_for_world(world, tile_w=16, tile_h=9):
-    """Tile grid (cols, rows) for `world` ranks of equal tiles: the tiles are laid out in ONE row (landscape tiles)
-    or one column (portrait tiles), so that the shared edges are the tiles' short sides and a tile has at most two
-    neighbours.  For 3840x2160 tiles with a 256-px apron that is 6.7 % (2 ranks) / 13.3 % (>= 3 ranks) extra
-    pixels on the busiest rank; a 2x2 / 4x2 arrangement (BASELINE cfg5 cuts its 8K frame that way) costs 19 % / 27 %."""
+    @property
+    def _sa(self):
+        return self.shade_apron if self.halo else self.apron
+
+    @property
+    def sx0(self):
+        return max(self.x0 - self._sa, 0)
+
+    @property
+    def sy0(self):
+        return max(self.y0 - self._sa, 0)
+
+    @property
+    def sx1(self):
+        return min(self.x0 + self.w + self._sa, self.full_w)
+
+    @property
+    def sy1(self):
+        return min(self.y0 + self.h + self._sa, self.full_h)
+
+    @property
+    def sw(self):
+        return self.sx1 - self.sx0
+
+    @property
+    def sh(self):
+        return self.sy1 - self.sy0
+
+    @property
+    def six(self):   # interior offset inside S
+        return self.x0 - self.sx0
+
+    @property
+    def siy(self):
+        return self.y0 - self.sy0
+
+
+def parse_layout(text):
+    """'RxC' (rows x cols, the way BASELINE cfg5 says "tiled 2x4": 2 rows of 4 tiles) -> (cols, rows)."""
+    r, c = text.lower().split("x")
+    return int(c), int(r)
+
+
+def grid_for_world(world, layout=None):
+    """Tile grid (cols, rows) for `world` ranks.  layout: explicit (cols, rows); default = the most square
+    factorisation with cols >= rows (1x1, 2x1, 3x1, 2x2, 3x2, 4x2 ...): the shorter the shared edges, the
+    smaller the apron / halo."""
     if world < 1:
         raise ValueError("world size must be >= 1")
-    return (world, 1) if tile_w >= tile_h else (1, world)
+    if layout is not None:
+        cols, rows = int(layout[0]), int(layout[1])
+        if cols < 1 or rows < 1 or cols * rows != world:
+            raise ValueError(f"layout {cols}x{rows} (cols x rows) does not hold {world} ranks")
+        return cols, rows
+    rows = max(r for r in range(1, int(world ** 0.5) + 1) if world % r == 0)
+    return world // rows, rows
 
 
-def tile_for_rank(rank, world, tile_w, tile_h, apron=DEFAULT_APRON):
-    """Weak scaling: every rank owns one tile_w x tile_h tile of a (cols*tile_w) x (rows*tile_h) frame."""
-    cols, rows = grid_for_world(world, tile_w, tile_h)
-    cx, cy = rank % cols, rank // cols
+def _check_tiling(world, tile_w, tile_h, apron, full_w, full_h):
     if world > 1 and (tile_w % 16 or tile_h % 16 or apron % 16):
         # every bloom mip of the extended tile must sit on the full frame's texel grid (2^(BLOOM_MIPS-1) = 16)
         raise ValueError("tile size and apron must be multiples of 16 for multi-GPU tiling")
-    if cols * tile_w > 65535 or rows * tile_h > 65535:
+    if full_w > 65535 or full_h > 65535:
         raise ValueError("the assembled frame exceeds 65535 pixels on a side")
-    return TileSpec(cx * tile_w, cy * tile_h, tile_w, tile_h, cols * tile_w, rows * tile_h, apron if world > 1 else 0)
+
+
+def tile_for_rank(rank, world, tile_w, tile_h, apron=DEFAULT_APRON, layout=None, halo=False):
+    """Weak scaling: every rank owns one tile_w x tile_h tile of a (cols*tile_w) x (rows*tile_h) frame."""
+    cols, rows = grid_for_world(world, layout)
+    cx, cy = rank % cols, rank // cols
+    _check_tiling(world, tile_w, tile_h, apron, cols * tile_w, rows * tile_h)
+    multi = world > 1
+    return TileSpec(cx * tile_w, cy * tile_h, tile_w, tile_h, cols * tile_w, rows * tile_h, apron if multi else 0,
+                    HALO_SHADE_APRON if (halo and multi) else None)
+
+
+def tile_of_frame(rank, world, frame_w, frame_h, apron=DEFAULT_APRON, layout=None, halo=False):
+    """Strong scaling: a frame_w x frame_h frame cut into cols x rows equal tiles (BASELINE cfg5: 7680x4320,
+    2 rows x 4 cols of 1920x2160)."""
+    cols, rows = grid_for_world(world, layout)
+    if frame_w % cols or frame_h % rows:
+        raise ValueError(f"{frame_w}x{frame_h} does not split into {cols}x{rows} equal tiles")
+    return tile_for_rank(rank, world, frame_w // cols, frame_h // rows, apron, (cols, rows), halo)
+
+
+def halo_plan(rank, world, specs):
+    """Level-1 (half-res) strips rank `rank` exchanges with every other rank, in GLOBAL half-res texel
+    coordinates.  specs: the TileSpec of every rank.  Rank r needs level 1 on E_r/2; it computes it on its
+    interior I_r/2 and receives (E_r/2 intersect I_n/2) from each rank n — which covers E_r/2 exactly, because the
+    interiors partition the frame and E is clipped to it.  Returns [(peer, send_rect, recv_rect)] with rect =
+    (x0, y0, x1, y1) or None; both sides derive the same rectangles from the same specs, so no sizes travel."""
+    def half(x0, y0, x1, y1):
+        return (x0 // 2, y0 // 2, x1 // 2, y1 // 2)
+
+    def isect(a, b):
+        r = (max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3]))
+        return r if r[0] < r[2] and r[1] < r[3] else None
+
+    me = specs[rank]
+    e_me = half(me.ex0, me.ey0, me.ex1, me.ey1)
+    i_me = half(me.x0, me.y0, me.x0 + me.w, me.y0 + me.h)
+    plan = []
+    for n in range(world):
+        if n == rank:
+            continue
+        o = specs[n]
+        recv = isect(e_me, half(o.x0, o.y0, o.x0 + o.w, o.y0 + o.h))
+        send = isect(half(o.ex0, o.ey0, o.ex1, o.ey1), i_me)
+        if recv or send:
+            plan.append((n, send, recv))
+    return plan
+
+
+class HaloTransport:
+    """How the level-1 strips travel between ranks in halo mode.  `exchange(frame)` is enqueued between
+    pbr_bloom_prefilter_rect and pbr_bloom_tiled.
+      "capi"  : pbr_halo_exchange — RCCL send/recv on the context's own communicator (pbr_comm_init);
+      "torch" : pbr_halo_pack + torch.distributed P2P (RCCL with the nccl backend) + unpack;
+      "host"  : like "torch" but through host copies — gloo rehearsals with several ranks on one GPU."""
+
+    def __init__(self, kind, dist=None):
+        assert kind in ("capi", "torch", "host")
+        self.kind, self.dist = kind, dist
+
+    def exchange(self, fr):
+        ctx, a1, pitch, rows = fr.ctx, fr.level1, fr.spec.ew // 2, fr.spec.eh // 2
+        if not fr.halo_n:
+            return
+        if self.kind == "capi":
+            ctx.halo_exchange(a1, pitch, rows, fr.halo_peers, fr.halo_n, fr.halo_staging)
+            return
+        dist = self.dist
+        ctx.halo_pack(a1, pitch, rows, fr.halo_peers, fr.halo_n, fr.halo_staging, unpack=False)
+        ops, off, host = [], 0, self.kind == "host"
+        st = fr.halo_staging
+        if host:
+            ctx.sync()
+            st = st.cpu()
+        for peer, send, _ in fr.halo_plan_local:
+            if send:
+                n = send[2] * send[3]
+                ops.append(dist.P2POp(dist.isend, st[off:off + n], peer))
+                off += n
+        for peer, _, recv in fr.halo_plan_local:
+            if recv:
+                n = recv[2] * recv[3]
+                ops.append(dist.P2POp(dist.irecv, st[off:off + n], peer))
+                off += n
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if host:
+            fr.halo_staging.copy_(st)
+        ctx.halo_pack(a1, pitch, rows, fr.halo_peers, fr.halo_n, fr.halo_staging, unpack=True)
 
 
 class DeferredFrame:
     """Owns the device buffers of one rank and runs the per-frame passes through the C ABI."""
 
     def __init__(self, ctx: PbrContext, spec: TileSpec, g: Global, lights_np, lut, lut_res, env, env_size,
-                 env_mips=ENV_MIPS, allreduce=None, sky=None):
+                 env_mips=ENV_MIPS, allreduce=None, sky=None, all_specs=None, rank=0, halo_transport=None):
         """sky: optional (cube tensor fp32 RGBA with mips, size, mips) — resolved on stencil == 0 pixels
-        before the shade like the reference's SkyboxPass; without it those pixels keep what the buffer holds."""
+        before the shade like the reference's SkyboxPass; without it those pixels keep what the buffer holds.
+        Halo mode (spec.halo): all_specs = the TileSpec of every rank, rank = this one, halo_transport = HaloTransport."""
         self.ctx, self.spec, self.g = ctx, spec, g
         self.sky = sky
         self.n_lights = int(len(lights_np))
@@ -106,27 +254,40 @@ class DeferredFrame:
         self.allreduce = allreduce
         ew, eh = spec.ew, spec.eh
         self.clusters = ctx.alloc_clusters()
-        self.hdr = ctx.zeros((eh, ew, 4), torch.float16)
+        self.hdr = ctx.zeros((spec.sh, spec.sw, 4), torch.float16)   # covers S (== E in apron mode)
         self.chain_a = ctx.alloc_bloom_chain(ew, eh)
         self.chain_b = ctx.alloc_bloom_chain(ew, eh)
         self.hist = ctx.zeros((HISTOGRAM_BINS,), torch.int32)
         self.avg = ctx.zeros((1,), torch.float32)
         self.ldr = ctx.zeros((spec.h, spec.w), torch.int32)
         self.gb = None
-        self.tile = Tile(spec.ex0, spec.ey0, ew, eh, spec.full_w, spec.full_h)
+        self.tile = Tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h)
+        self.halo_transport = halo_transport
+        if spec.halo:
+            assert all_specs is not None and halo_transport is not None, "halo mode needs every rank's TileSpec and a transport"
+            from .structs import bloom_level_offset
+            o = bloom_level_offset(ew, eh, 1)
+            self.level1 = self.chain_a[o:o + (ew // 2) * (eh // 2)]   # level 1 of chain A: the plane the halo fills
+            hx, hy = spec.ex0 // 2, spec.ey0 // 2
+
+            def loc(r):   # global half-res rect (x0,y0,x1,y1) -> (x, y, w, h) in the level-1 plane of E
+                return None if r is None else (r[0] - hx, r[1] - hy, r[2] - r[0], r[3] - r[1])
+            self.halo_plan_local = [(n, loc(snd), loc(rcv)) for n, snd, rcv in halo_plan(rank, len(all_specs), all_specs)]
+            self.halo_peers, self.halo_n = ctx.halo_peers(self.halo_plan_local)
+            self.halo_staging = ctx.zeros((max(ctx.halo_staging_bytes(self.halo_peers, self.halo_n) // 8, 1), 4), torch.float16)
 
     def upload_gbuffer(self, gb_np):
-        """gb_np: dict of numpy planes covering the EXTENDED rectangle (eh x ew)."""
-        assert gb_np["A"].shape == (self.spec.eh, self.spec.ew)
+        """gb_np: dict of numpy planes covering the SHADED rectangle S (sh x sw; the extended rectangle in apron mode)."""
+        assert gb_np["A"].shape == (self.spec.sh, self.spec.sw)
         self.gb = {k: self.ctx.upload(v) for k, v in gb_np.items()}
 
     def set_prev_luminance(self, v):
         self.avg.fill_(float(v))
 
-    # interior views (pointer + pitch) of the extended HDR buffer
+    # interior views (pointer + pitch) of the HDR buffer
     def _hdr_interior_ptr(self):
         s = self.spec
-        return self.hdr.data_ptr() + 8 * (s.iy * s.ew + s.ix)
+        return self.hdr.data_ptr() + 8 * (s.siy * s.sw + s.six)
 
     def clustered(self):
         self.ctx.clustered(self.g, self.lights, self.n_lights, self.clusters)
@@ -134,25 +295,50 @@ class DeferredFrame:
     def skybox(self):
         s = self.spec
         cube, size, mips = self.sky
-        self.ctx.skybox(self.g, self.tile, cube, size, mips, self.gb["stencil"], s.ew, self.hdr, s.ew)
+        self.ctx.skybox(self.g, self.tile, cube, size, mips, self.gb["stencil"], s.sw, self.hdr, s.sw)
 
     def shade(self):
         s = self.spec
-        self.ctx.deferred_shade(self.g, self.tile, self.gb, s.ew, self.lut, self.lut_res, self.env, self.env_size,
-                                self.env_mips, self.clusters, self.lights, self.n_lights, self.hdr, s.ew)
+        self.ctx.deferred_shade(self.g, self.tile, self.gb, s.sw, self.lut, self.lut_res, self.env, self.env_size,
+                                self.env_mips, self.clusters, self.lights, self.n_lights, self.hdr, s.sw)
 
     def bloom(self):
         s = self.spec
-        self.ctx.bloom(self.hdr, s.ew, s.eh, s.ew, self.chain_a, self.chain_b)
+        if s.halo:
+            self.bloom_halo(histogram=False)
+        else:
+            self.ctx.bloom(self.hdr, s.ew, s.eh, s.ew, self.chain_a, self.chain_b)
 
     def histogram(self):
         s = self.spec
-        self.ctx.lum_histogram(self._hdr_interior_ptr(), s.w, s.h, s.ew, self.hist)
+        self.ctx.lum_histogram(self._hdr_interior_ptr(), s.w, s.h, s.sw, self.hist)
+
+    # ---- halo mode: prefilter the interior, fetch the rest of level 1 from the neighbours, run levels 1..4 on E
+    def halo_prefilter(self):
+        s = self.spec
+        self.ctx.bloom_prefilter_rect(self.hdr, s.sw, s.sh, s.sw, self.level1, s.ew // 2, (s.sx0 - s.ex0) // 2, (s.sy0 - s.ey0) // 2,
+                                      (s.six // 2, s.siy // 2, s.w // 2, s.h // 2))
+
+    def halo_exchange(self):
+        self.halo_transport.exchange(self)
+
+    def halo_pyramid(self, histogram=True):
+        s = self.spec
+        self.ctx.bloom_tiled(self.hdr, s.sw, (s.sx0 - s.ex0, s.sy0 - s.ey0, s.sw, s.sh), s.ew, s.eh, self.chain_a, self.chain_b,
+                             (s.ix, s.iy, s.w, s.h), self.hist if histogram else None)
+
+    def bloom_halo(self, histogram=True):
+        self.halo_prefilter()
+        self.halo_exchange()
+        self.halo_pyramid(histogram)
 
     def bloom_histogram(self):
         """Bloom with the interior-tile luminance histogram accumulated in its final kernel."""
         s = self.spec
-        self.ctx.bloom_histogram(self.hdr, s.ew, s.eh, s.ew, self.chain_a, self.chain_b, (s.ix, s.iy, s.w, s.h), self.hist)
+        if s.halo:
+            self.bloom_halo(histogram=True)
+        else:
+            self.ctx.bloom_histogram(self.hdr, s.ew, s.eh, s.ew, self.chain_a, self.chain_b, (s.ix, s.iy, s.w, s.h), self.hist)
 
     def average(self):
         s = self.spec
@@ -160,7 +346,7 @@ class DeferredFrame:
 
     def tonemap(self):
         s = self.spec
-        self.ctx.tonemap(self._hdr_interior_ptr(), s.w, s.h, s.ew, self.avg, self.ldr, s.w)
+        self.ctx.tonemap(self._hdr_interior_ptr(), s.w, s.h, s.sw, self.avg, self.ldr, s.w)
 
     def render(self, shade_events=None):
         """One frame: every per-frame dispatch of the reference, in the frame graph's order.
@@ -185,7 +371,7 @@ class DeferredFrame:
     # ---- read-back helpers for tests ---------------------------------------------------------------
     def hdr_interior(self):
         s = self.spec
-        return self.hdr[s.iy:s.iy + s.h, s.ix:s.ix + s.w].cpu().numpy()
+        return self.hdr[s.siy:s.siy + s.h, s.six:s.six + s.w].cpu().numpy()
 
     def ldr_numpy(self):
         return self.ldr.cpu().numpy().view(np.uint32)

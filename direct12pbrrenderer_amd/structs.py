@@ -66,6 +66,11 @@ class GBuffer(C.Structure):
     ]
 
 
+class HaloPeer(C.Structure):
+    """pbr_halo_peer: rectangles {x, y, w, h} of the level-1 plane exchanged with rank `rank`."""
+    _fields_ = [("rank", C.c_int32), ("send", C.c_uint32 * 4), ("recv", C.c_uint32 * 4)]
+
+
 class CubeF32(C.Structure):
     _fields_ = [("data", C.c_void_p), ("size", C.c_uint32), ("mips", C.c_uint32)]
 

@@ -149,6 +149,10 @@ pbr_status  pbr_ctx_use_own_stream(pbr_ctx* ctx);
 const char* pbr_last_error(const pbr_ctx* ctx);
 pbr_status  pbr_sync(pbr_ctx* ctx);
 const char* pbr_version(void);
+/* NULL, or why this process cannot use the library: a second ROCm installation is mapped next to the HIP runtime in
+ * use (PyTorch ships its own libamdhip64; it must be loaded first).  pbr_ctx_create refuses with
+ * PBR_ERR_UNSUPPORTED in that case and prints this text. */
+const char* pbr_runtime_error(void);
 
 /* ---- one-shot IBL precompute --------------------------------------------------------------- */
 /* precompute_brdf.hlsl:20-62 dispatched by PrecomputeBRDFPass::Execute (DeferredPipeline.cpp:117-136).
@@ -211,6 +215,16 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
                               const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
                               pbr_half* hdr, uint32_t hdr_pitch);
 
+/* Parity probe (not a product path): the same shade, storing the fp32 colour (float4 per pixel, alpha 1, pitch
+ * hdr_pitch pixels, 16-byte aligned) instead of rounding it to the half4 target — the buffer the <= 1e-4 relative
+ * L-inf parity bound is stated on. */
+pbr_status pbr_deferred_shade_f32(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile,
+                                  const pbr_gbuffer* gb,
+                                  const pbr_half* lut, uint32_t lut_res,
+                                  const pbr_half* env_padded, uint32_t env_size, uint32_t env_mips,
+                                  const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
+                                  float* hdr_f32, uint32_t hdr_pitch);
+
 /* ---- SURVEY 8f "next" rows: the two raster passes either side of the shade, minus rasterization ---- */
 /* skybox.hlsl:12-28 (SkyboxPass::Execute, DeferredPipeline.cpp:59-75): the sky sphere is drawn at the far
  * plane with depth test and no depth write, i.e. it lands exactly on the pixels geometry did not cover
@@ -253,6 +267,22 @@ pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pb
 pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                      pbr_half* chain_a, pbr_half* chain_b, float threshold, float knee);
 
+/* bloom_prefilter.hlsl on part of the image (multi-GPU halo path): the half-res outputs rect = {x, y, w, h} of the
+ * w x h image `hdr` are computed and stored at out[(out_y + y) * out_pitch + (out_x + x)] — a tile writes the level-1
+ * texels of its interior into the level-1 plane of its extended rectangle. */
+pbr_status pbr_bloom_prefilter_rect(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                    pbr_half* out, uint32_t out_pitch, uint32_t out_x, uint32_t out_y,
+                                    const uint32_t rect[4], float threshold, float knee);
+/* BloomPass::Execute minus its first dispatch, on the extended rectangle E (ew x eh, a multiple of 16 and <= 8192 on
+ * a side) of a tile: level 1 of chain_a (offset pbr_bloom_level_offset(ew, eh, 1)) must hold the prefiltered image of
+ * ALL of E — the interior from pbr_bloom_prefilter_rect, the rest from the neighbouring tiles (pbr_halo_exchange).
+ * Runs the 3 + 3 level pairs on E and merges (DeferredPipeline.cpp:521-570) only merge_rect = {x, y, w, h} of E into
+ * hdr, which covers hdr_rect of E (hdr[0] = texel (hdr_rect.x, hdr_rect.y), pitch hdr_pitch pixels).  hist256 != NULL:
+ * the luminance histogram of the merged pixels is added (pbr_lum_histogram).  Chains are scratch. */
+pbr_status pbr_bloom_tiled(pbr_ctx* ctx, pbr_half* hdr, uint32_t hdr_pitch, const uint32_t hdr_rect[4],
+                           uint32_t ew, uint32_t eh, pbr_half* chain_a, pbr_half* chain_b, const uint32_t merge_rect[4],
+                           float min_log, float inv_range, uint32_t* hist256);
+
 /* pbr_bloom + the luminance histogram (pbr_lum_histogram) of rect = {x, y, w, h} of the bloomed
  * image, accumulated inside the final bloom kernel (saves one full read of the HDR buffer).
  * ADDS into hist256 like the separate pass. */
@@ -276,6 +306,31 @@ pbr_status pbr_comm_unique_id(void* out_128_bytes);
 pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_id_128_bytes);
 /* ncclAllReduce(sum, uint32, 256) on the ctx stream; no-op without a communicator / world 1 */
 pbr_status pbr_allreduce_hist(pbr_ctx* ctx, uint32_t* hist256);
+
+/* Halo exchange of half4 rectangles of one plane (level 1 of the bloom pyramid) with neighbouring tiles: for every
+ * peer, `send` = {x, y, w, h} of the plane that goes to rank `rank`, `recv` = the rectangle that arrives from it
+ * (w == 0: nothing).  Both sides derive the rectangles from the tile layout, so sizes never travel.  One pack launch,
+ * one ncclGroup of ncclSend / ncclRecv over xGMI, one unpack launch, all on the ctx stream.
+ * staging: device scratch of pbr_halo_staging_bytes(); at most 16 peers. */
+typedef struct pbr_halo_peer {
+    int32_t  rank;
+    uint32_t send[4];
+    uint32_t recv[4];
+} pbr_halo_peer;
+size_t     pbr_halo_staging_bytes(const pbr_halo_peer* peers, uint32_t n_peers);
+pbr_status pbr_halo_exchange(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
+                             const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes);
+/* the pack (unpack = 0: send rectangles -> staging) and unpack (unpack = 1: staging -> recv rectangles) halves on
+ * their own, for a transport other than the context's communicator.  Staging layout: all send rectangles in peer
+ * order, then all recv rectangles. */
+pbr_status pbr_halo_pack(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
+                         const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes, int unpack);
+
+/* ---- measurement aid ---------------------------------------------------------------------------- */
+/* Streaming read of `bytes` bytes (16-byte loads, grid-stride over `blocks` blocks of 256 lanes, one xor word per
+ * block into sink[blocks]) on the ctx stream: the kernel bench.py times to report the MEASURED HBM-read bandwidth of
+ * the device next to the 8 TB/s nominal peak.  buf 16-byte aligned. */
+pbr_status pbr_membench_read(pbr_ctx* ctx, const void* buf, size_t bytes, uint32_t* sink, uint32_t blocks);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ def lib():
         L.orc_cube_gen_mips.argtypes = [_vp, _u32, _u32]
         L.orc_prefilter_env.argtypes = [_vp, _u32, _u32, _u32, _u32, _vp]
         L.orc_prefilter_env_mip.argtypes = [_vp, _u32, _u32, _u32, _u32, _u32, _vp]
+        L.orc_prefilter_env_texels.argtypes = [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _vp]
         L.orc_sh9_project.argtypes = [_vp, _u32, _vp]
         L.orc_sh9_project_mc.argtypes = [_vp, _u32, _u32, _u32, _vp]
         L.orc_cluster_build.argtypes = [C.POINTER(Global), _vp]
@@ -192,6 +193,14 @@ def prefilter_env_mip(sky, sky_size, sky_mips, size, mips, mip):
     s = size >> mip
     out = np.zeros((6 * s * s, 4), dtype=np.float16)
     _ok(lib().orc_prefilter_env_mip(_p(sky), sky_size, sky_mips, size, mips, mip, _p(out)), "prefilter_env_mip")
+    return out
+
+
+def prefilter_env_texels(sky, sky_size, sky_mips, size, mips, mip, texels):
+    """env_map_gen.hlsl on the chosen texels (index (face * s + y) * s + x) of one mip -> [count, 4] half."""
+    texels = np.ascontiguousarray(texels, dtype=np.uint32)
+    out = np.zeros((len(texels), 4), dtype=np.float16)
+    _ok(lib().orc_prefilter_env_texels(_p(sky), sky_size, sky_mips, size, mips, mip, _p(texels), len(texels), _p(out)), "prefilter_env_texels")
     return out
 
 

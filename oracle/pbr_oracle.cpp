@@ -530,6 +530,43 @@ int orc_cube_gen_mips(float* cube, uint32_t size, uint32_t mips) {
 }
 
 // ==================================================================== a4: env_map_gen.hlsl:50-105
+namespace {
+// one output texel (index t = (face * s + y) * s + x of mip `mip`) of env_map_gen.hlsl::cs_main
+static inline void prefilter_texel(const CubeF32& cube, uint32_t sky_size, uint32_t sky_mips, uint32_t size, uint32_t s,
+                                   float Roughness, int64_t t, uint16_t* out4) {
+    uint32_t face = (uint32_t)(t / ((int64_t)s * s));
+    uint32_t y = (uint32_t)((t / s) % s), x = (uint32_t)(t % s);
+    // xy = dispatch_thread_id.xy / texture_size  (texel CORNER, Q8)
+    float u = (float)x / (float)s, v = (float)y / (float)s;
+    V3 R = normalize3(cube_dir_raw(face, 2.0f * u - 1.0f, 2.0f * v - 1.0f));
+    V3 N = R, V = R;
+    V3 total = v3(0, 0, 0);
+    float total_w = 0.0f;
+    for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
+        float xi_x = (float)i / (float)PBR_SAMPLE_COUNT;
+        float xi_y = radical_inverse_vdc(i);
+        V3 H = ggx_important_sample(Roughness, N, xi_x, xi_y);
+        V3 L = normalize3(H * (2.0f * dot3(V, H)) - V);
+        float NdotL = fmaxf(dot3(N, L), 0.0f);
+        if (NdotL > 0.0f) {
+            float NdotH = fmaxf(dot3(N, H), 0.0f);
+            float HdotV = fmaxf(dot3(H, V), 0.0f);
+            float D = distribution_ggx(NdotH, Roughness);
+            float pdf = D * NdotH / (4.0f * HdotV + 0.0001f);
+            // texel_sa uses the base size for every mip (Q8)
+            float texel_sa = 4.0f * PI_F / ((float)(6u * size * size));
+            float sample_sa = 1.0f / ((float)PBR_SAMPLE_COUNT * pdf + 0.0001f);
+            float lod = Roughness == 0.0f ? 0.0f : 0.5f * log2f(sample_sa / texel_sa);
+            F4 c = cube_trilinear(sky_size, sky_mips, L, lod, cube);
+            total = total + v3(c.x, c.y, c.z) * NdotL;
+            total_w += NdotL;
+        }
+    }
+    total = total / total_w;
+    store_h4(out4, f4(total.x, total.y, total.z, 1.0f));
+}
+}  // namespace
+
 int orc_prefilter_env_mip(const float* sky, uint32_t sky_size, uint32_t sky_mips,
                           uint32_t size, uint32_t mips, uint32_t mip, uint16_t* out) {
     if (!sky || !out || mips < 1 || mip >= mips || (size >> mip) == 0) return PBR_ERR_INVALID;
@@ -539,38 +576,21 @@ int orc_prefilter_env_mip(const float* sky, uint32_t sky_size, uint32_t sky_mips
     const float Roughness = mips > 1 ? (float)mip / (float)(mips - 1) : 0.0f;
     const int64_t n = (int64_t)6 * s * s;
 #pragma omp parallel for schedule(dynamic, 64)
-    for (int64_t t = 0; t < n; t++) {
-        uint32_t face = (uint32_t)(t / ((int64_t)s * s));
-        uint32_t y = (uint32_t)((t / s) % s), x = (uint32_t)(t % s);
-        // xy = dispatch_thread_id.xy / texture_size  (texel CORNER, Q8)
-        float u = (float)x / (float)s, v = (float)y / (float)s;
-        V3 R = normalize3(cube_dir_raw(face, 2.0f * u - 1.0f, 2.0f * v - 1.0f));
-        V3 N = R, V = R;
-        V3 total = v3(0, 0, 0);
-        float total_w = 0.0f;
-        for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
-            float xi_x = (float)i / (float)PBR_SAMPLE_COUNT;
-            float xi_y = radical_inverse_vdc(i);
-            V3 H = ggx_important_sample(Roughness, N, xi_x, xi_y);
-            V3 L = normalize3(H * (2.0f * dot3(V, H)) - V);
-            float NdotL = fmaxf(dot3(N, L), 0.0f);
-            if (NdotL > 0.0f) {
-                float NdotH = fmaxf(dot3(N, H), 0.0f);
-                float HdotV = fmaxf(dot3(H, V), 0.0f);
-                float D = distribution_ggx(NdotH, Roughness);
-                float pdf = D * NdotH / (4.0f * HdotV + 0.0001f);
-                // texel_sa uses the base size for every mip (Q8)
-                float texel_sa = 4.0f * PI_F / ((float)(6u * size * size));
-                float sample_sa = 1.0f / ((float)PBR_SAMPLE_COUNT * pdf + 0.0001f);
-                float lod = Roughness == 0.0f ? 0.0f : 0.5f * log2f(sample_sa / texel_sa);
-                F4 c = cube_trilinear(sky_size, sky_mips, L, lod, cube);
-                total = total + v3(c.x, c.y, c.z) * NdotL;
-                total_w += NdotL;
-            }
-        }
-        total = total / total_w;
-        store_h4(out + 4 * t, f4(total.x, total.y, total.z, 1.0f));
-    }
+    for (int64_t t = 0; t < n; t++) prefilter_texel(cube, sky_size, sky_mips, size, s, Roughness, t, out + 4 * t);
+    return PBR_OK;
+}
+// the same dispatch evaluated on `count` chosen texels of mip `mip` only (texel index = (face * s + y) * s + x):
+// what makes a 512^2 x 1024-sample chain checkable on the CPU in seconds
+int orc_prefilter_env_texels(const float* sky, uint32_t sky_size, uint32_t sky_mips, uint32_t size, uint32_t mips,
+                             uint32_t mip, const uint32_t* texels, uint32_t count, uint16_t* out) {
+    if (!sky || !out || !texels || mips < 1 || mip >= mips || (size >> mip) == 0) return PBR_ERR_INVALID;
+    CubeF32 cube{sky, sky_size, sky_mips};
+    const uint32_t s = size >> mip;
+    const float Roughness = mips > 1 ? (float)mip / (float)(mips - 1) : 0.0f;
+    for (uint32_t k = 0; k < count; k++)
+        if (texels[k] >= 6u * s * s) return PBR_ERR_INVALID;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t k = 0; k < (int64_t)count; k++) prefilter_texel(cube, sky_size, sky_mips, size, s, Roughness, (int64_t)texels[k], out + 4 * k);
     return PBR_OK;
 }
 int orc_prefilter_env(const float* sky, uint32_t sky_size, uint32_t sky_mips,
@@ -1035,7 +1055,8 @@ int orc_bloom_upsample_add(const uint16_t* upper, uint32_t uw, uint32_t uh,
 // bloom_merge.hlsl:7-11
 int orc_bloom_merge(uint16_t* hdr, uint32_t pitch, const uint16_t* in, uint32_t w, uint32_t h) {
     if (!hdr || !in) return PBR_ERR_INVALID;
-    for (uint32_t y = 0; y < h; y++)
+#pragma omp parallel for schedule(static)
+    for (int64_t y = 0; y < (int64_t)h; y++)
         for (uint32_t x = 0; x < w; x++) {
             uint16_t* p = hdr + 4 * ((size_t)y * pitch + x);
             store_h4(p, load_h4(p) + load_h4(in + 4 * ((size_t)y * w + x)));
@@ -1077,11 +1098,19 @@ int orc_bloom(uint16_t* hdr, uint32_t w, uint32_t h, uint32_t pitch,
 int orc_lum_histogram(const uint16_t* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                       float min_log, float inv_range, uint32_t* hist) {
     if (!hdr || !hist) return PBR_ERR_INVALID;
-    for (uint32_t y = 0; y < h; y++)
-        for (uint32_t x = 0; x < w; x++) {
-            F4 c = load_h4(hdr + 4 * ((size_t)y * pitch + x));
-            hist[luminance_bin(luminance(v3(c.x, c.y, c.z)), min_log, inv_range)]++;
-        }
+    // integer counts: a per-thread histogram folded at the end gives the same result in any order
+#pragma omp parallel
+    {
+        uint32_t local[PBR_HISTOGRAM_BINS] = {0};
+#pragma omp for schedule(static) nowait
+        for (int64_t y = 0; y < (int64_t)h; y++)
+            for (uint32_t x = 0; x < w; x++) {
+                F4 c = load_h4(hdr + 4 * ((size_t)y * pitch + x));
+                local[luminance_bin(luminance(v3(c.x, c.y, c.z)), min_log, inv_range)]++;
+            }
+#pragma omp critical
+        for (int i = 0; i < PBR_HISTOGRAM_BINS; i++) hist[i] += local[i];
+    }
     return PBR_OK;
 }
 

@@ -73,6 +73,8 @@ int orc_prefilter_env(const float* sky, uint32_t sky_size, uint32_t sky_mips,
 /* one output mip only (for bounded tests / baseline timing) */
 int orc_prefilter_env_mip(const float* sky, uint32_t sky_size, uint32_t sky_mips,
                           uint32_t size, uint32_t mips, uint32_t mip, uint16_t* out_mip_rgba);
+int orc_prefilter_env_texels(const float* sky, uint32_t sky_size, uint32_t sky_mips, uint32_t size, uint32_t mips,
+                             uint32_t mip, const uint32_t* texels, uint32_t count, uint16_t* out);   /* a4 on chosen texels */
 int orc_sh9_project(const float* sky_mip0, uint32_t size, float out_pack[28]);     /* a5 quadrature */
 int orc_sh9_project_mc(const float* sky_mip0, uint32_t size, uint32_t seed, uint32_t samples,
                        float out_pack[28]);                                        /* a5 seeded MC restatement */

@@ -43,3 +43,17 @@ def half_ulp_diff(a, b):
         u = np.ascontiguousarray(x, dtype=np.float16).view(np.uint16).astype(np.int32)
         return np.where(u & 0x8000, 0x8000 - u, u)
     return np.abs(key(a) - key(b))
+
+
+def oracle_bloom_from_level1(orc, a1):
+    """BloomPass::Execute after its prefilter dispatch, composed from the oracle's stage functions
+    (DeferredPipeline.cpp:428-570): a1 = level 1 [h/2, w/2, 4] half; returns A0 [h, w, 4] (what bloom_merge adds)."""
+    a = {1: a1}
+    for l in (1, 2, 3):                      # B(l+1) = H(A l); A(l+1) = V(B(l+1))
+        oh, ow = a[l].shape[0] >> 1, a[l].shape[1] >> 1
+        a[l + 1] = orc.blur_v(orc.blur_h(a[l], ow, oh), ow, oh)
+    for l in (3, 2, 1):                      # B l = H(A l) + H(A(l+1)); A l = V(B l)
+        oh, ow = a[l].shape[:2]
+        a[l] = orc.blur_v(orc.bloom_upsample_add(a[l], a[l + 1]), ow, oh)
+    h, w = a[1].shape[0] * 2, a[1].shape[1] * 2
+    return orc.blur_v(orc.blur_h(a[1], w, h), w, h)

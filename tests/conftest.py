@@ -29,6 +29,14 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden2():
+    """Full-size IBL fixtures (tests/golden/make_golden_v2.py): LUT 256^2 / 512^2 CRC + samples, prefiltered env
+    512^2 x 5 sampled texels, SH9 of the 512^2 bench sky."""
+    path = os.path.join(ROOT, "tests", "golden", "golden_v2.npz")
+    return dict(np.load(path, allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
 def ibl(orc):
     import common
     return common.small_ibl(orc)

@@ -63,6 +63,48 @@ def test_brdf_lut_512_reference_default(ctx, golden):
     assert np.abs(got[:, 0, 1].astype(np.float64) - B).max() <= 5e-4
 
 
+@pytest.mark.parametrize("res", [256, 512])
+def test_brdf_lut_whole_plane_vs_oracle(ctx, orc, golden2, res):
+    """cfg1 (256^2) and the reference's real size (512^2): EVERY texel within 1 fp16 ULP of the oracle plane, whose
+    CRC and 64 sampled texels are pinned by tests/golden/golden_v2.npz."""
+    import zlib
+    want = orc.brdf_lut(res)
+    assert np.uint32(zlib.crc32(np.ascontiguousarray(want).tobytes())) == golden2[f"lut{res}_crc"]
+    got = to_np_half(ctx.brdf_lut(res))
+    d = common.half_ulp_diff(got, want)
+    assert d.max() <= 1, f"LUT {res}: max {d.max()} ULP, {(d > 1).sum()} texels over"
+    idx = golden2[f"lut{res}_idx"]
+    assert common.half_ulp_diff(got.reshape(-1, 2)[idx], golden2[f"lut{res}_texels"]).max() <= 1
+    print(f"LUT {res}^2: {(d == 0).mean() * 100:.2f} % of the plane bit-identical to the oracle, max 1 ULP")
+
+
+def test_prefilter_env_512_and_sh9_vs_fixture(ctx, orc, golden2):
+    """cfg3 at its stated size: 512^2 cube, 5 mips, 1024 spp + SH9.  The CPU cannot afford the whole chain (2.1e9
+    sample steps), so 4096 seeded texels across the five mips are compared: fixture (generated in the build container)
+    and the live oracle on the box."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_v2 as mk
+    sky = mk.bench_sky()
+    dsky = ctx.upload(sky)
+    got = to_np_half(ctx.prefilter_env(dsky, mk.ENV_SIZE, mk.SKY_MIPS, mk.ENV_SIZE, mk.ENV_MIPS))
+    worst = 0
+    for m in range(mk.ENV_MIPS):
+        idx = golden2[f"env512_m{m}_idx"]
+        want = golden2[f"env512_m{m}_texels"]
+        live = orc.prefilter_env_texels(sky, mk.ENV_SIZE, mk.SKY_MIPS, mk.ENV_SIZE, mk.ENV_MIPS, m, idx[::4])
+        assert np.array_equal(live.view(np.uint16), want[::4].view(np.uint16)), f"mip {m}: oracle on this host differs from the fixture"
+        sub = got[cube_mip_offset(mk.ENV_SIZE, m) + idx.astype(np.int64)]
+        d = common.half_ulp_diff(sub, want)
+        ok = (d <= 1) | (np.abs(sub.astype(np.float32) - want.astype(np.float32)) <= 1e-3 * np.abs(want.astype(np.float32)))
+        assert ok.all(), f"prefilter 512^2 mip {m}: {(~ok).sum()} of {len(idx)} texels outside 1 ULP / 1e-3"
+        worst = max(worst, int(d.max()))
+        assert np.all(sub[:, 3] == 1.0)
+    print(f"prefilter 512^2 x 5: 4096 sampled texels, worst {worst} fp16 ULP")
+    sh = ctx.sh9_project(dsky, mk.ENV_SIZE, mk.SKY_MIPS).cpu().numpy()
+    assert np.abs(sh - golden2["sh512"]).max() <= 1e-5 * np.abs(golden2["sh512"]).max()
+
+
 def test_brdf_lut_bad_args(ctx):
     from direct12pbrrenderer_amd.api import PbrError
     with pytest.raises(PbrError):
@@ -218,6 +260,93 @@ def test_deferred_shade_ragged_tile_of_a_larger_frame(ctx, orc, ibl):
     cam2, g2, lights2, gbf, tilef = common.shade_scene(640, 360, 256, sh)
     full = _shade_on_gpu(ctx, g2, tilef, gbf, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights2)
     assert np.array_equal(full[91:91 + 37, 328:328 + 200], got)
+
+
+# ---- the north_star bound itself: <= 1e-4 relative L-inf on the fp32 colour BEFORE the fp16 store
+F32_REL_LINF = 1e-4
+
+
+def _shade_f32_on_gpu(ctx, g, tile, gb, dlut, lut_res, env_padded, env_size, env_mips, clusters_np, lights):
+    h, w = gb["A"].shape
+    gbd = {k: ctx.upload(v) for k, v in gb.items()}
+    out = ctx.zeros((h, w, 4), torch.float32)
+    ctx.deferred_shade_f32(g, tile, gbd, w, dlut, lut_res, env_padded, env_size, env_mips,
+                           ctx.upload(clusters_np), ctx.upload(lights) if len(lights) else None, len(lights), out, w)
+    return out.cpu().numpy()
+
+
+def _check_shade_f32(got, want_f32, stencil, what):
+    """relative L-inf = max |got - want| / max |want| over the covered pixels (rgb), the norm SURVEY 8c / north_star
+    state; the per-pixel relative error is bounded as well, with a floor of 1e-3 of the frame maximum so that
+    near-black channels do not divide by ~0."""
+    on = stencil > 0
+    a, b = got[on][:, :3].astype(np.float64), want_f32[on][:, :3].astype(np.float64)
+    assert np.isfinite(a).all() and np.isfinite(b).all(), what
+    scale = np.abs(b).max()
+    rel_linf = np.abs(a - b).max() / scale
+    assert rel_linf <= F32_REL_LINF, f"{what}: relative L-inf {rel_linf:.3g} > {F32_REL_LINF}"
+    per_px = (np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * scale)).max()
+    assert per_px <= 1e-3, f"{what}: per-pixel relative error {per_px:.3g}"
+    assert np.all(got[on][:, 3] == 1.0)
+    return rel_linf
+
+
+@pytest.mark.parametrize("n_lights", [0, 1, 256, 1024])
+def test_deferred_shade_f32_within_1e4_relative_linf(ctx, orc, ibl, n_lights):
+    """64x64 (0 / 1 / 256 / 1024 lights: the last one runs k_deferred_shade<*, 1025>) and a ragged tile of a larger frame."""
+    sky, env, lut, sh = ibl
+    dlut, denv = dev_half(ctx, lut), ctx.env_pad(dev_half(ctx, env), common.ENV_SIZE, common.ENV_MIPS)
+    for (w, h, full, x0, y0) in ((64, 64, None, 0, 0), (200, 37, (640, 360), 328, 91)):
+        cam, g, lights, gb, tile = common.shade_scene(w, h, n_lights, sh, full=full, x0=x0, y0=y0, rough_min=48)
+        cl = orc.cluster_build(g)
+        orc.cluster_cull(g, lights, cl)
+        if n_lights == 1024:
+            assert cl["NumLights"].max() == 32 and len(lights) > 256
+        _, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+        got = _shade_f32_on_gpu(ctx, g, tile, gb, dlut, lut.shape[0], denv, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+        _check_shade_f32(got, want_f32, gb["stencil"], f"f32 shade {w}x{h}, {n_lights} lights")
+
+
+def test_deferred_shade_1024_lights_fp16_target(ctx, orc, ibl):
+    """257..1024 scene lights select the kernel instantiation with the 1025-float LDS plane stride."""
+    sky, env, lut, sh = ibl
+    cam, g, lights, gb, tile = common.shade_scene(256, 144, 1024, sh, rough_min=48)
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    assert (cl["LightIndex"][cl["NumLights"] > 0].max() > 256)        # lists really index beyond the 257-stride table
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+    _check_shade(got, want, want_f32, gb["stencil"], "1024 lights", hard_ulp=None)
+
+
+@pytest.fixture(scope="module")
+def bench_ibl(ctx):
+    """The IBL bench.py shades with: 512^2 sky -> GPU-built LUT 512^2, prefiltered env 512^2 x 5 mips, SH9 (each
+    kernel is oracle-checked on its own: LUT over the whole plane, env on sampled texels of every mip, SH9)."""
+    import bench
+    lut, env, sh = bench.build_ibl(ctx)
+    return lut, env, sh, to_np_half(lut), to_np_half(env)
+
+
+@pytest.mark.parametrize("w,h,rows", [(1920, 1080, 32), (3840, 2160, 32)])
+def test_deferred_shade_band_with_the_bench_ibl(ctx, orc, bench_ibl, w, h, rows):
+    """A band of the cfg2 / cfg4 frame (256 lights) shaded against the REAL IBL of the bench — LUT 512^2 and the
+    512^2 x 5 env chain, not the 16^2 / 32^2 test set — in fp32 (<= 1e-4 rel L-inf) and on the fp16 target.  The oracle
+    consumes the very arrays the GPU built, so this checks the shade's sampling of the big chain, not the prefilter."""
+    lut_d, env_d, sh, lut, env = bench_ibl
+    y0 = (h - rows) // 2 // 8 * 8
+    cam, g, lights, gb, tile = common.shade_scene(w, rows, 256, sh, full=(w, h), x0=0, y0=y0, rough_min=48, coverage_mask=False)
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, 512, 5, cl, lights, want_f32=True)
+    envp = ctx.env_pad(env_d, 512, 5)
+    got32 = _shade_f32_on_gpu(ctx, g, tile, gb, lut_d, 512, envp, 512, 5, cl, lights)
+    rel = _check_shade_f32(got32, want_f32, gb["stencil"], f"{w}x{h} band, bench IBL")
+    print(f"fp32 shade vs oracle, {w}x{rows} band of {w}x{h}, 256 lights, bench IBL: relative L-inf {rel:.3g}")
+    gbd = {k: ctx.upload(v) for k, v in gb.items()}
+    hdr = ctx.zeros((rows, w, 4), torch.float16)
+    ctx.deferred_shade(g, tile, gbd, w, lut_d, 512, envp, 512, 5, ctx.upload(cl), ctx.upload(lights), len(lights), hdr, w)
+    _check_shade(to_np_half(hdr), want, want_f32, gb["stencil"], f"{w}x{h} band fp16, bench IBL", hard_ulp=None)
 
 
 # ------------------------------------------------------------------------------------------ a14-a15

@@ -1,4 +1,4 @@
-"""Tile + apron path on real hardware: two and three ranks (all on cuda:0 — the test box has one GPU; the
+"""Tile + apron / tile + halo path on real hardware: two, three and four (2x2) ranks (all on cuda:0 — the test box has one GPU; the
 collective is gloo on the host copy of the 256-bin histogram) against the single-GPU frame.
 What runs on the GPU is exactly what bench.py runs per rank: DeferredFrame on an apron-extended
 tile with global-pixel addressing, interior histogram, full-frame PixelCount."""
@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 import common
 
 pytestmark = pytest.mark.gpu
-TILE_W, TILE_H, N_LIGHTS = 512, 288, 256
+N_LIGHTS = 256
 
 
 def _free_port():
@@ -45,12 +45,12 @@ def _ibl_dev(ctx, ibl):
     return up(lut), up(env)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, layout, halo, tile_w, tile_h):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from direct12pbrrenderer_amd.api import PbrContext
-    from direct12pbrrenderer_amd.pipeline import tile_for_rank
+    from direct12pbrrenderer_amd.pipeline import DeferredFrame, HaloTransport, tile_for_rank
     from oracle import binding as orc
     ibl = common.small_ibl(orc)
     ctx = PbrContext(0)
@@ -61,8 +61,21 @@ def _worker(rank, world, port, outdir):
         dist.all_reduce(t)
         hist.copy_(t)
 
-    spec = tile_for_rank(rank, world, TILE_W, TILE_H)
-    fr = _frame(ctx, spec, _ibl_dev(ctx, ibl), ibl[3], allreduce)
+    specs = [tile_for_rank(r, world, tile_w, tile_h, layout=layout, halo=halo) for r in range(world)]
+    spec = specs[rank]
+    lut, env = _ibl_dev(ctx, ibl)
+    cam, g, lights, gb, _ = common.shade_scene(spec.sw, spec.sh, N_LIGHTS, ibl[3], full=(spec.full_w, spec.full_h),
+                                               x0=spec.sx0, y0=spec.sy0, rough_min=48, coverage_mask=False)
+    fr = DeferredFrame(ctx, spec, g, lights, lut, common.LUT_RES, env, common.ENV_SIZE, common.ENV_MIPS, allreduce=allreduce,
+                       all_specs=specs, rank=rank, halo_transport=HaloTransport("host", dist) if halo else None)
+    fr.upload_gbuffer(gb)
+    fr.set_prev_luminance(0.18)
+    if halo:
+        fr.level1.fill_(777.0)   # poison: every level-1 texel of E must come from the prefilter or a neighbour
+    fr.render()
+    ctx.sync()
+    if halo:
+        assert not bool((fr.level1 == 777.0).any()), "halo exchange left level-1 texels unfilled"
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), hdr=fr.hdr_interior().view(np.uint16), ldr=fr.ldr_numpy(),
              avg=fr.avg.cpu().numpy(), rect=np.array([spec.x0, spec.y0, spec.w, spec.h]))
     ctx.close()
@@ -70,14 +83,21 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])      # 3: the middle rank has a neighbour (and an apron) on both sides
-def test_ranks_with_apron_match_single_gpu_frame(ctx, ibl, world):
-    from direct12pbrrenderer_amd.pipeline import TileSpec
+# world 3: the middle rank has a neighbour (and an apron) on both sides; 2x2: aprons on two axes incl. the corner
+# (the way BASELINE cfg5 tiles its 8K frame); halo: level-1 strips from the neighbours instead of the shaded apron
+CASES = [(2, None, False, 512, 288), (3, None, False, 512, 288), (4, (2, 2), False, 384, 288), (4, (2, 2), True, 384, 288),
+         (2, None, True, 512, 288)]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,layout,halo,tile_w,tile_h", CASES)
+def test_ranks_match_single_gpu_frame(ctx, ibl, world, layout, halo, tile_w, tile_h):
+    from direct12pbrrenderer_amd.pipeline import TileSpec, grid_for_world
+    cols, rows = grid_for_world(world, layout)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, layout, halo, tile_w, tile_h), nprocs=world, join=True)
         ranks = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
-    W, H = TILE_W * world, TILE_H
+    W, H = tile_w * cols, tile_h * rows
     fr = _frame(ctx, TileSpec(0, 0, W, H, W, H, 0), _ibl_dev(ctx, ibl), ibl[3])
     full_hdr = fr.hdr_interior()
     full_ldr = fr.ldr_numpy()

@@ -98,25 +98,58 @@ def test_synthetic_tile_equals_region_of_full_frame():
 
 
 def test_tile_specs_cover_the_frame_once():
-    for world in (1, 2, 3, 4, 8):
-        cols, rows = grid_for_world(world, 64, 48)
-        assert (cols, rows) == (world, 1)                   # landscape tiles side by side: short edges shared
-        cover = np.zeros((rows * 48, cols * 64), dtype=np.int32)
-        for r in range(world):
-            s = tile_for_rank(r, world, 64, 48, apron=16)
-            cover[s.y0:s.y0 + s.h, s.x0:s.x0 + s.w] += 1
-            assert (s.full_w, s.full_h) == (cols * 64, rows * 48)
-            assert 0 <= s.ex0 <= s.x0 and s.ex1 <= s.full_w and s.ix == s.x0 - s.ex0
-            assert (s.apron == 0) == (world == 1)
-            assert s.ex0 % 16 == 0 and s.ey0 % 16 == 0      # extended origin stays on the coarsest mip grid
-        assert np.all(cover == 1)
-    assert grid_for_world(4, 48, 64) == (1, 4)              # portrait tiles stack
+    from direct12pbrrenderer_amd.pipeline import halo_plan, parse_layout, tile_of_frame
+    expect = {1: (1, 1), 2: (2, 1), 3: (3, 1), 4: (2, 2), 6: (3, 2), 8: (4, 2)}   # most square, cols >= rows
+    for world, grid in expect.items():
+        for layout in (None, (world, 1)):                     # default grid and one row of tiles
+            cols, rows = grid_for_world(world, layout)
+            assert (cols, rows) == (grid if layout is None else layout)
+            for halo in (False, True):
+                cover = np.zeros((rows * 48, cols * 64), dtype=np.int32)
+                specs = [tile_for_rank(r, world, 64, 48, apron=16, layout=layout, halo=halo) for r in range(world)]
+                for r, s in enumerate(specs):
+                    cover[s.y0:s.y0 + s.h, s.x0:s.x0 + s.w] += 1
+                    assert (s.full_w, s.full_h) == (cols * 64, rows * 48)
+                    assert 0 <= s.ex0 <= s.x0 and s.ex1 <= s.full_w and s.ix == s.x0 - s.ex0
+                    assert 0 <= s.ey0 <= s.y0 and s.ey1 <= s.full_h and s.iy == s.y0 - s.ey0
+                    assert (s.apron == 0) == (world == 1)
+                    assert s.ex0 % 16 == 0 and s.ey0 % 16 == 0      # extended origin stays on the coarsest mip grid
+                    assert s.halo == (halo and world > 1)
+                    if s.halo:      # shaded rectangle: interior + 4 px towards every neighbour, even origin
+                        assert (s.sx0, s.sy0) == (max(s.x0 - 4, 0), max(s.y0 - 4, 0)) and s.sx0 % 2 == 0 and s.sy0 % 2 == 0
+                        assert s.sx1 == min(s.x0 + s.w + 4, s.full_w) and s.sy1 == min(s.y0 + s.h + 4, s.full_h)
+                    else:
+                        assert (s.sx0, s.sy0, s.sw, s.sh) == (s.ex0, s.ey0, s.ew, s.eh)
+                assert np.all(cover == 1)
+                if halo and world > 1:
+                    # halo plan: what r receives from n is what n sends to r, and the strips + the interior tile E/2 exactly
+                    plans = [halo_plan(r, world, specs) for r in range(world)]
+                    for r, s in enumerate(specs):
+                        got = np.zeros((s.full_h // 2, s.full_w // 2), dtype=np.int32)
+                        got[s.y0 // 2:(s.y0 + s.h) // 2, s.x0 // 2:(s.x0 + s.w) // 2] += 1
+                        for n, snd, rcv in plans[r]:
+                            back = [q for q in plans[n] if q[0] == r][0]
+                            assert back[1] == rcv and back[2] == snd
+                            if rcv:
+                                got[rcv[1]:rcv[3], rcv[0]:rcv[2]] += 1
+                        e = np.zeros_like(got)
+                        e[s.ey0 // 2:s.ey1 // 2, s.ex0 // 2:s.ex1 // 2] = 1
+                        assert np.array_equal(got, e)
+    assert parse_layout("2x4") == (4, 2)                      # rows x cols, the way BASELINE cfg5 says "tiled 2x4"
     with pytest.raises(ValueError):
         grid_for_world(0)
     with pytest.raises(ValueError):
+        grid_for_world(8, (3, 2))
+    with pytest.raises(ValueError):
         tile_for_rank(0, 2, 64, 40, apron=16)
-    # the busiest rank of 8 shades 13.3 % more pixels than its 3840x2160 tile (27 % in a 4x2 arrangement)
-    s8 = tile_for_rank(3, 8, 3840, 2160)
+    # BASELINE cfg5: 7680x4320 as 2 rows x 4 cols of 1920x2160; an inner tile of the top row carries aprons on three sides
+    s5 = tile_of_frame(1, 8, 7680, 4320, layout=parse_layout("2x4"))
+    assert (s5.x0, s5.y0, s5.w, s5.h) == (1920, 0, 1920, 2160) and (s5.ew, s5.eh) == (1920 + 512, 2160 + 256)
+    assert abs(s5.ew * s5.eh / (1920 * 2160) - 1.417) < 1e-3          # apron mode: 42 % extra shaded pixels ...
+    h5 = tile_of_frame(1, 8, 7680, 4320, layout=parse_layout("2x4"), halo=True)
+    assert (h5.sw, h5.sh) == (1928, 2164) and h5.sw * h5.sh / (1920 * 2160) < 1.007   # ... halo mode: 0.6 %
+    # one row of eight 4K tiles: the busiest rank shades 13.3 % more pixels than its tile in apron mode
+    s8 = tile_for_rank(3, 8, 3840, 2160, layout=(8, 1))
     assert (s8.ew, s8.eh) == (3840 + 512, 2160) and abs(s8.ew * s8.eh / (3840 * 2160) - 1.1333) < 1e-3
     s = TileSpec(0, 0, 64, 40, 128, 40, 16)
     assert (s.ew, s.eh) == (80, 40)

@@ -1,7 +1,7 @@
-"""world_size-2 and -3 rehearsal of the multi-GPU path on CPU (gloo): tiling with aprons + the 256-bin
-histogram all-reduce.  The per-rank arithmetic is the ORACLE here (no GPU in this
+"""world_size-2, -3 and -4 (2x2) rehearsal of the multi-GPU path on CPU (gloo): tiling with aprons on one or two axes,
+or with a level-1 halo exchange instead of the shaded apron, + the 256-bin histogram all-reduce.  The per-rank arithmetic is the ORACLE here (no GPU in this
 container); what is under test is the host-side sharding logic that bench.py uses on the GPUs:
-tile_for_rank / TileSpec, global-pixel addressing, interior histogram, all-reduce, full-frame
+tile_for_rank / TileSpec / halo_plan, global-pixel addressing, interior histogram, all-reduce, full-frame
 PixelCount, identical average luminance on every rank."""
 import os
 import socket
@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 import common
 
-TILE_W, TILE_H, APRON, N_LIGHTS = 512, 64, 256, 64
+APRON, N_LIGHTS = 256, 64
 
 
 def _free_port():
@@ -26,30 +26,72 @@ def _free_port():
     return p
 
 
-def _render_rank(orc, spec, ibl):
-    """Oracle pipeline on one rank's extended tile; returns interior HDR (post-bloom) and its histogram."""
+def _shade_rank(orc, spec, ibl):
+    """Oracle shade of one rank's SHADED rectangle S; returns (g, hdr_S)."""
     from direct12pbrrenderer_amd.structs import Tile
     sky, env, lut, sh = ibl
-    cam, g, lights, gb, _ = common.shade_scene(spec.ew, spec.eh, N_LIGHTS, sh, full=(spec.full_w, spec.full_h),
-                                               x0=spec.ex0, y0=spec.ey0, rough_min=48, coverage_mask=False)
+    cam, g, lights, gb, _ = common.shade_scene(spec.sw, spec.sh, N_LIGHTS, sh, full=(spec.full_w, spec.full_h),
+                                               x0=spec.sx0, y0=spec.sy0, rough_min=48, coverage_mask=False)
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
-    hdr, _ = orc.deferred_shade(g, Tile(spec.ex0, spec.ey0, spec.ew, spec.eh, spec.full_w, spec.full_h), gb, lut, env,
+    hdr, _ = orc.deferred_shade(g, Tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h), gb, lut, env,
                                 common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+    return g, hdr
+
+
+def _render_rank(orc, spec, ibl):
+    """Apron mode / single frame: oracle pipeline on the extended tile; returns interior HDR (post-bloom) + histogram."""
+    g, hdr = _shade_rank(orc, spec, ibl)
     orc.bloom(hdr)
     interior = np.ascontiguousarray(hdr[spec.iy:spec.iy + spec.h, spec.ix:spec.ix + spec.w])
     return g, interior, orc.lum_histogram(interior)
 
 
-def _worker(rank, world, port, outdir):
+def _render_rank_halo(orc, spec, ibl, rank, world, specs):
+    """Halo mode with the oracle as the per-rank arithmetic: shade interior + 4 px, prefilter, take the interior's
+    level-1 texels, exchange strips per halo_plan over gloo, run levels 1..4 on E, merge the interior."""
+    from direct12pbrrenderer_amd.pipeline import halo_plan
+    g, hdr = _shade_rank(orc, spec, ibl)
+    a1_s = orc.bloom_prefilter(hdr)                                    # level 1 of S; exact on the interior
+    hx, hy = spec.ex0 // 2, spec.ey0 // 2
+    a1 = np.zeros((spec.eh // 2, spec.ew // 2, 4), dtype=np.float16)
+    a1[:] = np.float16(777.0)                                          # poison: every texel must come from somewhere
+    ix, iy = spec.x0 // 2 - hx, spec.y0 // 2 - hy
+    a1[iy:iy + spec.h // 2, ix:ix + spec.w // 2] = a1_s[spec.siy // 2:spec.siy // 2 + spec.h // 2, spec.six // 2:spec.six // 2 + spec.w // 2]
+    ops, bufs = [], []
+    for peer, send, recv in halo_plan(rank, world, specs):
+        if send:
+            t = torch.from_numpy(np.ascontiguousarray(a1[send[1] - hy:send[3] - hy, send[0] - hx:send[2] - hx]).view(np.int16).copy())
+            ops.append(dist.P2POp(dist.isend, t, peer))
+        if recv:
+            t = torch.zeros((recv[3] - recv[1], recv[2] - recv[0], 4), dtype=torch.int16)
+            ops.append(dist.P2POp(dist.irecv, t, peer))
+            bufs.append((recv, t))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for recv, t in bufs:
+        a1[recv[1] - hy:recv[3] - hy, recv[0] - hx:recv[2] - hx] = t.numpy().view(np.float16)
+    assert not (a1 == np.float16(777.0)).any(), "halo plan left level-1 texels of E unfilled"
+    a0 = common.oracle_bloom_from_level1(orc, a1)
+    interior = np.ascontiguousarray(hdr[spec.siy:spec.siy + spec.h, spec.six:spec.six + spec.w])
+    orc.bloom_merge(interior, np.ascontiguousarray(a0[spec.iy:spec.iy + spec.h, spec.ix:spec.ix + spec.w]))
+    return g, interior, orc.lum_histogram(interior)
+
+
+def _worker(rank, world, port, outdir, layout, halo, tile_w, tile_h):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import binding as orc
     from direct12pbrrenderer_amd.pipeline import tile_for_rank
     orc.set_num_threads(2)
-    spec = tile_for_rank(rank, world, TILE_W, TILE_H, APRON)
-    g, interior, hist = _render_rank(orc, spec, common.small_ibl(orc))
+    specs = [tile_for_rank(r, world, tile_w, tile_h, APRON, layout, halo) for r in range(world)]
+    spec = specs[rank]
+    ibl = common.small_ibl(orc)
+    if halo:
+        g, interior, hist = _render_rank_halo(orc, spec, ibl, rank, world, specs)
+    else:
+        g, interior, hist = _render_rank(orc, spec, ibl)
     t = torch.from_numpy(hist.view(np.int32).copy())
     dist.all_reduce(t)                                    # int32 sum == uint32 sum bit for bit
     hist_all = t.numpy().view(np.uint32).copy()
@@ -61,17 +103,24 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])      # 3: the middle rank carries an apron on both sides (the N >= 3 layout of bench.py)
-def test_tiling_matches_single_frame(orc, ibl, world):
-    from direct12pbrrenderer_amd.pipeline import TileSpec, tile_for_rank
+# world 3: the middle rank carries an apron on both sides; world 4 = 2x2: aprons on two axes incl. the corner
+# (BASELINE cfg5 cuts its 8K frame 2x4 the same way); halo: level-1 strips from the neighbours instead of a shaded apron
+CASES = [(2, None, False, 512, 64), (3, None, False, 512, 64), (4, (2, 2), False, 320, 272), (4, (2, 2), True, 320, 272),
+         (2, None, True, 512, 64)]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,layout,halo,tile_w,tile_h", CASES)
+def test_tiling_matches_single_frame(orc, ibl, world, layout, halo, tile_w, tile_h):
+    from direct12pbrrenderer_amd.pipeline import TileSpec, grid_for_world, tile_for_rank
     if world == 3:
-        mid = tile_for_rank(1, 3, TILE_W, TILE_H, APRON)
-        assert (mid.ex0, mid.ew, mid.ix) == (TILE_W - APRON, TILE_W + 2 * APRON, APRON)
+        mid = tile_for_rank(1, 3, tile_w, tile_h, APRON)
+        assert (mid.ex0, mid.ew, mid.ix) == (tile_w - APRON, tile_w + 2 * APRON, APRON)
+    cols, rows = grid_for_world(world, layout)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, layout, halo, tile_w, tile_h), nprocs=world, join=True)
         ranks = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
-    W, H = TILE_W * world, TILE_H
+    W, H = tile_w * cols, tile_h * rows
     g, full, hist_full = _render_rank(orc, TileSpec(0, 0, W, H, W, H, 0), ibl)
     avg_full = orc.lum_average(hist_full.copy(), W * H, float(g.DeltaTime), 0.18)
     # every rank holds the same all-reduced histogram = sum of the per-rank ones, and the same average
@@ -79,7 +128,13 @@ def test_tiling_matches_single_frame(orc, ibl, world):
         assert np.array_equal(ranks[0]["hist_all"], r["hist_all"]) and ranks[0]["avg"] == r["avg"]
     assert np.array_equal(ranks[0]["hist_all"], sum(r["hist"] for r in ranks))
     assert ranks[0]["hist_all"].sum() == W * H
-    # apron sufficiency: interiors equal the single-frame result (fp32 uv rounding may flip an fp16 ulp)
+    # the interiors tile the frame
+    cover = np.zeros((H, W), dtype=np.int32)
+    for r in ranks:
+        x0, y0, w, h = r["rect"]
+        cover[y0:y0 + h, x0:x0 + w] += 1
+    assert (cover == 1).all()
+    # apron / halo sufficiency: interiors equal the single-frame result (fp32 uv rounding may flip an fp16 ulp)
     for r in ranks:
         x0, y0, w, h = r["rect"]
         ref = full[y0:y0 + h, x0:x0 + w]

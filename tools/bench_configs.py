@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Times the BASELINE.json configs other than the bench.py headline (cfg4) on one MI355X:
 cfg1 LUT 256^2 / 512^2, cfg2 1080p shade with 1 point light (+ full frame), cfg3 512^2 prefilter (5 mips, 1 024 spp)
-+ SH9, cfg5 one rank's share of the 8K frame (1920x2160 tile + 256-px apron).  One JSON line per config."""
++ SH9, cfg5 one rank's share of the 8K frame (the busiest 1920x2160 tile of the 2 rows x 4 cols layout) in apron mode
+(tile + 256-px apron, everything measured) and in halo mode (tile + 4 px; the neighbours' level-1 strips cannot arrive on a
+one-GPU box, so the exchange itself is not in the figure — its plane is filled once before the clock).  One JSON line per config."""
 import json
 import os
 import sys
@@ -14,7 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from direct12pbrrenderer_amd import scene, synth  # noqa: E402
 from direct12pbrrenderer_amd.api import PbrContext  # noqa: E402
-from direct12pbrrenderer_amd.pipeline import DeferredFrame, TileSpec  # noqa: E402
+from direct12pbrrenderer_amd.pipeline import DeferredFrame, HaloTransport, TileSpec, parse_layout, tile_of_frame  # noqa: E402
 from direct12pbrrenderer_amd.structs import ENV_MIPS  # noqa: E402
 
 ctx = PbrContext(0)
@@ -52,27 +54,47 @@ emit(config="cfg3", what="env_pad (padded copy of the prefiltered chain)", ms=ro
 lut, env, sh = bench.build_ibl(ctx)
 
 
-def frame_times(name, spec, n_lights, what, cell=1):
+class _NoExchange(HaloTransport):
+    """One-GPU stand-in: the level-1 plane was filled once (zeros outside the interior); nothing travels."""
+    def __init__(self):
+        self.kind = "none"
+
+    def exchange(self, fr):
+        return
+
+
+def frame_times(name, spec, n_lights, what, cell=1, all_specs=None, rank=0):
     cam = scene.Camera.reference_default(spec.full_w, spec.full_h)
     g = scene.make_global(cam, spec.full_w, spec.full_h, sh_pack=sh, delta_time=1.0 / 60.0)
     lights = synth.reference_scene_light() if n_lights == 1 else synth.lights_in_view_box(n_lights, cam)
-    fr = DeferredFrame(ctx, spec, g, lights, lut, 512, env, 512, ENV_MIPS)
-    fr.upload_gbuffer(synth.gbuffer_tile(spec.ex0, spec.ey0, spec.ew, spec.eh, spec.full_w, spec.full_h, cell=cell))
+    fr = DeferredFrame(ctx, spec, g, lights, lut, 512, env, 512, ENV_MIPS, all_specs=all_specs, rank=rank,
+                       halo_transport=_NoExchange() if spec.halo else None)
+    fr.upload_gbuffer(synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h, cell=cell))
     fr.set_prev_luminance(0.18)
     fr.render()
     shade = bench.time_stage(fr.shade, 20)
+    bloom = bench.time_stage(fr.bloom_histogram, 20)
+    fr.hist.zero_()
     full = bench.time_stage(fr.render, 20)
-    ext, inner = spec.ew * spec.eh, spec.w * spec.h
-    emit(config=name, what=what, shade_ms=round(shade, 4), frame_ms=round(full, 4), shade_Mpixel_per_s=round(ext / shade / 1e3, 1),
-         shade_GBps_algorithmic=round(25.0 * ext / shade / 1e6, 1), frame_Mpixel_per_s_interior=round(inner / full / 1e3, 1),
-         extended_pixels=ext, interior_pixels=inner)
+    shaded, inner = spec.sw * spec.sh, spec.w * spec.h
+    emit(config=name, what=what, shade_ms=round(shade, 4), bloom_histogram_ms=round(bloom, 4), frame_ms=round(full, 4),
+         shade_Mpixel_per_s=round(shaded / shade / 1e3, 1),
+         shade_GBps_algorithmic=round(25.0 * shaded / shade / 1e6, 1), frame_Mpixel_per_s_interior=round(inner / full / 1e3, 1),
+         shaded_pixels=shaded, bloom_pixels=spec.ew * spec.eh, interior_pixels=inner)
 
 
 frame_times("cfg2", TileSpec(0, 0, 1920, 1080, 1920, 1080, 0), 1, "1920x1080 G-buffer, 1 point light + IBL")
 frame_times("cfg4", TileSpec(0, 0, 3840, 2160, 3840, 2160, 0), 256, "3840x2160 G-buffer, 256 clustered lights + IBL (bench.py headline)")
 frame_times("cfg4-coherent", TileSpec(0, 0, 3840, 2160, 3840, 2160, 0), 256,
             "3840x2160, 256 clustered lights + IBL, spatially coherent G-buffer (16x16-pixel surface patches) — NOT the BASELINE workload, for reference", cell=16)
-frame_times("cfg5", TileSpec(1920, 0, 1920, 2160, 7680, 4320, 256), 256, "one of 8 ranks of the 7680x4320 frame: 1920x2160 tile + 256-px apron")
+lay = parse_layout("2x4")
+for halo in (False, True):
+    specs5 = [tile_of_frame(r, 8, 7680, 4320, layout=lay, halo=halo) for r in range(8)]
+    frame_times("cfg5-halo" if halo else "cfg5-apron", specs5[1], 256,
+                "busiest of 8 ranks of the 7680x4320 frame (2 rows x 4 cols): 1920x2160 tile, " +
+                ("shaded +4 px, bloom on tile + 256-px halo of level 1 (exchange itself not included: one GPU)" if halo else "shaded and bloomed with a 256-px apron"),
+                all_specs=specs5, rank=1)
+frame_times("cfg5-1gpu", TileSpec(0, 0, 7680, 4320, 7680, 4320, 0), 256, "the whole 7680x4320 frame on one GPU (the strong-scaling denominator)")
 
 # ---- SURVEY 8f "next" rows at the headline size: G-buffer encode (48 B in + 12 B out per pixel) and a full-screen sky
 W4, H4 = 3840, 2160
