@@ -776,6 +776,21 @@ int orc_deferred_shade(const pbr_global* g, const pbr_tile* tile, const pbr_gbuf
                        const uint16_t* env, uint32_t env_size, uint32_t env_mips,
                        const pbr_cluster* clusters, const pbr_light* lights,
                        uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32) {
+    return orc_deferred_shade_sens(g, tile, gb, lut, lut_res, env, env_size, env_mips, clusters, lights, hdr, hdr_pitch, hdr_f32, nullptr);
+}
+
+// The same pass, optionally reporting how ILL-CONDITIONED each pixel's colour is in fp32 (sens_rgb, 3 floats per
+// pixel, may be null).  distribution_ggx computes t = NdotH^2 (a^4 - 1) + 1: near a highlight (NdotH -> 1) this cancels
+// down to ~a^4 = roughness^8, so a rounding error e in NdotH changes D = a^4 / (pi t^2) by the factor
+// 4 NdotH (1 - a^4) / t * e — up to 4 / roughness^8 (2.5e6 at roughness 0.19).  sens = sum over the pixel's lights of
+// |specular contribution| * 4 NdotH (1 - a^4) / t: first-order change of the colour per unit error of NdotH.  Any two
+// fp32 evaluations of the shader (this one, a GPU's, the reference's own on another driver) differ by a few 2^-24 in
+// NdotH, i.e. by a few 2^-24 * sens in the colour; parity tests allow exactly that on top of their relative bound.
+int orc_deferred_shade_sens(const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
+                            const uint16_t* lut, uint32_t lut_res,
+                            const uint16_t* env, uint32_t env_size, uint32_t env_mips,
+                            const pbr_cluster* clusters, const pbr_light* lights,
+                            uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32, float* sens_rgb) {
     if (!g || !tile || !gb || !lut || !env || !clusters || !hdr) return PBR_ERR_INVALID;
     CubeF16 cube{env, env_size, env_mips};
     // vs_main, deferred_shading.hlsl:91-121
@@ -828,6 +843,7 @@ int orc_deferred_shade(const pbr_global* g, const pbr_tile* tile, const pbr_gbuf
             int ci = cluster_index_uv(g, u, v, z_vs);
             const pbr_cluster& cl = clusters[ci];
             V3 pl = v3(0, 0, 0);
+            V3 sens = v3(0, 0, 0);
             for (int i = 0; i < cl.NumLights; i++) {
                 const pbr_light& lt = lights[cl.LightIndex[i]];
                 V3 dir = v3(lt.Position[0], lt.Position[1], lt.Position[2]) - pos;
@@ -838,12 +854,26 @@ int orc_deferred_shade(const pbr_global* g, const pbr_tile* tile, const pbr_gbuf
                 V3 f = brdf(metallic, roughness, albedo, n, view, dir);
                 V3 col = v3(lt.Color[0], lt.Color[1], lt.Color[2]);
                 pl = pl + (((f * col) * lt.Intensity) * att) * NdotL;
+                if (sens_rgb) {   // conditioning report only: does not feed the colour
+                    V3 H = normalize3(dir + view);
+                    float NdotH = fmaxf(dot3(n, H), 0.0f);
+                    float a = roughness * roughness, a4 = a * a;
+                    float t = (NdotH * NdotH) * (a4 - 1.0f) + 1.0f;
+                    if (PI_F * t * t > EPSILON_F) {
+                        V3 diffuse = ((v3(1.0f, 1.0f, 1.0f) - fresnel(NdotL, F0)) * (1.0f - metallic) * albedo) * INV_PI_F;
+                        V3 spec = f - diffuse;
+                        float amp = 4.0f * NdotH * (1.0f - a4) / fabsf(t);
+                        V3 c = (((spec * col) * lt.Intensity) * att) * NdotL;
+                        sens = sens + v3(fabsf(c.x), fabsf(c.y), fabsf(c.z)) * amp;
+                    }
+                }
             }
             V3 emission_l = albedo * emission;
             V3 out = ((env_diffuse + env_specular) + pl) + emission_l;   // Q1: directional light dropped
             size_t oi = (size_t)py * hdr_pitch + px;
             store_h4(hdr + 4 * oi, f4(out.x, out.y, out.z, 1.0f));
             if (hdr_f32) { hdr_f32[4 * oi] = out.x; hdr_f32[4 * oi + 1] = out.y; hdr_f32[4 * oi + 2] = out.z; hdr_f32[4 * oi + 3] = 1.0f; }
+            if (sens_rgb) { sens_rgb[3 * oi] = sens.x; sens_rgb[3 * oi + 1] = sens.y; sens_rgb[3 * oi + 2] = sens.z; }
         }
     }
     return PBR_OK;
