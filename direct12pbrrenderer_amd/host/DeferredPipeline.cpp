@@ -45,6 +45,7 @@ void PreFilterEnvMapPass::Execute(FGContext* context) {   // DeferredPipeline.cp
     mReady = true;
     SkyBox* sky = context->Scene->GetSkyBox();
     if (!sky) return;
+    PIXScope(context->CommandList, "Precompute PrefilterEnvMap Pass");
     for (uint32 i = 0; i < PreFilterEnvMapMipsLevel; i++) {
         ShadingState& st = mShadingState[i];
         st.SetShader("env_map_gen.hlsl", true);
@@ -68,6 +69,7 @@ PrecomputeBRDFPass::PrecomputeBRDFPass(uint32 res) : mRes(res), mReady(false) {
 
 void PrecomputeBRDFPass::Execute(FGContext* context) {   // :117-136
     if (mReady) return;
+    PIXScope(context->CommandList, "Precompute BRDF Pass");
     mReady = true;
     constexpr uint32 ThreadGroupSize = 8;
     mShadingState.SetConstantBuffer(PrecomputeBRDFConstant{mRes});
@@ -84,6 +86,7 @@ GBufferPass::GBufferPass(RenderSize s) {
 }
 
 void GBufferPass::Execute(FGContext* context) {
+    PIXScope(context->CommandList, "Gbuffer Pass");
     GBufferSource& src = context->Scene->GBuffer();
     if (!src.Dirty) return;   // the planes a rasterizer would have left in device memory are still there
     src.Dirty = false;
@@ -118,6 +121,7 @@ SkyboxPass::SkyboxPass() {   // DeferredPipeline.cpp:46-57
 void SkyboxPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:59-75
     SkyBox* sky_box = context->Scene->GetSkyBox();
     if (!sky_box) return;
+    PIXScope(context->CommandList, "Skybox Pass");
     mShadingState.SetTexture("SkyBox", sky_box->Resource());
     context->CommandList->DrawMesh(&mShadingState);   // sky sphere, depth test on / write off
 }
@@ -139,6 +143,7 @@ DeferredShadingPass::DeferredShadingPass(RenderSize s) {   // DeferredPipeline.h
 }
 
 void DeferredShadingPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:187-206
+    PIXScope(context->CommandList, "Deferred Shading");
     auto tex = [&](FGResourceId id) { return As<DeviceTexture>(GetTransientResource(context, id)); };
     mShadingState.SetTexture("GBufferA", tex(DeferredPipelineResource::GBufferA));
     mShadingState.SetTexture("GBufferB", tex(DeferredPipelineResource::GBufferB));
@@ -161,6 +166,7 @@ ClusteredPass::ClusteredPass() {
 }
 
 void ClusteredPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:208-258
+    PIXScope(context->CommandList, "Clustered Pass");
     auto* sw_cluster = As<DeviceStructuredBuffer>(GetTransientResource(context, DeferredPipelineResource::FrustumCluster));
     auto* sw_point_light = As<DeviceStructuredBuffer>(GetTransientResource(context, DeferredPipelineResource::PointLights));
     mClusteredCompute.SetRWStructuredBuffer("Clusters", sw_cluster);
@@ -198,6 +204,7 @@ AutoExposurePass::AutoExposurePass() : mAvarageLuminanceInitialized(false) {
 }
 
 void AutoExposurePass::Execute(FGContext* context) {   // DeferredPipeline.cpp:260-318
+    PIXScope(context->CommandList, "Auto Exposure Pass");
     auto* input_tex = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::DeferredShadingRT));
     auto* histogram = As<DeviceStructuredBuffer>(GetTransientResource(context, DeferredPipelineResource::LuminanceHistogram));
     auto* avg_luminance = As<DeviceStructuredBuffer>(GetTransientResource(context, DeferredPipelineResource::AverageLuminance));
@@ -205,11 +212,18 @@ void AutoExposurePass::Execute(FGContext* context) {   // DeferredPipeline.cpp:2
         mAvarageLuminanceInitialized = true;
         avg_luminance->Commit(&mInitialLuminance, sizeof(float));
     }
+    {
+    PIXScope(context->CommandList, "Luminance Histogram Pass");
     mLuminanceHistogramCompute.SetRWStructuredBuffer("LuminanceHistogram", histogram);
     mLuminanceHistogramCompute.SetTexture("LuminanceTexture", input_tex);
-    mLuminanceHistogramCompute.SetConstantBuffer(LuminanceHistogramConstant{input_tex->Width(), input_tex->Height(), MinLogLuminance, InvLogLuminanceRange});
-    context->CommandList->Dispatch(&mLuminanceHistogramCompute, CalculateDispatchSize(input_tex->Width(), HistogramComputeThreadGroupSize),
-                                   CalculateDispatchSize(input_tex->Height(), HistogramComputeThreadGroupSize), 1);
+    // multi-GPU: a device counts the interior of its tile only; one GPU: the whole texture, as the reference
+    const HipCommandList::Rect& in = context->CommandList->Interior();
+    const uint32 hw = in.w ? in.w : input_tex->Width(), hh = in.w ? in.h : input_tex->Height();
+    mLuminanceHistogramCompute.SetConstantBuffer(LuminanceHistogramConstant{hw, hh, MinLogLuminance, InvLogLuminanceRange});
+    context->CommandList->Dispatch(&mLuminanceHistogramCompute, CalculateDispatchSize(hw, HistogramComputeThreadGroupSize),
+                                   CalculateDispatchSize(hh, HistogramComputeThreadGroupSize), 1);
+    }
+    PIXScope(context->CommandList, "Average Luminance Pass");
     mAvarageLuminanceCompute.SetRWStructuredBuffer("LuminanceHistogram", histogram);
     mAvarageLuminanceCompute.SetRWStructuredBuffer("AverageLuminance", avg_luminance);
     const uint32 pixels = mFullFramePixels ? mFullFramePixels : input_tex->Width() * input_tex->Height();
@@ -226,6 +240,7 @@ ToneMappingPass::ToneMappingPass(RenderSize s) {
 }
 
 void ToneMappingPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:320-336
+    PIXScope(context->CommandList, "Tone Mapping Pass");
     auto* input_tex = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::DeferredShadingRT));
     auto* avg_luminance = As<DeviceStructuredBuffer>(GetTransientResource(context, DeferredPipelineResource::AverageLuminance));
     mToneMappingRender.SetRWStructuredBuffer("AverageLuminance", avg_luminance);
@@ -251,6 +266,7 @@ BloomPass::BloomPass() {   // DeferredPipeline.cpp:338-374
 }
 
 void BloomPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:400-570, 16 dispatches
+    PIXScope(context->CommandList, "Bloom Pass");
     auto* original_tex = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::DeferredShadingRT));
     auto* mip_chain = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::BloomMipchain));
     auto* temp_tex = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::BloomTempTexture));
@@ -261,23 +277,30 @@ void BloomPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:400-570,
         return;
     }
 
+    {
+    PIXScope(cmd, "Bloom Prefilter");
     mPrefilter.SetConstantBuffer(BloomPrefilterConstant{texel(original_tex->Width() >> 1, original_tex->Height() >> 1), 1.0f, 0.5f});
     mPrefilter.SetTexture("InputTexture", original_tex);
     mPrefilter.SetRWTexture("OutputTexture", mip_chain, 1);
     cmd->Dispatch(&mPrefilter, CalculateDispatchSize(temp_tex->Width(), 16), CalculateDispatchSize(temp_tex->Height(), 16), 1);   // full-res grid (Q9)
-
+    }
+    {
+    PIXScope(cmd, "Bloom Downsample");
     for (uint32 i = 0; i < BloomStep; i++) {   // downsample
         const uint32 upper = i + 1;
         const uint32 lw = temp_tex->Width() >> (upper + 1), lh = temp_tex->Height() >> (upper + 1);
         mDownsampleH[i].SetConstantBuffer(BlurConstant{texel(lw, lh)});
         mDownsampleH[i].SetTexture("InputTexture", mip_chain, upper);
         mDownsampleH[i].SetRWTexture("OutputTexture", temp_tex, upper + 1);
-        cmd->Dispatch(&mDownsampleH[i], CalculateDispatchSize(lw, 256), CalculateDispatchSize(lh, 1), 1);
+        { PIXScope(cmd, "Blur Horizontal"); cmd->Dispatch(&mDownsampleH[i], CalculateDispatchSize(lw, 256), CalculateDispatchSize(lh, 1), 1); }
         mDownsampleV[i].SetConstantBuffer(BlurConstant{texel(lw, lh)});
         mDownsampleV[i].SetTexture("InputTexture", temp_tex, i + 2);
         mDownsampleV[i].SetRWTexture("OutputTexture", mip_chain, i + 2);
-        cmd->Dispatch(&mDownsampleV[i], CalculateDispatchSize(lw, 1), CalculateDispatchSize(lh, 256), 1);
+        { PIXScope(cmd, "Blur Vertical"); cmd->Dispatch(&mDownsampleV[i], CalculateDispatchSize(lw, 1), CalculateDispatchSize(lh, 256), 1); }
     }
+    }
+    {
+    PIXScope(cmd, "Bloom Upsample");
     for (int i = (int)BloomStep - 1; i >= 0; i--) {   // upsample: V(H(t1) + H(t2))
         const uint32 upper = (uint32)i + 1;
         const uint32 uw = temp_tex->Width() >> upper, uh = temp_tex->Height() >> upper;
@@ -285,24 +308,26 @@ void BloomPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:400-570,
         mUpsampleH[i].SetTexture("UpperLevel", mip_chain, upper);
         mUpsampleH[i].SetTexture("LowerLevel", mip_chain, upper + 1);
         mUpsampleH[i].SetRWTexture("OutputTexture", temp_tex, i + 1);
-        cmd->Dispatch(&mUpsampleH[i], CalculateDispatchSize(uw, 256), CalculateDispatchSize(uh, 1), 1);
+        { PIXScope(cmd, "Upsample Horizontal Add"); cmd->Dispatch(&mUpsampleH[i], CalculateDispatchSize(uw, 256), CalculateDispatchSize(uh, 1), 1); }
         mUpsampleV[i].SetConstantBuffer(BlurConstant{texel(uw, uh)});
         mUpsampleV[i].SetTexture("InputTexture", temp_tex, upper);
         mUpsampleV[i].SetRWTexture("OutputTexture", mip_chain, upper);
-        cmd->Dispatch(&mUpsampleV[i], CalculateDispatchSize(uw, 1), CalculateDispatchSize(uh, 256), 1);
+        { PIXScope(cmd, "Blur Vertical"); cmd->Dispatch(&mUpsampleV[i], CalculateDispatchSize(uw, 1), CalculateDispatchSize(uh, 256), 1); }
     }
+    }
+    PIXScope(cmd, "Upsample Merge");
     const uint32 w = temp_tex->Width(), h = temp_tex->Height();   // merge
     mUpsampleBlurH.SetConstantBuffer(BlurConstant{texel(w, h)});
     mUpsampleBlurH.SetTexture("InputTexture", mip_chain, 1);
     mUpsampleBlurH.SetRWTexture("OutputTexture", temp_tex, 0);
-    cmd->Dispatch(&mUpsampleBlurH, CalculateDispatchSize(w, 256), CalculateDispatchSize(h, 1), 1);
+    { PIXScope(cmd, "Blur Horizontal"); cmd->Dispatch(&mUpsampleBlurH, CalculateDispatchSize(w, 256), CalculateDispatchSize(h, 1), 1); }
     mUpsampleBlurV.SetConstantBuffer(BlurConstant{texel(w, h)});
     mUpsampleBlurV.SetTexture("InputTexture", temp_tex, 0);
     mUpsampleBlurV.SetRWTexture("OutputTexture", mip_chain, 0);
-    cmd->Dispatch(&mUpsampleBlurV, CalculateDispatchSize(w, 1), CalculateDispatchSize(h, 256), 1);
+    { PIXScope(cmd, "Blur Vertical"); cmd->Dispatch(&mUpsampleBlurV, CalculateDispatchSize(w, 1), CalculateDispatchSize(h, 256), 1); }
     mUpsampleMerge.SetTexture("InputTexture", mip_chain, 0);
     mUpsampleMerge.SetRWTexture("OutputTexture", original_tex, 0);
-    cmd->Dispatch(&mUpsampleMerge, CalculateDispatchSize(original_tex->Width(), 16), CalculateDispatchSize(original_tex->Height(), 16), 1);
+    { PIXScope(cmd, "Merge"); cmd->Dispatch(&mUpsampleMerge, CalculateDispatchSize(original_tex->Width(), 16), CalculateDispatchSize(original_tex->Height(), 16), 1); }
 }
 
 }  // namespace MRendererHip

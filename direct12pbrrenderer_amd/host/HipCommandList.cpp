@@ -3,6 +3,8 @@
 
 #include "ShaderConstants.h"
 
+#include <dlfcn.h>
+
 namespace MRendererHip {
 
 // ---------------------------------------------------------------------------------------------
@@ -125,6 +127,37 @@ void HipCommandList::Check(pbr_status st, const char* what) {
 }
 void HipCommandList::EndFrame() { Check(pbr_sync(mCtx), "pbr_sync"); }
 
+// roctx (libroctx64.so.4: roctxRangePushA / roctxRangePop), resolved once; a copy that is already mapped — PyTorch
+// ships one, rocprofv3 preloads one — is preferred over opening another
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void* h = nullptr;
+        const char* names[] = {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"};
+        for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+        if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+}  // namespace
+void HipCommandList::BeginEvent(const char* name) {
+    mEventLog.emplace_back(name);
+    if (roctx().push) roctx().push(name);
+}
+void HipCommandList::EndEvent() {
+    if (roctx().pop) roctx().pop();
+}
+void HipCommandList::SetExternalHistogram(const uint32* counts256) {
+    if (counts256) mExternalHistogram.assign(counts256, counts256 + 256);
+    else mExternalHistogram.clear();
+}
+
 namespace {
 struct Mip {
     pbr_half* ptr;
@@ -204,14 +237,31 @@ void HipCommandList::Dispatch(ShadingState* s, uint32 gx, uint32 gy, uint32 gz) 
         const auto& c = s->Constants<LuminanceHistogramConstant>();
         Mip in = MipOf(s->Texture("LuminanceTexture"));
         ExpectGroups(f, gx, gy, gz, Groups(c.TextureWidth, 16), Groups(c.TextureHeight, 16), 1);
-        Check(pbr_lum_histogram(mCtx, in.ptr, c.TextureWidth, c.TextureHeight, in.w, c.MinLogLuminance, c.InvLogLuminanceRange,
-                                (uint32_t*)s->Buffer("LuminanceHistogram")->DevicePtr()), "pbr_lum_histogram");
+        uint32_t* hist = (uint32_t*)s->Buffer("LuminanceHistogram")->DevicePtr();
+        // multi-GPU: only the interior rectangle of the (apron-extended) target is counted
+        const Rect r = mInterior.w ? mInterior : Rect{0, 0, in.w, in.h};
+        if (r.x + r.w > in.w || r.y + r.h > in.h || c.TextureWidth != r.w || c.TextureHeight != r.h)
+            throw HipException("hdr_luminance_histogram: TextureWidth/Height must be the interior rectangle's size");
+        Check(pbr_lum_histogram(mCtx, in.ptr + 4 * ((size_t)r.y * in.w + r.x), r.w, r.h, in.w, c.MinLogLuminance, c.InvLogLuminanceRange, hist),
+              "pbr_lum_histogram");
+        if (mCaptureHistogram) {
+            Check(pbr_sync(mCtx), "pbr_sync");
+            mCapturedHistogram.resize(256);
+            ThrowIfFailed(hipMemcpy(mCapturedHistogram.data(), hist, 1024, hipMemcpyDeviceToHost), "read histogram");
+        }
     } else if (f == "hdr_average_histogram.hlsl") {
         const auto& c = s->Constants<AverageLuminanceConstant>();
         ExpectGroups(f, gx, gy, gz, 1, 1, 1);
         uint32_t* hist = (uint32_t*)s->Buffer("LuminanceHistogram")->DevicePtr();
         // new step: with several GPUs the tile histograms are summed first; no-op on one GPU
         Check(pbr_allreduce_hist(mCtx, hist), "pbr_allreduce_hist");
+        if (!mExternalHistogram.empty()) {   // the same sum where the other tiles' counts arrive through the host
+            Check(pbr_sync(mCtx), "pbr_sync");
+            std::vector<uint32> mine(256);
+            ThrowIfFailed(hipMemcpy(mine.data(), hist, 1024, hipMemcpyDeviceToHost), "read histogram");
+            for (int i = 0; i < 256; i++) mine[i] += mExternalHistogram[i];
+            ThrowIfFailed(hipMemcpy(hist, mine.data(), 1024, hipMemcpyHostToDevice), "write histogram");
+        }
         Check(pbr_lum_average(mCtx, hist, c.PixelCount, c.MinLogLuminance, c.LogLuminanceRange, mGlobal.DeltaTime,
                               (float*)s->Buffer("AverageLuminance")->DevicePtr()), "pbr_lum_average");
     } else {
@@ -247,8 +297,11 @@ void HipCommandList::DrawScreen(ShadingState* s) {
                                  mNumLights, (pbr_half*)mRenderTarget->DevicePtr(), w), "pbr_deferred_shade");
     } else if (f == "hdr_tone_mapping.hlsl") {
         Mip in = MipOf(s->Texture("LuminanceTexture"));
-        Check(pbr_tonemap(mCtx, in.ptr, in.w, in.h, in.w, (const float*)s->Buffer("AverageLuminance")->DevicePtr(),
-                          (uint32_t*)mRenderTarget->DevicePtr(), mRenderTarget->Width()), "pbr_tonemap");
+        // multi-GPU: only the interior rectangle is tone-mapped (the apron belongs to the neighbours)
+        const Rect r = mInterior.w ? mInterior : Rect{0, 0, in.w, in.h};
+        if (r.x + r.w > in.w || r.y + r.h > in.h || mRenderTarget->Width() < in.w) throw HipException("hdr_tone_mapping: interior rectangle outside the target");
+        Check(pbr_tonemap(mCtx, in.ptr + 4 * ((size_t)r.y * in.w + r.x), r.w, r.h, in.w, (const float*)s->Buffer("AverageLuminance")->DevicePtr(),
+                          (uint32_t*)mRenderTarget->DevicePtr() + (size_t)r.y * mRenderTarget->Width() + r.x, mRenderTarget->Width()), "pbr_tonemap");
     } else {
         throw HipException("DrawScreen: " + std::string(f) + " is not a full-screen kernel of this build");
     }

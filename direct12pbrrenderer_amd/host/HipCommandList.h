@@ -6,6 +6,9 @@
 // executes in order on one stream, which gives the ordering the reference gets from its single
 // DIRECT queue (it issues no UAV barriers between dependent dispatches).
 #pragma once
+#include <string>
+#include <vector>
+
 #include "IPipeline.h"
 
 namespace MRendererHip {
@@ -17,7 +20,7 @@ public:
     HipCommandList(const HipCommandList&) = delete;
     HipCommandList& operator=(const HipCommandList&) = delete;
 
-    void BeginFrame() { mDispatchCount = 0; }
+    void BeginFrame() { mDispatchCount = 0; mEventLog.clear(); }
     void EndFrame();   // D3D12Device::EndFrame blocks on the fence every frame (D3D12Device.cpp:993-1003)
 
     // global constants (b2), RenderScheduler.cpp:22-41
@@ -30,6 +33,18 @@ public:
     void SetDepthStencil(DeviceTexture2D* ds) { mDepthStencil = ds; }
     // multi-GPU: the region of the full frame this device renders; default = whole target
     void SetTile(const pbr_tile& tile) { mTile = tile; }
+    // multi-GPU: the part of the render target this device OWNS (the rest is the apron it shades only to feed bloom):
+    // the luminance histogram counts, and the tone-map writes, interior pixels only.  w == 0: the whole target.
+    struct Rect { uint32 x = 0, y = 0, w = 0, h = 0; };
+    void SetInterior(const Rect& r) { mInterior = r; }
+    const Rect& Interior() const { return mInterior; }
+    // multi-GPU without a communicator (several tiles rendered one after the other on one device: tests, a host that
+    // moves the 1 KiB itself): counts of the OTHER tiles, added to this tile's histogram before the average — what
+    // pbr_allreduce_hist does over RCCL when pbr_comm_init was called.  nullptr: none.
+    void SetExternalHistogram(const uint32* counts256);
+    // keep a host copy of the tile's own histogram (before external counts / the all-reduce) of the next frames
+    void CaptureHistogram(bool on) { mCaptureHistogram = on; }
+    const std::vector<uint32>& CapturedHistogram() const { return mCapturedHistogram; }
 
     // compute dispatch of `state`'s shader; (x,y,z) are thread-GROUP counts exactly as the reference passes them
     void Dispatch(ShadingState* state, uint32 thread_group_count_x, uint32 thread_group_count_y, uint32 thread_group_count_z);
@@ -54,6 +69,12 @@ public:
     // BloomPass::Execute's sixteen dispatches (pbr_bloom); mip_chain / temp are scratch afterwards
     void Bloom(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, DeviceTexture2D* temp, float threshold, float knee);
 
+    // Named ranges around pass bodies, where the reference has PIXScopedEvent (DeferredPipeline.cpp:8 `PIXScope`): roctx
+    // ranges here, visible to rocprofv3 --marker-trace.  libroctx64 is looked up at run time; absent = no-op.
+    void BeginEvent(const char* name);
+    void EndEvent();
+    const std::vector<std::string>& EventLog() const { return mEventLog; }   // names pushed since BeginFrame (tests)
+
     pbr_ctx* Context() const { return mCtx; }
     uint32 DispatchCount() const { return mDispatchCount; }
     DeviceTexture2D* Presented() const { return mPresented; }
@@ -73,9 +94,27 @@ private:
     DeviceTexture2D* mDepthStencil = nullptr;
     bool mFusedPasses = false;
     pbr_tile mTile{};
+    Rect mInterior{};
+    std::vector<uint32> mExternalHistogram, mCapturedHistogram;
+    bool mCaptureHistogram = false;
+    std::vector<std::string> mEventLog;
     // padded copies of prefiltered env chains (pbr_env_pad), keyed by the plain texture; rebuilt after
     // env_map_gen.hlsl rewrites the texture
     std::map<const DeviceTexture2DArray*, std::unique_ptr<DeviceStructuredBuffer>> mPaddedEnv;
 };
+
+// RAII twin of the reference's PIXScope(cmd, name) macro (DeferredPipeline.cpp:8)
+class PixScope {
+public:
+    PixScope(HipCommandList* cmd, const char* name) : mCmd(cmd) { mCmd->BeginEvent(name); }
+    ~PixScope() { mCmd->EndEvent(); }
+    PixScope(const PixScope&) = delete;
+    PixScope& operator=(const PixScope&) = delete;
+private:
+    HipCommandList* mCmd;
+};
+#define PBR_PIX_CAT2(a, b) a##b
+#define PBR_PIX_CAT(a, b) PBR_PIX_CAT2(a, b)
+#define PIXScope(cmd, name) ::MRendererHip::PixScope PBR_PIX_CAT(pix_scope_, __LINE__)((cmd), (name))
 
 }  // namespace MRendererHip

@@ -145,6 +145,43 @@ int pbrh_set_initial_luminance(pbrh_renderer* r, float v) {
     return guarded(r, [&] { r->pipeline->mAutoExposurePass->SetInitialLuminance(v); });
 }
 
+int pbrh_set_tile(pbrh_renderer* r, uint32_t x0, uint32_t y0, uint32_t full_w, uint32_t full_h,
+                  uint32_t ix, uint32_t iy, uint32_t iw, uint32_t ih) {
+    return guarded(r, [&] {
+        if (x0 + r->width > full_w || y0 + r->height > full_h) throw HipException("pbrh_set_tile: the target does not fit the frame");
+        if (iw == 0 || ih == 0 || ix + iw > r->width || iy + ih > r->height) throw HipException("pbrh_set_tile: interior outside the target");
+        HipCommandList* cmd = r->scheduler->CommandList();
+        cmd->SetTile(pbr_tile{x0, y0, r->width, r->height, full_w, full_h});
+        cmd->SetInterior(HipCommandList::Rect{ix, iy, iw, ih});
+        r->pipeline->mAutoExposurePass->SetFullFramePixelCount(full_w * full_h);
+        // the camera sees the FULL frame (App.cpp:99-101 with the frame's aspect ratio)
+        r->camera = std::make_unique<Camera>(0.333f * 3.14159265359f, full_w, full_h, 0.1f, 1000.0f);
+        r->camera->Move(Vector3{0, 3, 10});
+        r->camera->Rotate(0, 3.14159265359f, 0);
+    });
+}
+
+int pbrh_comm_init(pbrh_renderer* r, int world, int rank, const void* uid) {
+    return guarded(r, [&] {
+        pbr_ctx* ctx = r->scheduler->CommandList()->Context();
+        if (pbr_comm_init(ctx, world, rank, uid) != PBR_OK) throw HipException(pbr_last_error(ctx));
+    });
+}
+
+int pbrh_set_external_histogram(pbrh_renderer* r, const uint32_t* counts256) {
+    return guarded(r, [&] { r->scheduler->CommandList()->SetExternalHistogram(counts256); });
+}
+int pbrh_capture_histogram(pbrh_renderer* r, int on) {
+    return guarded(r, [&] { r->scheduler->CommandList()->CaptureHistogram(on != 0); });
+}
+int pbrh_captured_histogram(pbrh_renderer* r, uint32_t* dst256) {
+    return guarded(r, [&] {
+        const auto& h = r->scheduler->CommandList()->CapturedHistogram();
+        if (h.size() != 256) throw HipException("pbrh_captured_histogram: no frame was rendered with capture on");
+        std::memcpy(dst256, h.data(), 1024);
+    });
+}
+
 int pbrh_render(pbrh_renderer* r, float dt) {
     return guarded(r, [&] {
         r->time += dt;
@@ -179,6 +216,17 @@ int pbrh_execution_order(pbrh_renderer* r, char* buf, size_t len) {
         }
         std::snprintf(buf, len, "%s", s.c_str());
     });
+}
+
+int pbrh_event_log(const pbrh_renderer* r, char* buf, size_t len) {
+    if (!r || !buf || !len) return -1;
+    std::string s;
+    for (const std::string& e : r->scheduler->CommandList()->EventLog()) {
+        if (!s.empty()) s += ">";
+        s += e;
+    }
+    std::snprintf(buf, len, "%s", s.c_str());
+    return 0;
 }
 
 int pbrh_dispatch_count(const pbrh_renderer* r) { return r ? (int)r->scheduler->CommandList()->DispatchCount() : -1; }

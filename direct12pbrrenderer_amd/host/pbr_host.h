@@ -27,6 +27,20 @@ int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, con
  * pbr_gbuffer_encode in pbr_hip.h); GBufferPass encodes them on the GPU */
 int pbrh_set_materials(pbrh_renderer* r, const float* m0, const float* m1, const float* m2, const float* depth, const uint8_t* stencil);
 int pbrh_set_initial_luminance(pbrh_renderer* r, float v);
+/* ---- multi-GPU: this renderer's target is the apron-extended tile at (x0, y0) of a full_w x full_h frame;
+ * it OWNS the interior rectangle (ix, iy, iw, ih) of its target.  uv / camera ray / ClusterIndex use global pixels, the
+ * camera's aspect ratio is the full frame's, the histogram counts and the tone-map writes the interior only, and the
+ * average divides by the full frame's pixel count. */
+int pbrh_set_tile(pbrh_renderer* r, uint32_t x0, uint32_t y0, uint32_t full_w, uint32_t full_h,
+                  uint32_t ix, uint32_t iy, uint32_t iw, uint32_t ih);
+/* one process per GPU: RCCL communicator of the context (unique id from pbr_comm_unique_id on rank 0); the average
+ * pass then all-reduces the 256-bin histogram (pbr_allreduce_hist) */
+int pbrh_comm_init(pbrh_renderer* r, int world, int rank, const void* unique_id_128_bytes);
+/* no communicator (tiles rendered one after the other on one device, or a host that moves the 1 KiB itself): the
+ * other tiles' counts, added before the average (NULL: none); and a host copy of this tile's own counts */
+int pbrh_set_external_histogram(pbrh_renderer* r, const uint32_t* counts256);
+int pbrh_capture_histogram(pbrh_renderer* r, int on);
+int pbrh_captured_histogram(pbrh_renderer* r, uint32_t* dst256);
 /* on: ClusteredPass and BloomPass hand their fixed dispatch sequences over as one call each (pbr_clustered, pbr_bloom);
  * off (default): every reference dispatch is issued one by one.  Same results. */
 int pbrh_set_fused(pbrh_renderer* r, int on);
@@ -37,6 +51,8 @@ int pbrh_render(pbrh_renderer* r, float delta_time);
 /* "PreFilterEnvMap>PrecomputeBRDF>..." */
 int pbrh_execution_order(pbrh_renderer* r, char* buf, size_t len);
 int pbrh_dispatch_count(const pbrh_renderer* r);
+/* the named ranges (the reference's PIXScope strings; roctx ranges here) the last frame opened, '>'-separated, in order */
+int pbrh_event_log(const pbrh_renderer* r, char* buf, size_t len);
 /* copy a frame-graph resource (by its FGResourceIDs name) to host memory; returns bytes copied or <0 */
 long pbrh_read(pbrh_renderer* r, const char* resource_name, void* dst, size_t dst_bytes);
 /* the global constants the last frame used (412 bytes) */

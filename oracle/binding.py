@@ -71,7 +71,7 @@ def lib():
         L.orc_deferred_shade.argtypes = [C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer), _vp, _u32, _vp, _u32,
                                          _u32, _vp, _vp, _vp, _u32, _vp]
         L.orc_deferred_shade_sens.argtypes = [C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer), _vp, _u32, _vp, _u32,
-                                              _u32, _vp, _vp, _vp, _u32, _vp, _vp]
+                                              _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp]
         L.orc_skybox.argtypes = [C.POINTER(Global), C.POINTER(Tile), _vp, _u32, _u32, _vp, _u32, _vp, _u32]
         L.orc_gbuffer_encode.argtypes = [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]
         L.orc_rgbe_decode.argtypes = [_vp, C.c_size_t, _vp]
@@ -232,7 +232,8 @@ def cluster_cull(g, lights, clusters):
 
 def deferred_shade(g, tile: Tile, gb, lut, env, env_size, env_mips, clusters, lights, hdr=None, want_f32=False, want_sens=False):
     """gb: dict of numpy planes [h,w]; returns (hdr half [h,w,4], hdr fp32 or None[, sens fp32 [h,w,3]]).
-    sens (want_sens): first-order change of the colour per unit error of N.H — the fp32 conditioning of the pixel."""
+    sens (want_sens): float32 [2, h, w, 3] — [0] first-order change of the colour per unit error of N.H (the fp32
+    conditioning of the GGX term), [1] what one 1/256-texel step of the fixed-point sampler changes in the IBL term."""
     h, w = gb["A"].shape
     planes = {k: np.ascontiguousarray(v) for k, v in gb.items()}
     s = GBuffer(planes["A"].ctypes.data, planes["B"].ctypes.data, planes["C"].ctypes.data,
@@ -242,10 +243,11 @@ def deferred_shade(g, tile: Tile, gb, lut, env, env_size, env_mips, clusters, li
     f32 = np.zeros((h, w, 4), dtype=np.float32) if want_f32 else None
     lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
     lut = np.ascontiguousarray(lut)
-    sens = np.zeros((h, w, 3), dtype=np.float32) if want_sens else None
+    sens = np.zeros((2, h, w, 3), dtype=np.float32) if want_sens else None   # [0] = N.H sensitivity, [1] = sampler-step flip
     _ok(lib().orc_deferred_shade_sens(C.byref(g), C.byref(tile), C.byref(s), _p(lut), lut.shape[0], _p(env), env_size, env_mips,
                                       _p(clusters), _p(lights) if len(lights) else None, _p(hdr), w,
-                                      _p(f32) if want_f32 else None, _p(sens) if want_sens else None), "deferred_shade")
+                                      _p(f32) if want_f32 else None, _p(sens[0]) if want_sens else None,
+                                      _p(sens[1]) if want_sens else None), "deferred_shade")
     return (hdr, f32, sens) if want_sens else (hdr, f32)
 
 

@@ -190,6 +190,24 @@ static inline void cube_face_uv(V3 d, uint32_t& face, float& u, float& v) {
     v = (tc / ma + 1.0f) * 0.5f;
 }
 
+// the same projection onto the face of a GIVEN major axis (0 x, 1 y, 2 z) — conditioning reports only: what the
+// sample would be had a near-tie between two components been decided the other way
+static inline void cube_face_uv_axis(V3 d, int axis, uint32_t& face, float& u, float& v) {
+    float sc, tc, ma;
+    if (axis == 0) {
+        ma = fabsf(d.x);
+        if (d.x >= 0.0f) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; }
+    } else if (axis == 1) {
+        ma = fabsf(d.y);
+        if (d.y >= 0.0f) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; }
+    } else {
+        ma = fabsf(d.z);
+        if (d.z >= 0.0f) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; }
+    }
+    u = (sc / ma + 1.0f) * 0.5f;
+    v = (tc / ma + 1.0f) * 0.5f;
+}
+
 static inline size_t cube_mip_offset(uint32_t size, uint32_t mip) {
     size_t off = 0;
     for (uint32_t m = 0; m < mip; m++) { size_t s = size >> m; off += 6 * s * s; }
@@ -212,15 +230,36 @@ static inline F4 cube_fetch_seamless(int s, uint32_t face, int x, int y, Texel t
 }
 
 template <class Texel>
-static inline F4 cube_bilinear(int s, V3 dir, Texel texel) {
-    uint32_t face; float u, v;
-    cube_face_uv(dir, face, u, v);
+static inline F4 cube_bilinear_uv(int s, uint32_t face, float u, float v, Texel texel) {
     BilinearCoord cx = bilinear_coord(u, s), cy = bilinear_coord(v, s);
     F4 c00 = cube_fetch_seamless(s, face, cx.i0, cy.i0, texel);
     F4 c10 = cube_fetch_seamless(s, face, cx.i1, cy.i0, texel);
     F4 c01 = cube_fetch_seamless(s, face, cx.i0, cy.i1, texel);
     F4 c11 = cube_fetch_seamless(s, face, cx.i1, cy.i1, texel);
     return bilerp(c00, c10, c01, c11, cx.f, cy.f);
+}
+template <class Texel>
+static inline F4 cube_bilinear(int s, V3 dir, Texel texel) {
+    uint32_t face; float u, v;
+    cube_face_uv(dir, face, u, v);
+    return cube_bilinear_uv(s, face, u, v, texel);
+}
+
+// the trilinear fetch at given face coordinates (conditioning reports only: the shaders address cubes by direction)
+template <class MipTexel>
+static inline F4 cube_trilinear_uv(uint32_t size, uint32_t mips, uint32_t face, float u, float v, float lod, MipTexel mt) {
+    float maxl = (float)(mips - 1);
+    if (!(lod == lod)) lod = 0.0f;
+    lod = lod < 0.0f ? 0.0f : (lod > maxl ? maxl : lod);
+    lod = snap8(lod);
+    float fl = floorf(lod);
+    uint32_t l0 = (uint32_t)fl;
+    uint32_t l1 = l0 + 1 < mips ? l0 + 1 : mips - 1;
+    float f = lod - fl;
+    F4 a = cube_bilinear_uv((int)(size >> l0), face, u, v, mt(l0));
+    if (f == 0.0f || l1 == l0) return a;
+    F4 b = cube_bilinear_uv((int)(size >> l1), face, u, v, mt(l1));
+    return fma4(b, f, a * (1.0f - f));
 }
 
 // TextureCube.SampleLevel(SamplerLinearClamp (MIN_MAG_MIP_LINEAR), dir, lod)
@@ -776,21 +815,28 @@ int orc_deferred_shade(const pbr_global* g, const pbr_tile* tile, const pbr_gbuf
                        const uint16_t* env, uint32_t env_size, uint32_t env_mips,
                        const pbr_cluster* clusters, const pbr_light* lights,
                        uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32) {
-    return orc_deferred_shade_sens(g, tile, gb, lut, lut_res, env, env_size, env_mips, clusters, lights, hdr, hdr_pitch, hdr_f32, nullptr);
+    return orc_deferred_shade_sens(g, tile, gb, lut, lut_res, env, env_size, env_mips, clusters, lights, hdr, hdr_pitch, hdr_f32, nullptr, nullptr);
 }
 
 // The same pass, optionally reporting how ILL-CONDITIONED each pixel's colour is in fp32 (sens_rgb, 3 floats per
 // pixel, may be null).  distribution_ggx computes t = NdotH^2 (a^4 - 1) + 1: near a highlight (NdotH -> 1) this cancels
 // down to ~a^4 = roughness^8, so a rounding error e in NdotH changes D = a^4 / (pi t^2) by the factor
 // 4 NdotH (1 - a^4) / t * e — up to 4 / roughness^8 (2.5e6 at roughness 0.19).  sens = sum over the pixel's lights of
-// |specular contribution| * 4 NdotH (1 - a^4) / t: first-order change of the colour per unit error of NdotH.  Any two
+// |specular contribution| * 4 NdotH (1 - a^4) / t / min(1, |L + V|): first-order change of the colour per unit rounding
+// error in the components of H (at grazing incidence L ~ -V the sum L + V cancels before it is normalised).  Any two
 // fp32 evaluations of the shader (this one, a GPU's, the reference's own on another driver) differ by a few 2^-24 in
 // NdotH, i.e. by a few 2^-24 * sens in the colour; parity tests allow exactly that on top of their relative bound.
+//
+// flip_rgb (3 floats per pixel, may be null): the sampler model snaps texel coordinates to x.8 fixed point, so the
+// filtered value is a STEP function of the coordinate with steps of 1/256 texel.  A coordinate that sits within a
+// rounding error of a step edge lands on either side depending on who evaluates the reflection vector (IEEE divide vs
+// reciprocal, contraction, ...).  flip = the largest change of the IBL specular term when the env sample moves by one
+// step of its coarser mip in u or v, or the LUT sample by one step in N.V: what ONE such flip can cost this pixel.
 int orc_deferred_shade_sens(const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
                             const uint16_t* lut, uint32_t lut_res,
                             const uint16_t* env, uint32_t env_size, uint32_t env_mips,
                             const pbr_cluster* clusters, const pbr_light* lights,
-                            uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32, float* sens_rgb) {
+                            uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32, float* sens_rgb, float* flip_rgb) {
     if (!g || !tile || !gb || !lut || !env || !clusters || !hdr) return PBR_ERR_INVALID;
     CubeF16 cube{env, env_size, env_mips};
     // vs_main, deferred_shading.hlsl:91-121
@@ -838,6 +884,44 @@ int orc_deferred_shade_sens(const pbr_global* g, const pbr_tile* tile, const pbr
                 return f4(f16_to_f32(p[0]), f16_to_f32(p[1]), 0.0f, 0.0f); };
             F4 lb = bilerp(lutat(x0, y0), lutat(x1, y0), lutat(x0, y1), lutat(x1, y1), cx.f, cy.f);
             V3 env_specular = v3(envc.x, envc.y, envc.z) * (F0 * lb.x + v3(lb.y, lb.y, lb.y));
+            V3 flip = v3(0, 0, 0);
+            if (flip_rgb) {   // conditioning report only
+                auto amax = [](V3 a, V3 b) { return v3(fmaxf(a.x, fabsf(b.x)), fmaxf(a.y, fabsf(b.y)), fmaxf(a.z, fabsf(b.z))); };
+                uint32_t face; float cu, cv;
+                cube_face_uv(R, face, cu, cv);
+                float lod = roughness * (float)PBR_ENV_MIPS;
+                float lc = lod < 0.0f ? 0.0f : (lod > (float)(env_mips - 1) ? (float)(env_mips - 1) : lod);
+                uint32_t l1 = (uint32_t)floorf(snap8(lc)) + 1;
+                if (l1 > env_mips - 1) l1 = env_mips - 1;
+                float step = 1.0f / (256.0f * (float)(env_size >> l1));
+                V3 spec_w = F0 * lb.x + v3(lb.y, lb.y, lb.y);
+                V3 e0 = v3(envc.x, envc.y, envc.z);
+                const float du[4] = {step, -step, 0.0f, 0.0f}, dv[4] = {0.0f, 0.0f, step, -step};
+                for (int k = 0; k < 4; k++) {
+                    F4 e = cube_trilinear_uv(env_size, env_mips, face, cu + du[k], cv + dv[k], lod, cube);
+                    flip = amax(flip, (v3(e.x, e.y, e.z) - e0) * spec_w);
+                }
+                // a near-tie between the two largest components of R picks the face; the model's seamless rule is only
+                // approximately continuous across a face edge (coarse mips!), so the other face may give another value
+                {
+                    float ab[3] = {fabsf(R.x), fabsf(R.y), fabsf(R.z)};
+                    int major = face >> 1;
+                    for (int ax = 0; ax < 3; ax++) {
+                        if (ax == major || ab[ax] < ab[major] * (1.0f - 1e-5f)) continue;
+                        uint32_t f2; float u2, v2;
+                        cube_face_uv_axis(R, ax, f2, u2, v2);
+                        F4 e = cube_trilinear_uv(env_size, env_mips, f2, u2, v2, lod, cube);
+                        flip = amax(flip, (v3(e.x, e.y, e.z) - e0) * spec_w);
+                    }
+                }
+                float ls = 1.0f / (256.0f * (float)lut_res);
+                for (int k = -1; k <= 1; k += 2) {
+                    BilinearCoord cy2 = bilinear_coord(NdotV + (float)k * ls, (int)lut_res);
+                    int yy0 = clampi(cy2.i0, 0, (int)lut_res - 1), yy1 = clampi(cy2.i1, 0, (int)lut_res - 1);
+                    F4 l2 = bilerp(lutat(x0, yy0), lutat(x1, yy0), lutat(x0, yy1), lutat(x1, yy1), cx.f, cy2.f);
+                    flip = amax(flip, e0 * (F0 * (l2.x - lb.x) + v3(l2.y - lb.y, l2.y - lb.y, l2.y - lb.y)));
+                }
+            }
 
             // point lights :159-186
             int ci = cluster_index_uv(g, u, v, z_vs);
@@ -863,6 +947,11 @@ int orc_deferred_shade_sens(const pbr_global* g, const pbr_tile* tile, const pbr
                         V3 diffuse = ((v3(1.0f, 1.0f, 1.0f) - fresnel(NdotL, F0)) * (1.0f - metallic) * albedo) * INV_PI_F;
                         V3 spec = f - diffuse;
                         float amp = 4.0f * NdotH * (1.0f - a4) / fabsf(t);
+                        // H = normalize(L + V): at grazing incidence |L + V| << 1 and the components of L + V (absolute
+                        // rounding error ~2^-24 each) are relatively that much less accurate
+                        V3 wv = dir + view;
+                        float wl = sqrtf(dot3(wv, wv));
+                        if (wl < 1.0f) amp /= fmaxf(wl, 1e-6f);
                         V3 c = (((spec * col) * lt.Intensity) * att) * NdotL;
                         sens = sens + v3(fabsf(c.x), fabsf(c.y), fabsf(c.z)) * amp;
                     }
@@ -874,6 +963,7 @@ int orc_deferred_shade_sens(const pbr_global* g, const pbr_tile* tile, const pbr
             store_h4(hdr + 4 * oi, f4(out.x, out.y, out.z, 1.0f));
             if (hdr_f32) { hdr_f32[4 * oi] = out.x; hdr_f32[4 * oi + 1] = out.y; hdr_f32[4 * oi + 2] = out.z; hdr_f32[4 * oi + 3] = 1.0f; }
             if (sens_rgb) { sens_rgb[3 * oi] = sens.x; sens_rgb[3 * oi + 1] = sens.y; sens_rgb[3 * oi + 2] = sens.z; }
+            if (flip_rgb) { flip_rgb[3 * oi] = flip.x; flip_rgb[3 * oi + 1] = flip.y; flip_rgb[3 * oi + 2] = flip.z; }
         }
     }
     return PBR_OK;

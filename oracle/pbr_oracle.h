@@ -85,12 +85,13 @@ int orc_deferred_shade(const pbr_global* g, const pbr_tile* tile, const pbr_gbuf
                        const uint16_t* env, uint32_t env_size, uint32_t env_mips,
                        const pbr_cluster* clusters, const pbr_light* lights,
                        uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32_or_null);
-/* + per-pixel fp32 conditioning of the colour (see pbr_oracle.cpp): first-order change per unit error of N.H */
+/* + per-pixel fp32 conditioning of the colour (see pbr_oracle.cpp): sens = first-order change per unit error of N.H;
+   flip = what one 1/256-texel step of the fixed-point sampler can change in the IBL specular term */
 int orc_deferred_shade_sens(const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
                        const uint16_t* lut, uint32_t lut_res,
                        const uint16_t* env, uint32_t env_size, uint32_t env_mips,
                        const pbr_cluster* clusters, const pbr_light* lights,
-                       uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32_or_null, float* sens_rgb_or_null); /* a8-a12 */
+                       uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32_or_null, float* sens_rgb_or_null, float* flip_rgb_or_null); /* a8-a12 */
 int orc_skybox(const pbr_global* g, const pbr_tile* tile, const float* sky, uint32_t sky_size, uint32_t sky_mips,
                const uint8_t* stencil, uint32_t pitch, uint16_t* hdr, uint32_t hdr_pitch);                  /* 8f-1 */
 int orc_gbuffer_encode(const float* m0, const float* m1, const float* m2, uint32_t w, uint32_t h, uint32_t pitch,

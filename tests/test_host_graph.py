@@ -44,6 +44,12 @@ def host():
     L.pbrh_get_global.argtypes = [C.c_void_p, C.c_void_p]
     L.pbrh_probe_binding.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.pbrh_dry_run_execution_order.argtypes = [C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.pbrh_event_log.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.pbrh_set_tile.argtypes = [C.c_void_p] + [C.c_uint32] * 8
+    L.pbrh_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.pbrh_set_external_histogram.argtypes = [C.c_void_p, C.c_void_p]
+    L.pbrh_capture_histogram.argtypes = [C.c_void_p, C.c_int]
+    L.pbrh_captured_histogram.argtypes = [C.c_void_p, C.c_void_p]
     return L
 
 
@@ -106,6 +112,16 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
         assert host.pbrh_dispatch_count(r) == 5 + 1 + 2 + 1 + 1 + 16 + 2 + 1      # first frame incl. one-shot IBL; sky draw + shade
         buf = C.create_string_buffer(512)
         assert host.pbrh_execution_order(r, buf, 512) == 0 and buf.value.decode() == REFERENCE_ORDER
+        # named ranges = the reference's PIXScope strings, in its nesting order (DeferredPipeline.cpp:65-562); roctx here
+        ev = C.create_string_buffer(2048)
+        assert host.pbrh_event_log(r, ev, 2048) == 0
+        down = ["Blur Horizontal", "Blur Vertical"] * 3
+        up = ["Upsample Horizontal Add", "Blur Vertical"] * 3
+        assert ev.value.decode().split(">") == (
+            ["Precompute PrefilterEnvMap Pass", "Precompute BRDF Pass", "Clustered Pass", "Gbuffer Pass", "Skybox Pass", "Deferred Shading",
+             "Bloom Pass", "Bloom Prefilter", "Bloom Downsample"] + down + ["Bloom Upsample"] + up +
+            ["Upsample Merge", "Blur Horizontal", "Blur Vertical", "Merge", "Auto Exposure Pass", "Luminance Histogram Pass",
+             "Average Luminance Pass", "Tone Mapping Pass"])
 
         def read(name, shape, dtype):
             a = np.zeros(shape, dtype=dtype)
@@ -266,3 +282,97 @@ def test_host_fused_passes_equal_dispatch_by_dispatch(host):
     assert np.array_equal(staged["DeferredShadingRT"].view(np.uint16), fused["DeferredShadingRT"].view(np.uint16))
     assert np.array_equal(staged["ToneMappedTexture"], fused["ToneMappedTexture"])
     assert staged["AverageLuminance"][0] == fused["AverageLuminance"][0] != np.float32(0.18)
+
+
+@pytest.mark.gpu
+def test_host_graph_two_tiles_with_apron_reproduce_the_single_frame(host):
+    """SURVEY 8e through the C++ pass graph: the frame cut into two tiles, each rendered by its own
+    DeferredRenderPipeline on an apron-extended target (pbrh_set_tile: global-pixel addressing, interior-only histogram
+    and tone-map, full-frame PixelCount).  The 1 KiB histogram exchange goes through the host here (one GPU: the tiles
+    are rendered one after the other; with one process per GPU pbrh_comm_init makes the same pass all-reduce over RCCL).
+    Interiors must equal the single-frame render: HDR <= 2 fp16 ulp, identical exposure, LDR <= 1 LSB."""
+    from direct12pbrrenderer_amd import scene
+    from direct12pbrrenderer_amd.pipeline import tile_for_rank
+    TW, H, ENV, LUT, NL = 512, 288, 32, 64, 64
+    W = 2 * TW
+    sky_np = synth.env_cube(ENV)
+    cam = scene.Camera.reference_default(W, H)
+    lights = synth.lights_in_view_box(NL, cam)
+    packed = np.ascontiguousarray(np.concatenate([lights["Position"], lights["Color"], np.full((NL, 1), 2.0, np.float32),
+                                                  lights["Intensity"][:, None]], axis=1).astype(np.float32))
+    err = C.create_string_buffer(256)
+
+    def make(spec):
+        r = host.pbrh_create(0, spec.ew, spec.eh, ENV, LUT, err, 256)
+        assert r, err.value
+        assert host.pbrh_set_skybox(r, sky_np[:4 * 6 * ENV * ENV].ctypes.data, ENV) == 0, host.pbrh_last_error(r)
+        assert host.pbrh_set_lights(r, packed.ctypes.data, NL) == 0
+        gb = synth.gbuffer_tile(spec.ex0, spec.ey0, spec.ew, spec.eh, spec.full_w, spec.full_h, coverage_mask=False)
+        assert host.pbrh_set_gbuffer(r, *[np.ascontiguousarray(gb[k]).ctypes.data for k in ("A", "B", "C", "depth", "stencil")]) == 0
+        assert host.pbrh_set_initial_luminance(r, 0.18) == 0
+        if spec.apron:
+            assert host.pbrh_set_tile(r, spec.ex0, spec.ey0, spec.full_w, spec.full_h, spec.ix, spec.iy, spec.w, spec.h) == 0, host.pbrh_last_error(r)
+        return r
+
+    def read(r, name, shape, dtype):
+        a = np.zeros(shape, dtype=dtype)
+        assert host.pbrh_read(r, name.encode(), a.ctypes.data, a.nbytes) == a.nbytes, host.pbrh_last_error(r)
+        return a
+
+    from direct12pbrrenderer_amd.pipeline import TileSpec
+    full_spec = TileSpec(0, 0, W, H, W, H, 0)
+    rf = make(full_spec)
+    try:
+        assert host.pbrh_render(rf, 1.0 / 60.0) == 0, host.pbrh_last_error(rf)
+        hdr_f = read(rf, "DeferredShadingRT", (H, W, 4), np.float16)
+        ldr_f = read(rf, "ToneMappedTexture", (H, W), np.uint32)
+        avg_f = read(rf, "AverageLuminance", (1,), np.float32)[0]
+    finally:
+        host.pbrh_destroy(rf)
+    specs = [tile_for_rank(k, 2, TW, H) for k in range(2)]
+    assert specs[0].apron == 256 and (specs[1].ex0, specs[1].ix) == (TW - 256, 256)
+    # pass 1: every tile's own histogram (captured before the average); pass 2: the other tile's counts added
+    hists = []
+    for spec in specs:
+        r = make(spec)
+        try:
+            assert host.pbrh_capture_histogram(r, 1) == 0
+            assert host.pbrh_render(r, 1.0 / 60.0) == 0, host.pbrh_last_error(r)
+            h = np.zeros(256, np.uint32)
+            assert host.pbrh_captured_histogram(r, h.ctypes.data) == 0
+            assert h.sum() == spec.w * spec.h            # interior pixels only
+            hists.append(h)
+        finally:
+            host.pbrh_destroy(r)
+    for k, spec in enumerate(specs):
+        r = make(spec)
+        try:
+            other = np.ascontiguousarray(hists[1 - k])
+            assert host.pbrh_set_external_histogram(r, other.ctypes.data) == 0
+            assert host.pbrh_render(r, 1.0 / 60.0) == 0, host.pbrh_last_error(r)
+            hdr = read(r, "DeferredShadingRT", (spec.eh, spec.ew, 4), np.float16)[spec.iy:spec.iy + spec.h, spec.ix:spec.ix + spec.w]
+            ldr = read(r, "ToneMappedTexture", (spec.eh, spec.ew), np.uint32)[spec.iy:spec.iy + spec.h, spec.ix:spec.ix + spec.w]
+            avg = read(r, "AverageLuminance", (1,), np.float32)[0]
+        finally:
+            host.pbrh_destroy(r)
+        assert avg == pytest.approx(float(avg_f), rel=1e-6)
+        d = common.half_ulp_diff(hdr[..., :3], hdr_f[spec.y0:spec.y0 + spec.h, spec.x0:spec.x0 + spec.w, :3])
+        assert d.max() <= 2 and (d > 0).mean() < 2e-3, (k, d.max(), (d > 0).mean())
+        b = ldr_f[spec.y0:spec.y0 + spec.h, spec.x0:spec.x0 + spec.w]
+        for c in range(3):
+            assert np.abs(((ldr >> (8 * c)) & 255).astype(np.int32) - ((b >> (8 * c)) & 255).astype(np.int32)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_host_graph_comm_contract(host):
+    """pbrh_comm_init forwards to the context's RCCL communicator: world 1 without an id is a no-op, a missing id at
+    world 2 is reported (the pass graph then refuses to average with world > 1 and no communicator)."""
+    err = C.create_string_buffer(256)
+    r = host.pbrh_create(0, 64, 64, 16, 32, err, 256)
+    assert r, err.value
+    try:
+        assert host.pbrh_comm_init(r, 1, 0, None) == 0
+        assert host.pbrh_comm_init(r, 2, 0, None) == -1 and b"unique id" in host.pbrh_last_error(r)
+        assert host.pbrh_set_tile(r, 0, 0, 32, 64, 0, 0, 32, 64) == -1      # target larger than the frame
+    finally:
+        host.pbrh_destroy(r)
