@@ -118,9 +118,14 @@ __device__ __forceinline__ f2 rcp2(f2 a) { return f2{rcp(a.x), rcp(a.y)}; }
 // v_pk_mul_f32 with the clamp output modifier: clamp(a * b, 0, 1) on both halves, free of charge.  Used for the
 // cosines N.L and N.H, which the shader clamps from below with max(., 0) and which cannot exceed 1 except by a
 // rounding error of normalised vectors (1 + 1e-7 becomes 1).
+// The s_nop on either side are REQUIRED: gfx950 needs one wait state between a transcendental (v_rsq / v_rcp) or a
+// packed-fp32 instruction and a VALU instruction that reads its result.  The compiler inserts those wait states for
+// the code it schedules, but it cannot see into an asm statement: without them this instruction consumed a v_rsq result
+// issued immediately before it and read the register's OLD value in the high half (second light of the pair) — found
+// as a parity failure that came and went with instruction scheduling.
 __device__ __forceinline__ f2 mul2_sat(f2 a, f2 b) {
     f2 r;
-    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 clamp\n\ts_nop 0" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 

@@ -220,17 +220,23 @@ def _shade_on_gpu(ctx, g, tile, gb, lut, env, env_size, env_mips, clusters_np, l
 
 
 def _check_shade(got, want, want_f32, stencil, what, hard_ulp=64, sens=None):
+    """The fp16 target against the oracle's.  sens = the oracle's report of its own fp32 conditioning per pixel
+    (orc_deferred_shade_sens: [0] GGX highlight sensitivity to the rounding of N.H, [1] one step of the fixed-point
+    sampler); pixels where that allowance is a sizeable part of the bound are ILL-CONDITIONED in the reference formula
+    itself and are held to the allowance only, all others to the plain bound and to the ULP limits."""
     on = stencil > 0
     scale = np.abs(want_f32[on][:, :3]).max()
     err = np.abs(got.astype(np.float32) - want.astype(np.float32))[on][:, :3]
-    # the fp16 target: one fp16 ulp of the largest value (scale * 2^-10) is the storage granularity, the 1e-4 relative
-    # L-inf bound of SURVEY 8c sits on top of it (the fp32 probe tests check that bound without the fp16 term); sens =
-    # the oracle's fp32 conditioning of the pixel (orc_deferred_shade_sens), for scenes with GGX highlights
-    allow = 1e-4 * scale + scale * 2.0 ** -10 + (8.0 * 2.0 ** -24 * sens[0][on] + sens[1][on] if sens is not None else 0.0)
-    assert (err <= allow).all(), f"{what}: L-inf {err.max()} vs scale {scale} (worst {np.max(err / allow):.2f} x the bound)"
+    # one fp16 ulp of the largest value (scale * 2^-10) is the storage granularity, the 1e-4 relative L-inf bound of
+    # SURVEY 8c sits on top of it (the fp32 probe tests check that bound without the fp16 term)
+    plain = 1e-4 * scale + scale * 2.0 ** -10
+    cond = (8.0 * 2.0 ** -24 * sens[0][on] + sens[1][on]) if sens is not None else np.zeros_like(err)
+    assert (err <= plain + cond).all(), f"{what}: L-inf {err.max()} vs scale {scale} (worst {np.max(err / (plain + cond)):.2f} x the bound)"
+    well = cond.max(axis=1) <= 0.25 * plain
+    assert well.mean() >= 0.97, f"{what}: only {well.mean():.3f} of the pixels are well-conditioned"
     # hard_ulp bounds the RELATIVE error of every channel; on a million-texel band a near-black channel (absolute error
     # still inside the L-inf bound above) can exceed it, so the full-size tests pass None
-    assert_half_close(got[on], want[on], 2, what, frac_over=1e-3, hard_ulp=hard_ulp)
+    assert_half_close(got[on][well], want[on][well], 2, what, frac_over=1e-3, hard_ulp=hard_ulp)
     assert np.all(got[on][:, 3] == 1.0)
 
 
@@ -240,11 +246,11 @@ def test_deferred_shade_64_vs_oracle_and_golden(ctx, orc, golden, ibl, n_lights)
     cam, g, lights, gb, tile = common.shade_scene(64, 64, n_lights, sh)
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
-    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
     assert np.array_equal(want, golden[f"shade64_l{n_lights}"])
     sentinel = np.full((64, 64, 4), 7.0, dtype=np.float16)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, prefill=sentinel)
-    _check_shade(got, want, want_f32, gb["stencil"], f"shade {n_lights} lights")
+    _check_shade(got, want, want_f32, gb["stencil"], f"shade {n_lights} lights", sens=sens)
     assert np.all(got[gb["stencil"] == 0] == 7.0)      # stencil == 0 pixels are left untouched
 
 
@@ -255,9 +261,9 @@ def test_deferred_shade_ragged_tile_of_a_larger_frame(ctx, orc, ibl):
     cam, g, lights, gb, tile = common.shade_scene(200, 37, 256, sh, full=(640, 360), x0=328, y0=91)
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
-    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
-    _check_shade(got, want, want_f32, gb["stencil"], "ragged tile")
+    _check_shade(got, want, want_f32, gb["stencil"], "ragged tile", sens=sens)
     # the same region shaded as part of the whole frame agrees with the tile
     cam2, g2, lights2, gbf, tilef = common.shade_scene(640, 360, 256, sh)
     full = _shade_on_gpu(ctx, g2, tilef, gbf, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights2)
@@ -567,8 +573,8 @@ def test_frame_1080p_region_properties_and_oracle_sample(ctx, orc, ibl):
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     band = {k: np.ascontiguousarray(v[y0:y0 + rows]) for k, v in gb.items()}
-    want, want_f32 = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
-    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "1080p band")
+    want, want_f32, sens = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
+    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "1080p band", sens=sens)
     fr.bloom()
     fr.histogram()
     hist = fr.hist.cpu().numpy().view(np.uint32).copy()
@@ -734,9 +740,9 @@ def test_deferred_shade_attenuation_floor_and_odd_lists(ctx, orc, ibl):
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     assert (cl["NumLights"] % 2 == 1).any()
-    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
-    _check_shade(got, want, want_f32, gb["stencil"], "attenuation floor / odd lists")
+    _check_shade(got, want, want_f32, gb["stencil"], "attenuation floor / odd lists", sens=sens)
 
 
 @pytest.mark.gpu
@@ -790,8 +796,8 @@ def test_frame_4k_256_lights_full_size_properties_tiles_and_oracle_band(ctx, orc
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     band = {k: np.ascontiguousarray(v[y0:y0 + rows]) for k, v in gb.items()}
-    want, want_f32 = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
-    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "4K band", hard_ulp=None)
+    want, want_f32, sens = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
+    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "4K band", hard_ulp=None, sens=sens)
     full.bloom_histogram()
     hist_full = full.hist.cpu().numpy().view(np.uint32).copy()
     assert hist_full.sum() == W * H
