@@ -14,6 +14,6 @@ for mode in halo apron; do
   python bench.py --gpus 2 --steps 5 --warmup 1 --mode $mode --no-cpu-baseline > $out/${tag}_rehearsal2_$mode.json 2> $out/${tag}_rehearsal2_$mode.err || { tail -n 40 $out/${tag}_rehearsal2_$mode.err; exit 1; }
   tail -c 1500 $out/${tag}_rehearsal2_$mode.json; echo
 done
-python bench.py --gpus 4 --steps 3 --warmup 1 --frame 3840x2160 --layout 2x2 --no-cpu-baseline --no-kernel-timing > $out/${tag}_rehearsal4_strong.json 2> $out/${tag}_rehearsal4_strong.err || { tail -n 40 $out/${tag}_rehearsal4_strong.err; exit 1; }
+python bench.py --gpus 4 --steps 3 --warmup 1 --frame 3840x2048 --layout 2x2 --no-cpu-baseline --no-kernel-timing > $out/${tag}_rehearsal4_strong.json 2> $out/${tag}_rehearsal4_strong.err || { tail -n 40 $out/${tag}_rehearsal4_strong.err; exit 1; }
 tail -c 1200 $out/${tag}_rehearsal4_strong.json; echo
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_rate3.hip -o /tmp/valu_rate3 && timeout -k 10 300 /tmp/valu_rate3 > $out/${tag}_valu_rate3.txt && cat $out/${tag}_valu_rate3.txt
