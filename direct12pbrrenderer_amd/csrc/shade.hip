@@ -112,6 +112,8 @@ constexpr int LIST_STRIDE_U16 = 34;
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2s(float a) { return f2{a, a}; }
 __device__ __forceinline__ f2 max2(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ f2 min2(f2 a, f2 b) { return f2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+typedef __attribute__((address_space(3))) const float lds_cf;   // a float in LDS: 32-bit addresses, ds_read with an immediate plane offset
 __device__ __forceinline__ f2 rsq2(f2 a) { return f2{rsq(a.x), rsq(a.y)}; }
 __device__ __forceinline__ f2 rcp2(f2 a) { return f2{rcp(a.x), rcp(a.y)}; }
 
@@ -185,78 +187,88 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
         sy = clampi(sy, 0, PBR_CLUSTER_Y - 1);
         sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
-        // brdf() (brdf.hlsli:47-67) with D, G and the 4 NdotL NdotV denominator under ONE reciprocal:
-        //   D G / max(4 NdotL NdotV,1e-4) = [a^4/pi * gV] * NdotL / (T * A * B),  T = max(t^2, 1e-6/pi),
-        //   A = NdotL(1-k)+k (>= 1/8: the shader's max(.,1e-6) never binds), B = max(4 NdotL NdotV, 1e-4)
+        // brdf() (brdf.hlsli:47-67) with D, G, the 4 NdotL NdotV denominator AND the attenuation under ONE reciprocal:
+        //   D G / max(4 NdotL NdotV, 1e-4) = [a^2/pi * gV] * gl / (T * A),   a = roughness^2 (the shader's `a * a`),
+        //   T  = max(t^2, 1e-6/pi), t = NdotH^2 (a^2 - 1) + 1,
+        //   A  = NdotL(1-k)+k (>= 1/8: the shader's max(.,1e-6) never binds),
+        //   gl = NdotL / max(4 NdotL NdotV, 1e-4) = min(1 / (4 NdotV), 1e4 NdotL)      (1 / max(a,b) = min(1/a, 1/b))
+        //   attenuation * NdotL = NdotL / Q;  with r = 1 / (Q T A):  1/Q = r T A,  so one v_rcp serves both.
         const float ra = roughness * roughness;
         const float a4m1 = ra * ra - 1.0f;
         const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
         const float one_k = 1.0f - k;
-        const float ndv4 = 4.0f * NdotV;
+        const float inv_ndv4 = 1.0f / (4.0f * NdotV);   // +inf at NdotV = 0: min() then picks 1e4 NdotL, as the shader's floor does
         const float t_floor = EPSILON_F * INV_PI_F;
-        // Two lights per trip in the two halves of packed-fp32 registers (light A | light B): measured on
-        // gfx950 (tools/valu_rate*.hip) a plain fp32 VALU op issues every ~4 cycles per SIMD whatever the
-        // occupancy, v_pk_{fma,mul,add}_f32 every ~5.4 with >= 6 resident waves — 1.5x per flop.  The SoA
-        // light planes put the same component of both lights into an adjacent VGPR pair with no moves.
+        // Instruction budget of the loop, from the measured issue costs (tools/valu_rate3.hip -> profiles/r02_valu_rate3.txt,
+        // 5 waves per SIMD, cycles per wave-instruction per SIMD): v_pk_{fma,mul,add}_f32 4.7 (two lights per instruction),
+        // plain v_fma 2.6 / v_mul 3.0, v_max / v_min 4.6, v_rsq / v_rcp 8.5.  Two lights per trip in the halves of packed
+        // registers therefore buy ~1.2x per flop, not 2x; the SoA light planes put the same component of both lights into
+        // an adjacent VGPR pair with no moves.  Per trip: 47 packed + 6 transcendental + 2 min (+ 2 max on the slow paths).
         f2 a1x = f2s(0.0f), a1y = f2s(0.0f), a1z = f2s(0.0f), a2x = f2s(0.0f), a2y = f2s(0.0f), a2z = f2s(0.0f), a3x = f2s(0.0f), a3y = f2s(0.0f), a3z = f2s(0.0f);
-        auto light2 = [&](auto q_safe, int liA, int liB) {
-            constexpr bool QSAFE = decltype(q_safe)::value;
-            const float* la = llds + liA;   // indices were clamped to the staged table when the lists were staged
-            const float* lb = llds + liB;
+        auto light2 = [&](auto q_safe, auto t_safe, const lds_cf* la, const lds_cf* lb) {
+            constexpr bool QSAFE = decltype(q_safe)::value, TSAFE = decltype(t_safe)::value;
             auto comp = [&](int c) { return f2{la[c * LSTRIDE], lb[c * LSTRIDE]}; };
             const f2 dx = comp(0) - f2s(pos.x), dy = comp(1) - f2s(pos.y), dz = comp(2) - f2s(pos.z);
             const f2 d2 = dx * dx + dy * dy + dz * dz;
             const f2 invd = rsq2(d2);
             const f2 dist = d2 * invd;
             const f2 dn = dx * n.x + dy * n.y + dz * n.z;
-            const f2 NdL = dn * invd;
             const f2 NdotL = mul2_sat(dn, invd);   // max(N.L, 0)
             // N.H = N.(L + V) / |L + V| without normalising H.  |L + V|^2 is summed from the components of L + V, NOT taken
             // as 2 + 2 L.V: at grazing incidence (L ~ -V, |L + V|^2 ~ 1e-2) the shortcut cancels and its 1e-7 error becomes
-            // 1e-5 of N.H, which a GGX highlight at roughness 0.2 (t = N.H^2 (a^4 - 1) + 1 ~ 2e-3) multiplies by 4 / t:
-            // several per cent of D (measured against the oracle on a 4K band: 3 pixels of 122 880).  One packed
-            // instruction more than the shortcut.  (L = -V exactly: 0 * rsq(0) = NaN, and max(NaN, 0) = 0 as before.)
+            // 1e-5 of N.H, which a GGX highlight at roughness 0.2 (t ~ 2e-3) multiplies by 4 / t: several per cent of D
+            // (measured against the oracle on a 4K band: 3 pixels of 122 880).  One packed instruction more than the
+            // shortcut.  (L = -V exactly: 0 * rsq(0) = NaN, and the clamp turns NaN into 0.)
             const f2 wx = dx * invd + f2s(view.x), wy = dy * invd + f2s(view.y), wz = dz * invd + f2s(view.z);
             const f2 h2 = wx * wx + wy * wy + wz * wz;
-            const f2 NdotH = mul2_sat(NdL + f2s(NdV), rsq2(h2));
+            const f2 NdotH = mul2_sat(dn * invd + f2s(NdV), rsq2(h2));
             const f2 t = (NdotH * NdotH) * a4m1 + f2s(1.0f);
-            const f2 T = max2(t * t, f2s(t_floor));
+            // TSAFE: every active lane of the wave has a^2 >= 6e-4, hence t >= a^2 - 6e-8 > sqrt(1e-6 / pi) = 5.64e-4 and the
+            // shader's max(pi t^2, 1e-6) never binds (decided per wave before the walk)
+            f2 T = t * t;
+            if constexpr (!TSAFE) T = max2(T, f2s(t_floor));
             const f2 A = NdotL * one_k + f2s(k);
-            const f2 B = max2(NdotL * ndv4, f2s(0.0001f));
             // attenuation(): max(C0 + C1 d + C2 d^2, 1e-6).  QSAFE: every staged light has C0 >= 1e-6 and C1, C2 >= 0,
             // so the floor never binds (checked once per block while the table is staged)
             f2 Q = comp(6) + comp(7) * dist + comp(8) * d2;
             if constexpr (!QSAFE) Q = max2(Q, f2s(EPSILON_F));
-            const f2 X = NdotL * rcp2(Q);   // attenuation * NdotL
+            const f2 TA = T * A;
+            const f2 r = rcp2(Q * TA);                       // 1 / (Q T A)
+            const f2 X = NdotL * (r * TA);                   // attenuation * NdotL = NdotL / Q
+            const f2 gl = min2(f2s(inv_ndv4), NdotL * 1.0e4f);
             // fresnel on NdotL (Q3).  The shader's max(1-NdotL, 1e-6) only matters within 1e-6 of NdotL = 1, where it
             // changes f5 by < 1e-30: dropped.
             const f2 fm = f2s(1.0f) - NdotL;
             const f2 fm2 = fm * fm;
             const f2 f5 = fm2 * fm2 * fm;
-            const f2 w2 = X * NdotL * rcp2(T * A * B);   // X * s
-            const f2 w1 = X - X * f5;                    // X * (1 - f5)
+            const f2 w2 = (NdotL * gl) * r;                  // X * gl / (T A)
+            const f2 w1 = X - X * f5;                        // X * (1 - f5)
             const f2 w3 = w2 * f5;
             const f2 cr = comp(3), cg = comp(4), cb = comp(5);
             a1x += cr * w1; a1y += cg * w1; a1z += cb * w1;
             a2x += cr * w2; a2y += cg * w2; a2z += cb * w2;
             a3x += cr * w3; a3y += cg * w3; a3z += cb * w3;
         };
+        const lds_cf* const ltab = (const lds_cf*)llds;      // the staged light planes, as an LDS (address space 3) pointer
         if (STAGED_LISTS) {
             const uint16_t* my = lists + (((sy - tile_y0) * tiles_x + (sx - tile_x0)) * PBR_CLUSTER_Z + sz) * LIST_STRIDE_U16;
-            // staged lists are padded to an even count with the null light (black, far away): no odd tail
+            // staged lists are padded to an even count with the null light (black, far away): no odd tail.  An entry is
+            // the LDS BYTE ADDRESS of the light's first plane (table base + 4 * index, < 64 KiB): one mask / shift per light
             const int nl = my[0];
-            auto walk = [&](auto qs) {
-                for (int i = 0; i < nl; i += 2) {   // two indices per LDS read
+            const bool t_ok = __all(ra * ra >= 6.0e-4f) != 0;
+            auto walk = [&](auto qs, auto ts) {
+                for (int i = 0; i < nl; i += 2) {   // two entries per LDS read
                     const uint32_t pair = *reinterpret_cast<const uint32_t*>(my + 2 + i);   // i even -> 4-byte aligned
-                    light2(qs, (int)(pair & 0xFFFFu), (int)(pair >> 16));
+                    light2(qs, ts, (const lds_cf*)(uintptr_t)(pair & 0xFFFFu), (const lds_cf*)(uintptr_t)(pair >> 16));
                 }
             };
-            if (q_safe) walk(std::true_type{}); else walk(std::false_type{});
+            if (q_safe) { if (t_ok) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{}); }
+            else walk(std::false_type{}, std::false_type{});
         } else {
             const pbr_cluster* cl = p.clusters + (sz + sx * PBR_CLUSTER_Z + sy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
             const int nl = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
             auto idx = [&](int q) { return q < nl ? min(max(cl->LightIndex[q], 0), n_lights - 1) : n_lights; };   // n_lights = the null light
-            for (int i = 0; i < nl; i += 2) light2(std::false_type{}, idx(i), idx(i + 1));
+            for (int i = 0; i < nl; i += 2) light2(std::false_type{}, std::false_type{}, ltab + idx(i), ltab + idx(i + 1));
         }
         s1x = a1x.x + a1x.y; s1y = a1y.x + a1y.y; s1z = a1z.x + a1z.y;
         s2x = a2x.x + a2x.y; s2y = a2y.x + a2y.y; s2z = a2z.x + a2z.y;
@@ -408,6 +420,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     const uint32_t y_begin = by < nb_big ? by * SHADE_ROWS : nb_big * SHADE_ROWS + (by - nb_big) * rows_small;
     const uint32_t y_end = min(y_begin + (by < nb_big ? (uint32_t)SHADE_ROWS : rows_small), p.h);
     int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;   // < 64 KiB: the whole light table (<= 9 x 1025 floats) stays addressable in 16 bits
     if (STAGED_LISTS) {
         // cluster (x,y) tiles the block's pixel rectangle can fall into — same arithmetic as the per-pixel
         // ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners bound it
@@ -429,7 +442,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
             const int cnt = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
             int val = 0;
             if (j == 0) val = (cnt + 1) & ~1;   // padded to even with the null light
-            else if (j >= 2) val = (j - 2) < cnt ? min(max(cl->LightIndex[j - 2], 0), n_lights - 1) : n_lights;   // never index past the staged table
+            else if (j >= 2) {
+                const int li = (j - 2) < cnt ? min(max(cl->LightIndex[j - 2], 0), n_lights - 1) : n_lights;   // never index past the staged table
+                val = (int)(lds_base + 4u * (uint32_t)li);   // LDS byte address of the light's first plane
+            }
             lists[e] = (uint16_t)val;
         }
     }

@@ -1,5 +1,9 @@
 set -o pipefail
-out=gpurun_out; tag=r02_a
-python bench.py --gpus 4 --steps 3 --warmup 1 --frame 3840x2048 --layout 2x2 --no-cpu-baseline --no-kernel-timing > $out/${tag}_rehearsal4_strong.json 2> $out/${tag}_rehearsal4_strong.err || { tail -n 40 $out/${tag}_rehearsal4_strong.err; exit 1; }
-tail -c 1200 $out/${tag}_rehearsal4_strong.json; echo
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/valu_rate3.hip -o /tmp/valu_rate3 && timeout -k 10 300 /tmp/valu_rate3 > $out/${tag}_valu_rate3.txt && cat $out/${tag}_valu_rate3.txt
+out=gpurun_out; tag=r02_b
+python -m pytest tests -m gpu -x -q -s > $out/${tag}_pytest_gpu.log 2>&1; rc=$?
+tail -n 5 $out/${tag}_pytest_gpu.log
+[ $rc -eq 0 ] || exit $rc
+python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_4k.json 2> $out/${tag}_bench.err || { tail -n 30 $out/${tag}_bench.err; exit 1; }
+python -c "
+import json;d=json.load(open('$out/${tag}_bench_4k.json'));print(d['value'],d['ms_per_step'],d['roofline']['stage_ms'])"
+python tools/shade_coherence.py > $out/${tag}_shade_coherence.txt 2>&1; cat $out/${tag}_shade_coherence.txt
