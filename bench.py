@@ -43,6 +43,9 @@ from direct12pbrrenderer_amd.structs import CLUSTER_DTYPE, CLUSTER_X, CLUSTER_Y,
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec; the measured streaming-read rate is reported beside it
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip table (packed FMA on every lane every cycle)
 N_SIMD, CLOCK_HZ = 1024, 2.4e9
+# tools/valu_rate3.hip on gfx950 at 5 waves per SIMD (profiles/r02_valu_rate3.txt): cycles per wave-instruction per SIMD
+MEASURED_CYCLES = {"plain": 3.0, "fma": 2.6, "packed": 4.7, "trans": 8.5}
+MEASURED_CLOCK_HZ = 2.1e9
 # algorithmic bytes per pixel: unique bytes a reference pass must read + write once
 BYTES_PER_PX = {"shade": 25.0, "bloom": 75.75, "histogram": 8.0, "tonemap": 12.0}
 ENV_SIZE, LUT_RES, N_LIGHTS = 512, 512, 256
@@ -502,23 +505,37 @@ def main():
                                    "IBL gathers served by L2/MALL included"}
         sq = kernel_entry(load_profile("pmc_sq_latest.json", shaded_px), "k_deferred_shade", ("SQ_INSTS_VALU",))
         if sq:
-            # supplementary compute roofline for the VALU-bound shade, against BOTH ceilings: the guide's spec issue
-            # rate (a wave64 fp32 op every 2 cycles per SIMD; 157.3 TFLOP/s when every op is a packed FMA) and the
-            # issue rate tools/valu_rate2.hip measures on this part (profiles/r02_valu_rate.txt: ~4 cycles per plain
-            # fp32 op whatever the occupancy)
+            # Supplementary compute roofline for the VALU-bound shade, against BOTH ceilings:
+            #  * the guide's spec issue rate: a wave64 fp32 op every 2 cycles per SIMD at 2.4 GHz (157.3 TFLOP/s when every
+            #    op is a packed FMA);
+            #  * what tools/valu_rate3.hip measures on this part in shader-clock cycles (profiles/r02_valu_rate3.txt), at the
+            #    kernel's own occupancy of 5 waves per SIMD: plain v_mul/v_add 3.0, v_fma 2.6, v_pk_{fma,mul,add}_f32 4.7,
+            #    v_max/v_min 4.6, v_rcp/v_rsq 8.5 cycles per wave-instruction per SIMD, at the ~2.1 GHz the chip sustains
+            #    under packed fp32 load.  issue_model = the launch's instruction mix (SQ_INSTS_VALU_* counters) priced at
+            #    those costs: the time the VALU needs to ISSUE the kernel's instructions, as a share of the launch.
             nv = sq["SQ_INSTS_VALU"]
             rate = nv / (shade_ms_in_frame * 1e-3)
             valu = {"wave_insts_per_launch": nv, "achieved_Ginst_s": round(rate / 1e9, 1),
                     "spec_peak_Ginst_s": round(N_SIMD * CLOCK_HZ / 2.0 / 1e9, 1), "frac_of_spec": round(rate / (N_SIMD * CLOCK_HZ / 2.0), 3),
-                    "measured_peak_Ginst_s": round(N_SIMD * CLOCK_HZ / 4.0 / 1e9, 1), "frac_of_measured": round(rate / (N_SIMD * CLOCK_HZ / 4.0), 3),
-                    "source": "profiles/pmc_sq_latest.json (rocprofv3 SQ_INSTS_VALU, same shade.hip) + tools/valu_rate2.hip -> profiles/r02_valu_rate.txt"}
+                    "measured_plain_peak_Ginst_s": round(N_SIMD * MEASURED_CLOCK_HZ / MEASURED_CYCLES["plain"] / 1e9, 1),
+                    "frac_of_measured_plain": round(rate / (N_SIMD * MEASURED_CLOCK_HZ / MEASURED_CYCLES["plain"]), 3),
+                    "source": "profiles/pmc_sq_latest.json + pmc_shade_issue_latest.json (rocprofv3, same shade.hip) and "
+                              "profiles/r02_valu_rate3.txt (tools/valu_rate3.hip)"}
             mix = kernel_entry(load_profile("pmc_shade_issue_latest.json", shaded_px), "k_deferred_shade",
-                               ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32"))
+                               ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32"))
             if mix:
-                # upper bound: every FMA/MUL/ADD wave-instruction counted as PACKED (2 results per lane): 64 lanes x 2 x (2 | 1 | 1) flop
-                flop = 64.0 * 2.0 * (2.0 * mix["SQ_INSTS_VALU_FMA_F32"] + mix["SQ_INSTS_VALU_MUL_F32"] + mix["SQ_INSTS_VALU_ADD_F32"])
+                fma, mul, add, trans = (mix["SQ_INSTS_VALU_FMA_F32"], mix["SQ_INSTS_VALU_MUL_F32"], mix["SQ_INSTS_VALU_ADD_F32"],
+                                        mix["SQ_INSTS_VALU_TRANS_F32"])
+                other = max(nv - fma - mul - add - trans, 0.0)
+                c = MEASURED_CYCLES
+                # the counters do not tell packed from plain: price FMA/MUL/ADD once as all plain and once as all packed
+                lo = (fma * c["fma"] + (mul + add) * c["plain"] + trans * c["trans"] + other * c["plain"]) / N_SIMD / MEASURED_CLOCK_HZ * 1e3
+                hi = ((fma + mul + add) * c["packed"] + trans * c["trans"] + other * c["plain"]) / N_SIMD / MEASURED_CLOCK_HZ * 1e3
+                valu["issue_model_ms"] = [round(lo, 4), round(hi, 4)]
+                valu["issue_model_frac_of_launch"] = [round(lo / shade_ms_in_frame, 3), round(hi / shade_ms_in_frame, 3)]
+                # flop upper bound: every FMA/MUL/ADD wave-instruction counted as PACKED (2 results per lane)
+                flop = 64.0 * 2.0 * (2.0 * fma + mul + add)
                 tf = flop / (shade_ms_in_frame * 1e-3) / 1e12
-                valu["flop_per_launch_upper_bound"] = flop
                 valu["TFLOPs_upper_bound"] = round(tf, 1)
                 valu["frac_of_fp32_peak_upper_bound"] = round(tf / FP32_VALU_PEAK_TFLOPS, 3)
             out["roofline"]["valu"] = valu

@@ -178,6 +178,213 @@ __global__ __launch_bounds__(256) void k_prefilter_env_all(const float* __restri
     prefilter_block(tab, sky, sky_size, sky_mips, size, size >> mip, roughness, out + 4 * cube_mip_offset(size, mip), b);
 }
 
+// ---------------------------------------------------------------------------- wave-parallel prefilter (pbr_prefilter_env)
+// The same integral, mapped the way the hardware likes it:
+//  * ONE WAVE PER OUTPUT TEXEL: the 64 lanes take the texel's samples 64 at a time (<= 16 trips instead of a 1 024-step
+//    dependent chain), keep per-lane partial sums and combine them with a fixed xor-shuffle tree — deterministic, but
+//    not the shader's strictly sequential fp32 sum (SURVEY 8c allows <= 1 fp16 ULP or 1e-3 for this output; the
+//    sequential kernel above remains what pbr_prefilter_env_mip runs, one reference dispatch at a time).  N, T, B of the
+//    texel are wave-uniform.  mip 4 is 6 144 waves instead of 96.
+//  * the sample set of a mip is a TABLE built on the host with the oracle's own libm calls: with V = N the half vector
+//    in tangent space depends only on (i, roughness), and so do the reflected direction L_t = (2 hz hx, 2 hz hy,
+//    2 hz^2 - 1), the weight N.L = L_t.z and the source LOD.  Samples with N.L <= 0 are dropped when the table is built
+//    (a quarter of them at roughness 0.75, half at 1) and the weight sum is one number per mip.  The loop keeps no
+//    normalize, no sqrt, no log2: L = T lx + B ly + N lz.
+//  * the source cube is sampled from a PADDED copy (every face of every mip with the 1-texel border the seamless rule
+//    selects, like the shade's env chain): the trilinear fetch is branch-free, 8 x 16-byte loads per sample.
+//  * roughness 0 (mip 0) degenerates to one bilinear fetch per texel: its own thread-per-texel kernel.
+constexpr int PF_TEXELS_PER_WAVE = 8;
+constexpr int PF_TEXELS_PER_BLOCK = 4 * PF_TEXELS_PER_WAVE;
+struct PfLaunch {
+    uint32_t first_block[17];   // first block of output mip m (m = 1 .. mips-1), [mips] = total
+    uint32_t count[16];         // valid samples of mip m
+    float wsum[16];             // sum of their weights, accumulated in sample order in fp32 like the shader's total_weight
+    uint32_t src_off[16];       // texel offset of padded SOURCE mip l
+    uint32_t mips, size, sky_size, sky_mips;
+};
+
+__global__ __launch_bounds__(256) void k_cube_pad_f32(const float4* __restrict__ src, float4* __restrict__ dst, int s) {
+    const int sp = s + 2;
+    const size_t n = (size_t)6 * sp * sp;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int xp = (int)(t % sp), yp = (int)((t / sp) % sp);
+    uint32_t face = (uint32_t)(t / ((size_t)sp * sp));
+    int x = xp - 1, y = yp - 1;
+    const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
+    if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
+        if (xo & yo) y = clampi(y, 0, s - 1);
+        const float uu = 2.0f * ((float)x + 0.5f) / (float)s - 1.0f;
+        const float vv = 2.0f * ((float)y + 0.5f) / (float)s - 1.0f;
+        float u2, v2;
+        cube_face_uv(cube_dir_raw(face, uu, vv), face, u2, v2);
+        x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
+        y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
+    }
+    dst[t] = src[((size_t)face * s + y) * s + x];
+}
+
+// trilinear fetch of the padded fp32 chain along `d` at the (already clamped and x.8-snapped) LOD; rgb only
+__device__ __forceinline__ V3 padded_trilinear(const float4* __restrict__ sky, const PfLaunch& pl, V3 d, float lod_s) {
+    uint32_t face;
+    float cu, cv;
+    cube_face_uv(d, face, cu, cv);
+    const float fl = floorf(lod_s), f = lod_s - fl;
+    const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, pl.sky_mips - 1u);
+    auto level = [&](uint32_t l) {
+        const int s = (int)(pl.sky_size >> l), sp = s + 2;
+        const float fxp = snap8(cu * (float)s) - 0.5f, fyp = snap8(cv * (float)s) - 0.5f;
+        const float flx = floorf(fxp), fly = floorf(fyp);
+        const float fx = fxp - flx, fy = fyp - fly;
+        const float4* m = sky + pl.src_off[l] + ((size_t)face * sp + (size_t)((int)fly + 1)) * sp + (size_t)((int)flx + 1);
+        const float4 c00 = m[0], c10 = m[1], c01 = m[sp], c11 = m[sp + 1];
+        // the sampler's lerps on rgb (alpha is not used): far tap fused onto the weighted near tap, the oracle's order.
+        // Its "a tap of weight exactly 0 does not contribute" select is left out: it only matters for inf / NaN texels.
+        const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+        const float tr = __builtin_fmaf(c10.x, fx, c00.x * wx0), br = __builtin_fmaf(c11.x, fx, c01.x * wx0);
+        const float tg = __builtin_fmaf(c10.y, fx, c00.y * wx0), bg = __builtin_fmaf(c11.y, fx, c01.y * wx0);
+        const float tb = __builtin_fmaf(c10.z, fx, c00.z * wx0), bb = __builtin_fmaf(c11.z, fx, c01.z * wx0);
+        return v3(__builtin_fmaf(br, fy, tr * wy0), __builtin_fmaf(bg, fy, tg * wy0), __builtin_fmaf(bb, fy, tb * wy0));
+    };
+    const V3 a = level(l0);
+    if (f == 0.0f || l1 == l0) return a;   // wave-divergent only where lanes sit on different LODs: both sides are cheap
+    const V3 b = level(l1);
+    const float w0 = 1.0f - f;
+    return v3(__builtin_fmaf(b.x, f, a.x * w0), __builtin_fmaf(b.y, f, a.y * w0), __builtin_fmaf(b.z, f, a.z * w0));
+}
+
+__global__ __launch_bounds__(256) void k_prefilter_fast(const float4* __restrict__ sky_padded, const float4* __restrict__ tables,
+                                                          PfLaunch pl, pbr_half* __restrict__ out) {
+    __shared__ float4 tab[PBR_SAMPLE_COUNT];
+    uint32_t mip = 1;
+    while (mip + 1 < pl.mips && blockIdx.x >= pl.first_block[mip + 1]) mip++;
+    const uint32_t count = pl.count[mip];
+    for (uint32_t i = threadIdx.x; i < count; i += 256) tab[i] = tables[(size_t)mip * PBR_SAMPLE_COUNT + i];
+    __syncthreads();
+    const uint32_t s = pl.size >> mip;
+    const uint32_t n = 6u * s * s;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x - pl.first_block[mip]) * 4u + (threadIdx.x >> 6));
+    pbr_half* out_mip = out + 4 * cube_mip_offset(pl.size, mip);
+    for (uint32_t k = 0; k < (uint32_t)PF_TEXELS_PER_WAVE; k++) {
+        const uint32_t t = wave * PF_TEXELS_PER_WAVE + k;
+        if (t >= n) break;
+        const uint32_t x = t % s, y = (t / s) % s, face = t / (s * s);
+        const float u = (float)x / (float)s, v = (float)y / (float)s;   // texel corner (Q8)
+        const V3 N = normalize3_exact(cube_dir_raw(face, 2.0f * u - 1.0f, 2.0f * v - 1.0f));
+        const V3 up = fabsf(N.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+        const V3 T = normalize3_exact(cross3(N, up));
+        const V3 Bt = cross3(N, T);
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        for (uint32_t j = lane; j < count; j += 64u) {
+            const float4 e = tab[j];
+            const V3 L = T * e.x + Bt * e.y + N * e.z;
+            const V3 c = padded_trilinear(sky_padded, pl, L, e.w);
+            cr += c.x * e.z; cg += c.y * e.z; cb += c.z * e.z;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {   // fixed combine order
+            cr += __shfl_xor(cr, off, 64); cg += __shfl_xor(cg, off, 64); cb += __shfl_xor(cb, off, 64);
+        }
+        if (lane == 0) {
+            const float w = pl.wsum[mip];   // 0 samples -> 0/0 = NaN like the reference
+            store_h4(out_mip + 4 * (size_t)t, f4(cr / w, cg / w, cb / w, 1.0f));
+        }
+    }
+}
+
+// The same table-driven, branch-free inner loop with the OTHER mapping: one lane per output texel, the 64 lanes of a
+// wave are 64 neighbouring texels and all of them take sample j at the same time.  Neighbouring texels reflect the same
+// tangent-space direction into neighbouring source positions, so a wave's 8 x 64 texel fetches fall into a few dozen
+// cache lines (measured: 2.4x faster than the wave-per-texel mapping, whose 64 lanes scatter over the whole lobe and
+// pull ~256 lines per trip through a 32 KB L1).  The sum runs in sample order like the shader's.  This is what
+// pbr_prefilter_env launches; k_prefilter_fast stays selectable (PBR_PREFILTER_WAVE=1) as the measured alternative.
+__global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict__ sky_padded, const float4* __restrict__ tables,
+                                                         PfLaunch pl, pbr_half* __restrict__ out) {
+    __shared__ float4 tab[PBR_SAMPLE_COUNT];
+    uint32_t mip = 1;
+    while (mip + 1 < pl.mips && blockIdx.x >= pl.first_block[mip + 1]) mip++;
+    const uint32_t count = pl.count[mip];
+    for (uint32_t i = threadIdx.x; i < count; i += 256) tab[i] = tables[(size_t)mip * PBR_SAMPLE_COUNT + i];
+    __syncthreads();
+    const uint32_t s = pl.size >> mip;
+    const uint32_t n = 6u * s * s;
+    const uint32_t t = (blockIdx.x - pl.first_block[mip]) * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t x = t % s, y = (t / s) % s, face = t / (s * s);
+    const float u = (float)x / (float)s, v = (float)y / (float)s;   // texel corner (Q8)
+    const V3 N = normalize3_exact(cube_dir_raw(face, 2.0f * u - 1.0f, 2.0f * v - 1.0f));
+    const V3 up = fabsf(N.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+    const V3 T = normalize3_exact(cross3(N, up));
+    const V3 Bt = cross3(N, T);
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+#pragma unroll 2
+    for (uint32_t j = 0; j < count; j++) {
+        const float4 e = tab[j];   // wave-uniform: one broadcast LDS read
+        const V3 L = T * e.x + Bt * e.y + N * e.z;
+        const V3 c = padded_trilinear(sky_padded, pl, L, e.w);
+        cr += c.x * e.z; cg += c.y * e.z; cb += c.z * e.z;
+    }
+    const float w = pl.wsum[mip];   // 0 samples -> 0/0 = NaN like the reference
+    store_h4(out + 4 * (cube_mip_offset(pl.size, mip) + (size_t)t), f4(cr / w, cg / w, cb / w, 1.0f));
+}
+
+// roughness 0: H = L = N for every sample, weight 1: the filtered value IS the bilinear fetch at the texel-corner
+// direction (the reference's 1 024-fold running sum of one value differs from it by < 1e-4 relative, far inside the fp16 ULP)
+__global__ __launch_bounds__(256) void k_prefilter_mip0(const float4* __restrict__ sky_padded, PfLaunch pl, pbr_half* __restrict__ out) {
+    const uint32_t s = pl.size;
+    const size_t n = (size_t)6 * s * s;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t x = (uint32_t)(t % s), y = (uint32_t)((t / s) % s), face = (uint32_t)(t / ((size_t)s * s));
+    const float u = (float)x / (float)s, v = (float)y / (float)s;
+    const V3 N = normalize3_exact(cube_dir_raw(face, 2.0f * u - 1.0f, 2.0f * v - 1.0f));
+    const V3 c = padded_trilinear(sky_padded, pl, N, 0.0f);
+    store_h4(out + 4 * t, f4(c.x, c.y, c.z, 1.0f));
+}
+
+// host: the sample table of one output mip (the per-sample part of env_map_gen.hlsl:69-94 with V = N), libm in fp32
+// exactly as the oracle evaluates it; returns the number of samples kept and their weight sum
+static uint32_t build_prefilter_table(float roughness, uint32_t size, uint32_t sky_mips, float* tab4, float* wsum_out) {
+    uint32_t n = 0;
+    float wsum = 0.0f;
+    const float maxl = (float)(sky_mips - 1);
+    for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
+        uint32_t bits = i;   // radical inverse (brdf.hlsli:101-109)
+        bits = (bits << 16u) | (bits >> 16u);
+        bits = ((bits & 0x55555555u) << 1u) | ((bits & 0xAAAAAAAAu) >> 1u);
+        bits = ((bits & 0x33333333u) << 2u) | ((bits & 0xCCCCCCCCu) >> 2u);
+        bits = ((bits & 0x0F0F0F0Fu) << 4u) | ((bits & 0xF0F0F0F0u) >> 4u);
+        bits = ((bits & 0x00FF00FFu) << 8u) | ((bits & 0xFF00FF00u) >> 8u);
+        const float xi_x = (float)i / (float)PBR_SAMPLE_COUNT, xi_y = (float)bits * 2.3283064365386963e-10f;
+        const float a = roughness * roughness;
+        const float phi = 6.28318530718f * xi_x;
+        const float cos_theta = sqrtf((1.0f - xi_y) / (1.0f + (a * a - 1.0f) * xi_y));
+        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        const float hx = sin_theta * cosf(phi), hy = sin_theta * sinf(phi), hz = cos_theta;
+        const float lz = 2.0f * hz * hz - 1.0f;   // N.L with V = N
+        if (!(lz > 0.0f)) continue;
+        const float NdotH = fmaxf(hz, 0.0f), HdotV = NdotH;
+        const float t = (NdotH * NdotH) * (a * a - 1.0f) + 1.0f;
+        const float D = a * a / fmaxf(3.14159265359f * t * t, 1e-6f);
+        const float pdf = D * NdotH / (4.0f * HdotV + 0.0001f);
+        const float texel_sa = 4.0f * 3.14159265359f / ((float)(6u * size * size));   // base size for every mip (Q8)
+        const float sample_sa = 1.0f / ((float)PBR_SAMPLE_COUNT * pdf + 0.0001f);
+        float lod = roughness == 0.0f ? 0.0f : 0.5f * log2f(sample_sa / texel_sa);
+        if (!(lod == lod)) lod = 0.0f;
+        lod = lod < 0.0f ? 0.0f : (lod > maxl ? maxl : lod);
+        lod = floorf(lod * 256.0f + 0.5f) * (1.0f / 256.0f);   // D3D12_MIP_LOD_FRACTIONAL_BIT_COUNT = 8
+        tab4[4 * n + 0] = 2.0f * hz * hx;
+        tab4[4 * n + 1] = 2.0f * hz * hy;
+        tab4[4 * n + 2] = lz;
+        tab4[4 * n + 3] = lod;
+        wsum += lz;
+        n++;
+    }
+    *wsum_out = wsum;
+    return n;
+}
+
 // ============================================================================ SH9 (a5)
 // Stage 1: per-block partial sums of colour * Y_n(dir) * dOmega over all mip-0 texels
 // (27 accumulators per thread -> wave shuffle reduce -> LDS -> one row of 27 per block).
@@ -323,11 +530,59 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     PBR_REQUIRE(ctx, size >= 1 && mips >= 1 && mips <= 16 && (size >> (mips - 1)) >= 1, "pbr_prefilter_env: bad output size/mips");
     PBR_REQUIRE(ctx, sky && sky->data && sky->size >= 1 && sky->mips >= 1 && (sky->size >> (sky->mips - 1)) >= 1, "pbr_prefilter_env: bad sky cube");
     PBR_REQUIRE(ctx, size <= 8192, "pbr_prefilter_env: bad output size/mips");
-    size_t blocks = 0;
-    for (uint32_t m = 0; m < mips; m++) blocks += ((size_t)6 * (size >> m) * (size >> m) + 255) / 256;
-    PBR_REQUIRE(ctx, blocks <= 0x7FFFFFFFull, "pbr_prefilter_env: cube too large");
-    hipLaunchKernelGGL(k_prefilter_env_all, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sky->data, sky->size, sky->mips, size, mips, out);
-    return launched(ctx, "k_prefilter_env_all");
+    static const bool sequential = getenv("PBR_PREFILTER_SEQ") != nullptr;   // A/B switch: the thread-per-texel kernel, all mips in one launch
+    if (sequential || sky->mips > 16) {
+        size_t blocks = 0;
+        for (uint32_t m = 0; m < mips; m++) blocks += ((size_t)6 * (size >> m) * (size >> m) + 255) / 256;
+        PBR_REQUIRE(ctx, blocks <= 0x7FFFFFFFull, "pbr_prefilter_env: cube too large");
+        hipLaunchKernelGGL(k_prefilter_env_all, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sky->data, sky->size, sky->mips, size, mips, out);
+        return launched(ctx, "k_prefilter_env_all");
+    }
+    // ---- wave-parallel path: padded source chain + per-mip sample tables (stream-ordered scratch)
+    PfLaunch pl{};
+    pl.mips = mips; pl.size = size; pl.sky_size = sky->size; pl.sky_mips = sky->mips;
+    for (uint32_t l = 0; l < sky->mips; l++) pl.src_off[l] = (uint32_t)env_padded_mip_offset(sky->size, l);
+    const size_t padded_texels = env_padded_mip_offset(sky->size, sky->mips);
+    PBR_REQUIRE(ctx, padded_texels <= 0xFFFFFFFFull, "pbr_prefilter_env: sky cube too large");
+    ctx->host_tmp.assign((size_t)mips * PBR_SAMPLE_COUNT * 4, 0.0f);
+    static const bool wave_per_texel = getenv("PBR_PREFILTER_WAVE") != nullptr;   // A/B switch: the other mapping
+    const uint32_t per_block = wave_per_texel ? (uint32_t)PF_TEXELS_PER_BLOCK : 256u;
+    uint32_t blocks = 0;
+    for (uint32_t m = 1; m < mips; m++) {
+        const float roughness = (float)m / (float)(mips - 1);   // DeferredPipeline.cpp:99
+        pl.count[m] = build_prefilter_table(roughness, size, sky->mips, ctx->host_tmp.data() + (size_t)m * PBR_SAMPLE_COUNT * 4, &pl.wsum[m]);
+        pl.first_block[m] = blocks;
+        const uint32_t sm = size >> m;
+        blocks += (6u * sm * sm + per_block - 1) / per_block;
+    }
+    pl.first_block[mips] = blocks;
+    const size_t table_bytes = (size_t)mips * PBR_SAMPLE_COUNT * 16;
+    float4* padded = nullptr;
+    float4* tables = nullptr;
+    PBR_HIP(ctx, hipMallocAsync((void**)&padded, padded_texels * 16 + table_bytes, ctx->stream));
+    tables = padded + padded_texels;
+    pbr_status r = PBR_OK;
+    hipError_t e = hipMemcpyAsync(tables, ctx->host_tmp.data(), table_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) r = hip_fail(ctx, e, "hipMemcpyAsync(prefilter tables)");
+    for (uint32_t l = 0; l < sky->mips && r == PBR_OK; l++) {
+        const int sl = (int)(sky->size >> l);
+        const size_t n = (size_t)6 * (sl + 2) * (sl + 2);
+        hipLaunchKernelGGL(k_cube_pad_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float4*>(sky->data) + cube_mip_offset(sky->size, l), padded + pl.src_off[l], sl);
+        r = launched(ctx, "k_cube_pad_f32");
+    }
+    if (r == PBR_OK && blocks) {
+        if (wave_per_texel) hipLaunchKernelGGL(k_prefilter_fast, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
+        else hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
+        r = launched(ctx, "k_prefilter_tex");
+    }
+    if (r == PBR_OK) {
+        const size_t n0 = (size_t)6 * size * size;
+        hipLaunchKernelGGL(k_prefilter_mip0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, padded, pl, out);
+        r = launched(ctx, "k_prefilter_mip0");
+    }
+    (void)hipFreeAsync(padded, ctx->stream);
+    return r;
 }
 
 pbr_status pbr_sh9_project(pbr_ctx* ctx, const pbr_cube_f32* sky, float* out_pack) {

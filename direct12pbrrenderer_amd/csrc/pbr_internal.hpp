@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <vector>
 #include <cstdio>
 #include "../../include/pbr_hip.h"
 
@@ -12,6 +13,7 @@ struct pbr_ctx {
     void* scratch = nullptr;          // device scratch (SH partials, ...)
     size_t scratch_bytes = 0;
     std::string err;
+    std::vector<float> host_tmp;      // host staging that must outlive an enqueued copy (prefilter sample tables)
     // RCCL (loaded lazily with dlopen so a 1-GPU run never needs librccl)
     void* rccl_lib = nullptr;
     void* comm = nullptr;
