@@ -104,6 +104,17 @@ class PbrContext:
         self._check(self.lib.pbr_prefilter_env(self.h, C.byref(c), size, mips, _ptr(out)))
         return out
 
+    def prefilter_env_dispatches(self, sky, sky_size, sky_mips, size=512, mips=ENV_MIPS, out=None):
+        """The chain as PreFilterEnvMapPass::Execute builds it: ONE pbr_prefilter_env_mip per mip (the shader's sequential
+        sum, roughness = mip / (mips - 1), DeferredPipeline.cpp:99) — what the C++ pass graph dispatches."""
+        from .structs import cube_mip_offset
+        out = out if out is not None else self.empty((cube_texels(size, mips), 4), torch.float16)
+        c = CubeF32(sky.data_ptr(), sky_size, sky_mips)
+        for m in range(mips):
+            dst = out.data_ptr() + 8 * cube_mip_offset(size, m)
+            self._check(self.lib.pbr_prefilter_env_mip(self.h, C.byref(c), size, m, float(m) / float(max(mips - 1, 1)), C.c_void_p(dst)))
+        return out
+
     def env_pad(self, env, size, mips=ENV_MIPS, out=None):
         """Padded copy of a prefiltered env chain — the layout deferred_shade samples (one-shot)."""
         out = out if out is not None else self.empty((env_padded_texels(size, mips), 4), torch.float16)

@@ -5,14 +5,15 @@
 //  * one lane per pixel, a wave = 64 consecutive pixels of a row: every G-buffer plane is read as
 //    one 256-byte (RGBA8 / depth) or 64-byte (stencil) coalesced segment per wave, the half4 output
 //    is one 512-byte store; a block walks SHADE_ROWS rows after staging its tables once;
-//  * the light table is staged in LDS (48-byte records, three ds_read_b128-class reads per light);
-//  * the light lists of the clusters the block can touch are staged in LDS as u16 indices, so the
+//  * the light table is staged in LDS as nine structure-of-arrays planes (position, colour * intensity, attenuation):
+//    the same component of two lights lands in an adjacent VGPR pair straight from two ds_read_b32;
+//  * the light lists of the clusters the block can touch are staged in LDS as 16-bit LDS byte addresses, so the
 //    divergent per-lane list walk is an LDS read, not a global gather (blocks that span too many
 //    cluster tiles — tiny render targets — fall back to the global list);
-//  * IBL gathers (prefiltered env + LUT) are issued BEFORE the light loop and filtered after it,
-//    so their L2/MALL latency hides under ~2 000 VALU instructions; the env chain is sampled from
-//    its padded layout (pbr_env_pad): no seam branches, each bilinear row is one 16-byte load;
-//  * with 256 lights the kernel is FP32-VALU-bound (~60 VALU per pixel-light), not HBM-bound.
+//  * the env chain is sampled from its padded layout (pbr_env_pad): no seam branches, each bilinear row is one
+//    16-byte load;
+//  * with 256 lights the kernel is FP32-VALU-issue-bound (48 packed + 4 transcendental instructions per pair of
+//    lights), not HBM-bound.
 #include <type_traits>
 #include "pbr_internal.hpp"
 #include "pbr_device.hpp"
@@ -134,10 +135,12 @@ __device__ __forceinline__ f2 mul2_sat(f2 a, f2 b) {
 struct alignas(8) H4x2 { H4 a, b; };   // two x-adjacent half4 texels (16 bytes, 8-byte aligned)
 struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-byte aligned)
 
-// One pixel.  Register budget is the design constraint: on gfx950 a SIMD issues plain fp32 VALU at
-// ~2.2 cycles/instruction with 8 resident waves but only ~3.5 with 3 (measured, tools/valu_rate.hip;
-// v_pk_*_f32 costs two issue slots, so packing buys nothing).  The pixel is therefore shaded in
-// phases that keep <= 64 VGPRs live (8 waves/SIMD):
+// One pixel.  The kernel is bound by VALU ISSUE at 256 lights (SQ_ACTIVE_INST_VALU ~90 % of the launch), so the design
+// constraints are instruction count and instruction class; measured issue costs on gfx950 at this kernel's occupancy of
+// 5 waves per SIMD (tools/valu_rate3.hip -> profiles/r02_valu_rate3.txt, shader-clock cycles per wave-instruction per
+// SIMD): v_fma_f32 2.6, v_mul/v_add 3.0, v_pk_{fma,mul,add}_f32 4.7, v_max/v_min 4.6, v_rcp/v_rsq 8.5; with one wave
+// alone every plain op costs 7.5.  96 VGPRs (5 waves) is the measured optimum: 64 VGPRs (8 waves) spills heavily, 80 and
+// 116 VGPRs time the same.  The pixel is shaded in phases that keep the live set small:
 //   1. geometry: position, normal, view vector, roughness terms;
 //   2. light loop: accumulates nine light-colour-weighted sums that do not depend on albedo/F0:
 //        pl_c = Kdiff_c * S1_c + F0_c * spec_pix * S2_c + (1-F0_c) * spec_pix * S3_c
@@ -192,7 +195,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         //   T  = max(t^2, 1e-6/pi), t = NdotH^2 (a^2 - 1) + 1,
         //   A  = NdotL(1-k)+k (>= 1/8: the shader's max(.,1e-6) never binds),
         //   gl = NdotL / max(4 NdotL NdotV, 1e-4) = min(1 / (4 NdotV), 1e4 NdotL)      (1 / max(a,b) = min(1/a, 1/b))
-        //   attenuation * NdotL = NdotL / Q;  with r = 1 / (Q T A):  1/Q = r T A,  so one v_rcp serves both.
+        //   attenuation * NdotL = NdotL / Q;  with r = 1 / (Q T A):  1/Q = r T A,  so one v_rcp serves both; and T is
+        //   carried as t^2 h2^2 (h2 = |L + V|^2), which removes the normalisation of H: 4 transcendentals per pair of lights.
         const float ra = roughness * roughness;
         const float a4m1 = ra * ra - 1.0f;
         const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
@@ -203,7 +207,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // 5 waves per SIMD, cycles per wave-instruction per SIMD): v_pk_{fma,mul,add}_f32 4.7 (two lights per instruction),
         // plain v_fma 2.6 / v_mul 3.0, v_max / v_min 4.6, v_rsq / v_rcp 8.5.  Two lights per trip in the halves of packed
         // registers therefore buy ~1.2x per flop, not 2x; the SoA light planes put the same component of both lights into
-        // an adjacent VGPR pair with no moves.  Per trip: 47 packed + 6 transcendental + 2 min (+ 2 max on the slow paths).
+        // an adjacent VGPR pair with no moves.  Per trip: 48 packed + 4 transcendental + 2 min (+ 2 max on the slow paths).
         f2 a1x = f2s(0.0f), a1y = f2s(0.0f), a1z = f2s(0.0f), a2x = f2s(0.0f), a2y = f2s(0.0f), a2z = f2s(0.0f), a3x = f2s(0.0f), a3y = f2s(0.0f), a3z = f2s(0.0f);
         auto light2 = [&](auto q_safe, auto t_safe, const lds_cf* la, const lds_cf* lb) {
             constexpr bool QSAFE = decltype(q_safe)::value, TSAFE = decltype(t_safe)::value;
@@ -214,26 +218,32 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const f2 dist = d2 * invd;
             const f2 dn = dx * n.x + dy * n.y + dz * n.z;
             const f2 NdotL = mul2_sat(dn, invd);   // max(N.L, 0)
-            // N.H = N.(L + V) / |L + V| without normalising H.  |L + V|^2 is summed from the components of L + V, NOT taken
-            // as 2 + 2 L.V: at grazing incidence (L ~ -V, |L + V|^2 ~ 1e-2) the shortcut cancels and its 1e-7 error becomes
-            // 1e-5 of N.H, which a GGX highlight at roughness 0.2 (t ~ 2e-3) multiplies by 4 / t: several per cent of D
-            // (measured against the oracle on a 4K band: 3 pixels of 122 880).  One packed instruction more than the
-            // shortcut.  (L = -V exactly: 0 * rsq(0) = NaN, and the clamp turns NaN into 0.)
+            // |L + V|^2 is summed from the components of L + V, NOT taken as 2 + 2 L.V: at grazing incidence (L ~ -V,
+            // |L + V|^2 ~ 1e-2) the shortcut cancels and its 1e-7 error becomes 1e-5 of N.H, which a GGX highlight at
+            // roughness 0.2 (t ~ 2e-3) multiplies by 4 / t: several per cent of D (measured against the oracle on a 4K
+            // band: 3 pixels of 122 880).  One packed instruction more than the shortcut.
             const f2 wx = dx * invd + f2s(view.x), wy = dy * invd + f2s(view.y), wz = dz * invd + f2s(view.z);
-            const f2 h2 = wx * wx + wy * wy + wz * wz;
-            const f2 NdotH = mul2_sat(dn * invd + f2s(NdV), rsq2(h2));
-            const f2 t = (NdotH * NdotH) * a4m1 + f2s(1.0f);
+            // (the 1e-15 keeps h2 > 0 when L = -V exactly, so that the shared reciprocal below stays finite; it is
+            //  ten orders of magnitude below any |L + V|^2 that contributes light)
+            const f2 h2 = wx * wx + (wy * wy + (wz * wz + f2s(1.0e-15f)));
+            // GGX without normalising H at all: with nw = N.(L + V) and h2 = |L + V|^2, N.H^2 = nw^2 / h2 and
+            //   t = N.H^2 (a^2 - 1) + 1 = tn / h2,  tn = nw^2 (a^2 - 1) + h2,   so  1 / t^2 = h2^2 / tn^2
+            // which joins the one reciprocal of the trip: no v_rsq for H.  nw < 0 (the shader clamps N.H to 0 there)
+            // needs no case: N.L > 0 then forces N.V < 0, which zeroes the specular term through spec_pix.
+            const f2 nw = dn * invd + f2s(NdV);
+            const f2 tn = (nw * nw) * a4m1 + h2;
+            const f2 h4 = h2 * h2;
             // TSAFE: every active lane of the wave has a^2 >= 6e-4, hence t >= a^2 - 6e-8 > sqrt(1e-6 / pi) = 5.64e-4 and the
             // shader's max(pi t^2, 1e-6) never binds (decided per wave before the walk)
-            f2 T = t * t;
-            if constexpr (!TSAFE) T = max2(T, f2s(t_floor));
+            f2 Tn = tn * tn;                                 // t^2 h2^2
+            if constexpr (!TSAFE) Tn = max2(Tn, h4 * t_floor);
             const f2 A = NdotL * one_k + f2s(k);
             // attenuation(): max(C0 + C1 d + C2 d^2, 1e-6).  QSAFE: every staged light has C0 >= 1e-6 and C1, C2 >= 0,
             // so the floor never binds (checked once per block while the table is staged)
             f2 Q = comp(6) + comp(7) * dist + comp(8) * d2;
             if constexpr (!QSAFE) Q = max2(Q, f2s(EPSILON_F));
-            const f2 TA = T * A;
-            const f2 r = rcp2(Q * TA);                       // 1 / (Q T A)
+            const f2 TA = Tn * A;
+            const f2 r = rcp2(Q * TA);                       // 1 / (Q A t^2 h2^2)
             const f2 X = NdotL * (r * TA);                   // attenuation * NdotL = NdotL / Q
             const f2 gl = min2(f2s(inv_ndv4), NdotL * 1.0e4f);
             // fresnel on NdotL (Q3).  The shader's max(1-NdotL, 1e-6) only matters within 1e-6 of NdotL = 1, where it
@@ -241,7 +251,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const f2 fm = f2s(1.0f) - NdotL;
             const f2 fm2 = fm * fm;
             const f2 f5 = fm2 * fm2 * fm;
-            const f2 w2 = (NdotL * gl) * r;                  // X * gl / (T A)
+            const f2 w2 = (NdotL * gl) * (h4 * r);           // X * gl / (t^2 A)
             const f2 w1 = X - X * f5;                        // X * (1 - f5)
             const f2 w3 = w2 * f5;
             const f2 cr = comp(3), cg = comp(4), cb = comp(5);
@@ -385,7 +395,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
 // dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 68 B of light lists.
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 #ifndef SHADE_MIN_WAVES
-#define SHADE_MIN_WAVES 5   // 96 VGPRs, no spills: best of 4..8 measured (tools/probe_shade.py)
+#define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
 #endif
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters,
                                                                                  uint32_t nb_big, uint32_t rows_small) {

@@ -130,6 +130,16 @@ def test_prefilter_env_vs_oracle_and_golden(ctx, orc, golden, ibl):
     assert np.all(got[:, 3] == 1.0)
 
 
+def test_prefilter_env_per_dispatch_kernel_vs_oracle(ctx, orc, ibl):
+    """pbr_prefilter_env_mip — one reference dispatch, the shader's strictly sequential sum (what the C++ pass graph
+    issues five times) — against the oracle, all five mips of the 16^2 chain."""
+    sky, env, _, _ = ibl
+    got = to_np_half(ctx.prefilter_env_dispatches(ctx.upload(sky), common.SKY_SIZE, common.SKY_MIPS, common.ENV_SIZE, common.ENV_MIPS))
+    ok = (common.half_ulp_diff(got, env) <= 1) | (np.abs(got.astype(np.float32) - env.astype(np.float32)) <= 1e-3 * np.abs(env.astype(np.float32)))
+    assert ok.all(), f"prefilter (per dispatch): {(~ok).sum()} texels outside 1 ULP / 1e-3"
+    assert (common.half_ulp_diff(got, env) == 0).mean() > 0.99      # same summation order: nearly every texel bit-identical
+
+
 def test_prefilter_env_larger_cube_one_mip(ctx, orc):
     # 64^2 source, 32^2 output mip 2 (roughness 0.5): exercises PDF-based LOD selection across mips
     sky = synth.env_cube(64, 7)

@@ -78,6 +78,11 @@ def test_shading_state_binding_contract(host):
     assert host.pbrh_probe_binding(b"blur_vertical.hlsl", 0, b"InputTexture", T) == -1        # compute shader bound as graphics
 
 
+def to_half(t):
+    import torch
+    return t.cpu().view(torch.int16).numpy().view(np.float16)
+
+
 @pytest.mark.gpu
 def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
     """Two frames through RenderScheduler/FrameGraph vs the same passes issued from Python
@@ -139,7 +144,10 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
         sky = ctx.upload(sky_np)
         ctx.cube_gen_mips(sky, ENV, sky_mips)
         lut = ctx.brdf_lut(LUT)
-        env = ctx.prefilter_env(sky, ENV, sky_mips, ENV, 5)
+        env = ctx.prefilter_env_dispatches(sky, ENV, sky_mips, ENV, 5)    # one dispatch per mip, like PreFilterEnvMapPass
+        fast = to_half(ctx.prefilter_env(sky, ENV, sky_mips, ENV, 5))     # all mips, table-driven: <= 1 fp16 ULP or 1e-3 apart
+        seq = to_half(env)
+        assert ((common.half_ulp_diff(fast, seq) <= 1) | (np.abs(fast.astype(np.float32) - seq.astype(np.float32)) <= 1e-3 * np.abs(seq.astype(np.float32)))).all()
         sh = ctx.sh9_project(sky, ENV, sky_mips).cpu().numpy()
         g = scene.make_global(cam, W, H, sh_pack=sh, delta_time=1.0 / 60.0, time=1.0 / 60.0)
         for f in ("InvView", "View", "Projection", "CameraPos"):      # C++ Camera == Python Camera
