@@ -348,12 +348,14 @@ def main():
         if fr.allreduce is not None:
             fr.allreduce(fr.hist)
         ctx.sync()
+        # every rank runs the SAME sequence of collectives below whatever it finds; a finding is raised at the end
+        problem = None
         counted = int(fr.hist.cpu().to(torch.int64).sum())
         if counted != spec.full_w * spec.full_h:
-            raise RuntimeError(f"histogram counts {counted} pixels, frame has {spec.full_w * spec.full_h}")
+            problem = f"histogram counts {counted} pixels, frame has {spec.full_w * spec.full_h}"
         if halo:
             if bool((fr.level1 == 777.0).any()):
-                raise RuntimeError("halo exchange left level-1 texels of the extended tile unfilled")
+                problem = problem or "halo exchange left level-1 texels of the extended tile unfilled"
             pw = spec.ew // 2
             l1 = fr.level1.view(spec.eh // 2, pw, 4).view(torch.int16).to(torch.int64)
 
@@ -370,7 +372,9 @@ def main():
             sent = {k[1:]: v for d in every for k, v in d.items() if k[0] == "s"}
             for k, v in mine.items():
                 if k[0] == "r" and sent.get(k[1:]) != v:
-                    raise RuntimeError(f"halo strip {k[1]} -> {k[2]} arrived with another checksum")
+                    problem = problem or f"halo strip {k[1]} -> {k[2]} arrived with another checksum"
+        if problem:
+            raise RuntimeError(problem)
         fr.hist.zero_()
         fr.set_prev_luminance(0.18)
         return fr, gb_np
