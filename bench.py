@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--mode", choices=["halo", "apron"], default="halo", help="bloom across tile borders (N > 1)")
     p.add_argument("--transport", choices=["capi", "torch"], default="capi",
                    help="collectives through the C ABI's own RCCL communicator or through torch.distributed (also RCCL)")
+    p.add_argument("--no-overlap", action="store_true",
+                   help="halo mode: plain sequence shade -> prefilter -> exchange -> pyramid instead of ring / exchange || core")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     return p.parse_args()
@@ -325,7 +327,7 @@ def main():
             return f
         return lambda h: dist.all_reduce(h)   # RCCL, int32 sum == uint32 sum bit for bit
 
-    def setup(mode, transport):
+    def setup(mode, transport, overlap):
         """Build this rank's frame for (mode, transport), render one verification frame and check it:
         the all-reduced histogram must count every pixel of the whole frame exactly once, and in halo mode every
         level-1 texel of E must have arrived, with the sender's checksum.  Returns (frame, gb_np) or raises."""
@@ -336,15 +338,18 @@ def main():
         if halo:
             ht = HaloTransport("host" if rehearsal else transport, dist)
         fr = DeferredFrame(ctx, spec, g, lights, lut, LUT_RES, env, ENV_SIZE, ENV_MIPS, allreduce=make_allreduce(transport),
-                           all_specs=specs, rank=rank, halo_transport=ht)
+                           all_specs=specs, rank=rank, halo_transport=ht, overlap=overlap)
         gb_np = synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h)
         fr.upload_gbuffer(gb_np)
         fr.set_prev_luminance(0.18)
         if halo:
             fr.level1.fill_(777.0)
         fr.clustered()
-        fr.shade()
-        fr.bloom_histogram()
+        if fr.split is not None:       # the very sequence the timed frames run
+            fr.shade_and_bloom_overlapped()
+        else:
+            fr.shade()
+            fr.bloom_histogram()
         if fr.allreduce is not None:
             fr.allreduce(fr.hist)
         ctx.sync()
@@ -379,27 +384,31 @@ def main():
         fr.set_prev_luminance(0.18)
         return fr, gb_np
 
+    want_overlap = a.mode == "halo" and not a.no_overlap
     if world == 1:
-        candidates = [("single", "none")]
+        candidates = [("single", "none", False)]
     elif rehearsal:
-        candidates = [(a.mode, "torch")] + ([("apron", "torch")] if a.mode == "halo" else [])
+        candidates = [(a.mode, "torch", want_overlap)] + ([(a.mode, "torch", False)] if want_overlap else []) + \
+                     ([("apron", "torch", False)] if a.mode == "halo" else [])
     else:
         first = "capi" if capi_comm else "torch"
-        candidates = [(a.mode, first)]
+        candidates = [(a.mode, first, want_overlap)]
+        if want_overlap:
+            candidates.append((a.mode, first, False))
         if first == "capi":
-            candidates.append((a.mode, "torch"))
+            candidates.append((a.mode, "torch", False))
         if a.mode == "halo":
-            candidates.append(("apron", "torch"))
+            candidates.append(("apron", "torch", False))
     frame = None
-    for mode, transport in candidates:
+    for mode, transport, overlap in candidates:
         ok, err = True, None
         try:
-            frame, gb_np = setup(mode, transport)
+            frame, gb_np = setup(mode, transport, overlap)
         except Exception as e:   # noqa: BLE001
-            ok, err = False, f"{mode}/{transport} failed verification on rank {rank}: {e}"
+            ok, err = False, f"{mode}/{transport}{'/overlap' if overlap else ''} failed verification on rank {rank}: {e}"
         if all_agree(ok):
             break
-        notes.append(err or f"{mode}/{transport} failed on another rank")
+        notes.append(err or f"{mode}/{transport}{'/overlap' if overlap else ''} failed on another rank")
         frame = None
         torch.cuda.synchronize()
     if frame is None:
@@ -455,7 +464,7 @@ def main():
         "config": {"workload": workload, "frame": [spec.full_w, spec.full_h], "layout_rows_x_cols": f"{rows}x{cols}",
                    "tile": [spec.x0, spec.y0, spec.w, spec.h], "shaded_rect": [spec.sx0, spec.sy0, spec.sw, spec.sh],
                    "bloom_rect": [spec.ex0, spec.ey0, spec.ew, spec.eh],
-                   "bloom_borders": "none" if world == 1 else mode, "collectives": "none" if world == 1 else ("gloo-rehearsal" if rehearsal else f"rccl-{transport}"),
+                   "bloom_borders": "none" if world == 1 else (mode + (" (ring first: exchange overlaps the core's shade)" if frame.split is not None else "")), "collectives": "none" if world == 1 else ("gloo-rehearsal" if rehearsal else f"rccl-{transport}"),
                    "mean_lights_per_pixel_by_rank": lp},
     }
     if rehearsal:

@@ -82,6 +82,9 @@ void pbr_ctx_destroy(pbr_ctx* ctx) {
         nccl_destroy_fn d = (nccl_destroy_fn)dlsym(ctx->rccl_lib, "ncclCommDestroy");
         if (d) d(ctx->comm);
     }
+    if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -240,8 +243,8 @@ size_t pbr_halo_staging_bytes(const pbr_halo_peer* peers, uint32_t n_peers) {
     return t * 8;
 }
 
-pbr_status pbr_halo_exchange(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
-                             const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes) {
+static pbr_status halo_exchange_on(pbr_ctx* ctx, hipStream_t stream, pbr_half* plane, uint32_t pitch, uint32_t rows,
+                                   const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes) {
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, plane && pitch >= 1 && rows >= 1, "pbr_halo_exchange: null plane");
     if (n_peers == 0) return PBR_OK;
@@ -283,22 +286,60 @@ pbr_status pbr_halo_exchange(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint
     uint2* st = (uint2*)staging;
     if (snd.n) {
         const int bx = (max_s + 255) / 256 > 256 ? 256 : (max_s + 255) / 256;
-        hipLaunchKernelGGL(k_halo_copy<true>, dim3(bx, snd.n), dim3(256), 0, ctx->stream, (uint2*)plane, (int)pitch, st, snd);
+        hipLaunchKernelGGL(k_halo_copy<true>, dim3(bx, snd.n), dim3(256), 0, stream, (uint2*)plane, (int)pitch, st, snd);
         pbr_status r = pbr::launched(ctx, "k_halo_copy<pack>");
         if (r) return r;
     }
     if (f_gs() != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclGroupStart failed");
     int rc = 0;
-    for (int k = 0; k < snd.n && rc == 0; k++) rc = f_send(st + snd.off[k], (size_t)snd.w[k] * snd.h[k] * 8, NCCL_INT8, peer_of_s[k], ctx->comm, ctx->stream);
-    for (int k = 0; k < rcv.n && rc == 0; k++) rc = f_recv(st + rcv.off[k], (size_t)rcv.w[k] * rcv.h[k] * 8, NCCL_INT8, peer_of_r[k], ctx->comm, ctx->stream);
+    for (int k = 0; k < snd.n && rc == 0; k++) rc = f_send(st + snd.off[k], (size_t)snd.w[k] * snd.h[k] * 8, NCCL_INT8, peer_of_s[k], ctx->comm, stream);
+    for (int k = 0; k < rcv.n && rc == 0; k++) rc = f_recv(st + rcv.off[k], (size_t)rcv.w[k] * rcv.h[k] * 8, NCCL_INT8, peer_of_r[k], ctx->comm, stream);
     const int ge = f_ge();
     if (rc != 0 || ge != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclSend/ncclRecv group failed");
     if (rcv.n) {
         const int bx = (max_r + 255) / 256 > 256 ? 256 : (max_r + 255) / 256;
-        hipLaunchKernelGGL(k_halo_copy<false>, dim3(bx, rcv.n), dim3(256), 0, ctx->stream, (uint2*)plane, (int)pitch, st, rcv);
+        hipLaunchKernelGGL(k_halo_copy<false>, dim3(bx, rcv.n), dim3(256), 0, stream, (uint2*)plane, (int)pitch, st, rcv);
         pbr_status r = pbr::launched(ctx, "k_halo_copy<unpack>");
         if (r) return r;
     }
+    return PBR_OK;
+}
+
+pbr_status pbr_halo_exchange(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
+                             const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes) {
+    if (!ctx) return PBR_ERR_INVALID;
+    return halo_exchange_on(ctx, ctx->stream, plane, pitch, rows, peers, n_peers, staging, staging_bytes);
+}
+
+// The same exchange on the context's SIDE stream, so that it overlaps whatever the caller enqueues on the context's
+// stream between _begin and _end (the shade of the tile's core, while the strips of its border ring travel):
+//   _begin: the side stream waits for everything enqueued so far, then packs, sends / receives, unpacks;
+//   _end:   the context's stream waits for the exchange.
+// Between the two calls the caller must not touch the rectangles being sent or received, nor the staging area.
+pbr_status pbr_halo_exchange_begin(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
+                                   const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, !ctx->exchange_in_flight, "pbr_halo_exchange_begin: the previous exchange was not ended");
+    PBR_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->comm_stream) {
+        PBR_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        PBR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        PBR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    PBR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    PBR_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_fork, 0));
+    pbr_status r = halo_exchange_on(ctx, ctx->comm_stream, plane, pitch, rows, peers, n_peers, staging, staging_bytes);
+    if (r) return r;
+    PBR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->comm_stream));
+    ctx->exchange_in_flight = true;
+    return PBR_OK;
+}
+
+pbr_status pbr_halo_exchange_end(pbr_ctx* ctx) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, ctx->exchange_in_flight, "pbr_halo_exchange_end: no exchange in flight");
+    ctx->exchange_in_flight = false;
+    PBR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return PBR_OK;
 }
 

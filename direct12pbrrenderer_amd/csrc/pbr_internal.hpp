@@ -19,6 +19,10 @@ struct pbr_ctx {
     void* comm = nullptr;
     int world = 1;
     int rank = 0;
+    // side stream + events of pbr_halo_exchange_begin / _end (created on first use)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool exchange_in_flight = false;
 };
 
 namespace pbr {

@@ -205,6 +205,33 @@ class HaloTransport:
         assert kind in ("capi", "torch", "host")
         self.kind, self.dist = kind, dist
 
+    def begin(self, fr):
+        """Start the exchange so that it overlaps what the caller enqueues until end(): capi -> the context's side
+        stream (pbr_halo_exchange_begin); torch -> a torch side stream; host -> done synchronously here."""
+        if not fr.halo_n:
+            return
+        if self.kind == "capi":
+            fr.ctx.halo_exchange_begin(fr.level1, fr.spec.ew // 2, fr.spec.eh // 2, fr.halo_peers, fr.halo_n, fr.halo_staging)
+        elif self.kind == "torch":
+            main = torch.cuda.current_stream(fr.ctx.torch_device)
+            if getattr(self, "side", None) is None:
+                self.side = torch.cuda.Stream(fr.ctx.torch_device)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                fr.ctx.bind_torch_stream()
+                self.exchange(fr)
+            fr.ctx.bind_torch_stream()
+        else:
+            self.exchange(fr)
+
+    def end(self, fr):
+        if not fr.halo_n:
+            return
+        if self.kind == "capi":
+            fr.ctx.halo_exchange_end()
+        elif self.kind == "torch":
+            torch.cuda.current_stream(fr.ctx.torch_device).wait_stream(self.side)
+
     def exchange(self, fr):
         ctx, a1, pitch, rows = fr.ctx, fr.level1, fr.spec.ew // 2, fr.spec.eh // 2
         if not fr.halo_n:
@@ -240,10 +267,12 @@ class DeferredFrame:
     """Owns the device buffers of one rank and runs the per-frame passes through the C ABI."""
 
     def __init__(self, ctx: PbrContext, spec: TileSpec, g: Global, lights_np, lut, lut_res, env, env_size,
-                 env_mips=ENV_MIPS, allreduce=None, sky=None, all_specs=None, rank=0, halo_transport=None):
+                 env_mips=ENV_MIPS, allreduce=None, sky=None, all_specs=None, rank=0, halo_transport=None, overlap=False):
         """sky: optional (cube tensor fp32 RGBA with mips, size, mips) — resolved on stencil == 0 pixels
         before the shade like the reference's SkyboxPass; without it those pixels keep what the buffer holds.
-        Halo mode (spec.halo): all_specs = the TileSpec of every rank, rank = this one, halo_transport = HaloTransport."""
+        Halo mode (spec.halo): all_specs = the TileSpec of every rank, rank = this one, halo_transport = HaloTransport.
+        overlap (halo mode): shade the tile's border RING first, start the exchange of its level-1 strips on a side stream
+        and shade the CORE while they travel (falls back to the plain sequence when the tile is too small to split)."""
         self.ctx, self.spec, self.g = ctx, spec, g
         self.sky = sky
         self.n_lights = int(len(lights_np))
@@ -275,6 +304,34 @@ class DeferredFrame:
             self.halo_plan_local = [(n, loc(snd), loc(rcv)) for n, snd, rcv in halo_plan(rank, len(all_specs), all_specs)]
             self.halo_peers, self.halo_n = ctx.halo_peers(self.halo_plan_local)
             self.halo_staging = ctx.zeros((max(ctx.halo_staging_bytes(self.halo_peers, self.halo_n) // 8, 1), 4), torch.float16)
+        self.split = self._ring_core_split() if (spec.halo and overlap) else None
+
+    def _ring_core_split(self):
+        """Rectangles of the overlapped halo frame.  The strips a neighbour needs are the interior's level-1 texels within
+        128 half-res texels of the shared edge; their prefilter reads full-res pixels up to 256 + 3 px inside the edge.
+        Returns (shade_ring, shade_core, l1_ring, l1_core): shade rects in S-local pixels, level-1 rects in half-res texels
+        of the S image; ring U core = S resp. interior / 2, disjoint.  None if the tile is too small to be worth it."""
+        s = self.spec
+        L, R = s.x0 > 0, s.x0 + s.w < s.full_w
+        T, B = s.y0 > 0, s.y0 + s.h < s.full_h
+        reach = s.apron + 4                                  # 256 + 3, rounded to keep rectangle edges even
+        left = s.six + reach if L else 0
+        right = (s.sw - s.six - s.w) + reach if R else 0
+        top = s.siy + reach if T else 0
+        bot = (s.sh - s.siy - s.h) + reach if B else 0
+        mid_w, mid_h = s.sw - left - right, s.sh - top - bot
+        if mid_w < 256 or mid_h < 64:
+            return None
+        ring = [r for r in ((0, 0, s.sw, top), (0, s.sh - bot, s.sw, bot), (0, top, left, mid_h), (s.sw - right, top, right, mid_h))
+                if r[2] > 0 and r[3] > 0]
+        core = (left, top, mid_w, mid_h)
+        hb = s.apron // 2
+        ox, oy, iw, ih = s.six // 2, s.siy // 2, s.w // 2, s.h // 2
+        l, r_, t, b = (hb if L else 0), (hb if R else 0), (hb if T else 0), (hb if B else 0)
+        l1_ring = [q for q in ((ox, oy, iw, t), (ox, oy + ih - b, iw, b), (ox, oy + t, l, ih - t - b), (ox + iw - r_, oy + t, r_, ih - t - b))
+                   if q[2] > 0 and q[3] > 0]
+        l1_core = (ox + l, oy + t, iw - l - r_, ih - t - b)
+        return ring, core, l1_ring, l1_core
 
     def upload_gbuffer(self, gb_np):
         """gb_np: dict of numpy planes covering the SHADED rectangle S (sh x sw; the extended rectangle in apron mode)."""
@@ -301,6 +358,32 @@ class DeferredFrame:
         s = self.spec
         self.ctx.deferred_shade(self.g, self.tile, self.gb, s.sw, self.lut, self.lut_res, self.env, self.env_size,
                                 self.env_mips, self.clusters, self.lights, self.n_lights, self.hdr, s.sw)
+
+    def shade_rect(self, rect):
+        """The shade on rect = (x, y, w, h) of the shaded rectangle S only (pointer offsets + the rect's own pbr_tile)."""
+        s = self.spec
+        x, y, w, h = rect
+        gb = {k: v[y:y + h, x:x + w] for k, v in self.gb.items()}
+        self.ctx.deferred_shade(self.g, Tile(s.sx0 + x, s.sy0 + y, w, h, s.full_w, s.full_h), gb, s.sw, self.lut, self.lut_res,
+                                self.env, self.env_size, self.env_mips, self.clusters, self.lights, self.n_lights,
+                                self.hdr.data_ptr() + 8 * (y * s.sw + x), s.sw)
+
+    def prefilter_l1_rect(self, rect):
+        s = self.spec
+        self.ctx.bloom_prefilter_rect(self.hdr, s.sw, s.sh, s.sw, self.level1, s.ew // 2, (s.sx0 - s.ex0) // 2, (s.sy0 - s.ey0) // 2, rect)
+
+    def shade_and_bloom_overlapped(self, histogram=True):
+        """Halo frame with the exchange hidden behind the core's shade: ring -> strips -> exchange || core -> pyramid."""
+        ring, core, l1_ring, l1_core = self.split
+        for r in ring:
+            self.shade_rect(r)
+        for q in l1_ring:
+            self.prefilter_l1_rect(q)
+        self.halo_transport.begin(self)
+        self.shade_rect(core)
+        self.prefilter_l1_rect(l1_core)
+        self.halo_transport.end(self)
+        self.halo_pyramid(histogram)
 
     def bloom(self):
         s = self.spec
@@ -354,6 +437,20 @@ class DeferredFrame:
         self.clustered()
         if self.sky is not None:
             self.skybox()
+        if self.split is not None:
+            e0 = e1 = None
+            if shade_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.shade_and_bloom_overlapped()
+            if shade_events is not None:   # brackets shade + bloom here: the two are interleaved
+                e1.record()
+                shade_events.append((e0, e1))
+            if self.allreduce is not None:
+                self.allreduce(self.hist)
+            self.average()
+            self.tonemap()
+            return
         if shade_events is None:
             self.shade()
         else:

@@ -45,7 +45,7 @@ def _ibl_dev(ctx, ibl):
     return up(lut), up(env)
 
 
-def _worker(rank, world, port, outdir, layout, halo, tile_w, tile_h):
+def _worker(rank, world, port, outdir, layout, halo, tile_w, tile_h, overlap=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -67,7 +67,8 @@ def _worker(rank, world, port, outdir, layout, halo, tile_w, tile_h):
     cam, g, lights, gb, _ = common.shade_scene(spec.sw, spec.sh, N_LIGHTS, ibl[3], full=(spec.full_w, spec.full_h),
                                                x0=spec.sx0, y0=spec.sy0, rough_min=48, coverage_mask=False)
     fr = DeferredFrame(ctx, spec, g, lights, lut, common.LUT_RES, env, common.ENV_SIZE, common.ENV_MIPS, allreduce=allreduce,
-                       all_specs=specs, rank=rank, halo_transport=HaloTransport("host", dist) if halo else None)
+                       all_specs=specs, rank=rank, halo_transport=HaloTransport("host", dist) if halo else None, overlap=overlap)
+    assert (fr.split is not None) == overlap
     fr.upload_gbuffer(gb)
     fr.set_prev_luminance(0.18)
     if halo:
@@ -85,17 +86,19 @@ def _worker(rank, world, port, outdir, layout, halo, tile_w, tile_h):
 
 # world 3: the middle rank has a neighbour (and an apron) on both sides; 2x2: aprons on two axes incl. the corner
 # (the way BASELINE cfg5 tiles its 8K frame); halo: level-1 strips from the neighbours instead of the shaded apron
-CASES = [(2, None, False, 512, 288), (3, None, False, 512, 288), (4, (2, 2), False, 384, 288), (4, (2, 2), True, 384, 288),
-         (2, None, True, 512, 288)]
+# overlap: the border ring is shaded first, its level-1 strips travel while the core is shaded (needs tiles > 2 x 264 px)
+CASES = [(2, None, False, 512, 288, False), (3, None, False, 512, 288, False), (4, (2, 2), False, 384, 288, False),
+         (4, (2, 2), True, 384, 288, False), (2, None, True, 512, 288, False), (4, (2, 2), True, 1024, 640, True),
+         (3, None, True, 832, 400, True)]
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,layout,halo,tile_w,tile_h", CASES)
-def test_ranks_match_single_gpu_frame(ctx, ibl, world, layout, halo, tile_w, tile_h):
+@pytest.mark.parametrize("world,layout,halo,tile_w,tile_h,overlap", CASES)
+def test_ranks_match_single_gpu_frame(ctx, ibl, world, layout, halo, tile_w, tile_h, overlap):
     from direct12pbrrenderer_amd.pipeline import TileSpec, grid_for_world
     cols, rows = grid_for_world(world, layout)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d, layout, halo, tile_w, tile_h), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, layout, halo, tile_w, tile_h, overlap), nprocs=world, join=True)
         ranks = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
     W, H = tile_w * cols, tile_h * rows
     fr = _frame(ctx, TileSpec(0, 0, W, H, W, H, 0), _ibl_dev(ctx, ibl), ibl[3])

@@ -271,3 +271,48 @@ def test_rgbe_decode_oracle_known_answers(orc):
     x = np.exp(np.random.default_rng(3).uniform(-20, 20, size=(1000, 3))).astype(np.float32)
     back = orc.rgbe_decode(hdr_writer.float_to_rgbe(x))[:, :3]
     assert np.all(back <= x) and np.all(x - back <= x.max(axis=1, keepdims=True) / 128.0)   # truncating 8-bit mantissa
+
+
+def test_ring_core_split_of_the_overlapped_halo_frame():
+    """DeferredFrame._ring_core_split (no GPU needed): ring U core tile the shaded rectangle resp. the interior's level-1
+    texels exactly once, every send rectangle of the halo plan lies in the ring, and the ring's level-1 texels read
+    ring pixels only — so the exchange can start before the core is shaded."""
+    from direct12pbrrenderer_amd import pipeline
+    from direct12pbrrenderer_amd.pipeline import halo_plan, tile_of_frame
+
+    class Stub:
+        pass
+    cases = [[tile_of_frame(r, 8, 7680, 4320, layout=(4, 2), halo=True) for r in range(8)],
+             [tile_for_rank(r, 8, 2720, 3056, layout=(4, 2), halo=True) for r in range(8)],
+             [tile_for_rank(r, 2, 2720, 3056, halo=True) for r in range(2)],
+             [tile_for_rank(r, 4, 1024, 640, layout=(2, 2), halo=True) for r in range(4)]]
+    for specs in cases:
+        for rank, spec in enumerate(specs):
+            f = Stub()
+            f.spec = spec
+            ring, core, l1_ring, l1_core = pipeline.DeferredFrame._ring_core_split(f)
+            cov = np.zeros((spec.sh, spec.sw), dtype=np.int32)
+            for x, y, w, h in ring + [core]:
+                cov[y:y + h, x:x + w] += 1
+            assert (cov == 1).all()
+            c1 = np.zeros((spec.sh // 2, spec.sw // 2), dtype=np.int32)
+            for x, y, w, h in l1_ring + [l1_core]:
+                c1[y:y + h, x:x + w] += 1
+            ox, oy = spec.six // 2, spec.siy // 2
+            want = np.zeros_like(c1)
+            want[oy:oy + spec.h // 2, ox:ox + spec.w // 2] = 1
+            assert np.array_equal(c1, want)
+            shaded = np.zeros((spec.sh, spec.sw), dtype=bool)
+            for x, y, w, h in ring:
+                shaded[y:y + h, x:x + w] = True
+            in_ring = np.zeros_like(c1, dtype=bool)
+            for x, y, w, h in l1_ring:      # prefilter of half-res texel x reads full-res 2x-3 .. 2x+2 (clamped at the image edge)
+                in_ring[y:y + h, x:x + w] = True
+                assert shaded[max(2 * y - 3, 0):min(2 * (y + h - 1) + 2, spec.sh - 1) + 1, max(2 * x - 3, 0):min(2 * (x + w - 1) + 2, spec.sw - 1) + 1].all()
+            for n, snd, rcv in halo_plan(rank, len(specs), specs):
+                if snd:                          # global half-res -> S-image half-res
+                    sx, sy = snd[0] - spec.sx0 // 2, snd[1] - spec.sy0 // 2
+                    assert in_ring[sy:sy + snd[3] - snd[1], sx:sx + snd[2] - snd[0]].all(), (rank, n)
+    small = Stub()
+    small.spec = tile_for_rank(0, 4, 384, 288, layout=(2, 2), halo=True)
+    assert pipeline.DeferredFrame._ring_core_split(small) is None      # too small to split: plain sequence

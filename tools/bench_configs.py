@@ -63,15 +63,16 @@ class _NoExchange(HaloTransport):
         return
 
 
-def frame_times(name, spec, n_lights, what, cell=1, all_specs=None, rank=0):
+def frame_times(name, spec, n_lights, what, cell=1, all_specs=None, rank=0, overlap=False):
     cam = scene.Camera.reference_default(spec.full_w, spec.full_h)
     g = scene.make_global(cam, spec.full_w, spec.full_h, sh_pack=sh, delta_time=1.0 / 60.0)
     lights = synth.reference_scene_light() if n_lights == 1 else synth.lights_in_view_box(n_lights, cam)
     fr = DeferredFrame(ctx, spec, g, lights, lut, 512, env, 512, ENV_MIPS, all_specs=all_specs, rank=rank,
-                       halo_transport=_NoExchange() if spec.halo else None)
+                       halo_transport=_NoExchange() if spec.halo else None, overlap=overlap)
     fr.upload_gbuffer(synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h, cell=cell))
     fr.set_prev_luminance(0.18)
-    fr.render()
+    for _ in range(30):     # clocks up: the small tiles are over before the device has ramped
+        fr.render()
     shade = bench.time_stage(fr.shade, 20)
     bloom = bench.time_stage(fr.bloom_histogram, 20)
     fr.hist.zero_()
@@ -94,6 +95,10 @@ for halo in (False, True):
                 "busiest of 8 ranks of the 7680x4320 frame (2 rows x 4 cols): 1920x2160 tile, " +
                 ("shaded +4 px, bloom on tile + 256-px halo of level 1 (exchange itself not included: one GPU)" if halo else "shaded and bloomed with a 256-px apron"),
                 all_specs=specs5, rank=1)
+specs5 = [tile_of_frame(r, 8, 7680, 4320, layout=lay, halo=True) for r in range(8)]
+frame_times("cfg5-halo-ring-first", specs5[1], 256,
+            "the same tile, border ring shaded first (5 shade + 5 prefilter launches instead of 1 + 1) so that the exchange can overlap the core's shade "
+            "(exchange itself not included: one GPU) — the single-GPU cost of the split", all_specs=specs5, rank=1, overlap=True)
 frame_times("cfg5-1gpu", TileSpec(0, 0, 7680, 4320, 7680, 4320, 0), 256, "the whole 7680x4320 frame on one GPU (the strong-scaling denominator)")
 
 # ---- SURVEY 8f "next" rows at the headline size: G-buffer encode (48 B in + 12 B out per pixel) and a full-screen sky
