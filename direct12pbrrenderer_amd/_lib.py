@@ -26,6 +26,9 @@ SIGNATURES = {
     "pbr_ctx_destroy": (None, [_vp]),
     "pbr_ctx_set_stream": (_int, [_vp, _vp]),
     "pbr_ctx_use_own_stream": (_int, [_vp]),
+    "pbr_ctx_side_begin": (_int, [_vp]),
+    "pbr_ctx_side_end": (_int, [_vp]),
+    "pbr_ctx_side_join": (_int, [_vp]),
     "pbr_last_error": (C.c_char_p, [_vp]),
     "pbr_sync": (_int, [_vp]),
     "pbr_brdf_lut": (_int, [_vp, _u32, _vp]),
@@ -40,6 +43,8 @@ SIGNATURES = {
     "pbr_clustered": (_int, [_vp, C.POINTER(Global), _vp, _int, _vp]),
     "pbr_deferred_shade": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer),
                                   _vp, _u32, _vp, _u32, _u32, _vp, _vp, _int, _vp, _u32]),
+    "pbr_deferred_shade_rects": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer),
+                                        _vp, _u32, _vp, _u32, _u32, _vp, _vp, _int, _vp, _u32, _vp, _u32]),
     "pbr_deferred_shade_f32": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer),
                                       _vp, _u32, _vp, _u32, _u32, _vp, _vp, _int, _vp, _u32]),
     "pbr_skybox": (_int, [_vp, C.POINTER(Global), C.POINTER(Tile), C.POINTER(CubeF32), _vp, _u32, _vp, _u32]),
@@ -51,6 +56,7 @@ SIGNATURES = {
     "pbr_bloom_merge": (_int, [_vp, _vp, _u32, _vp, _u32, _u32]),
     "pbr_bloom": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32]),
     "pbr_bloom_prefilter_rect": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _u32, _u32, C.POINTER(_u32 * 4), _f32, _f32]),
+    "pbr_bloom_prefilter_rects": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _u32, _u32, _vp, _u32, _f32, _f32]),
     "pbr_bloom_tiled": (_int, [_vp, _vp, _u32, C.POINTER(_u32 * 4), _u32, _u32, _vp, _vp, C.POINTER(_u32 * 4), _f32, _f32, _vp]),
     "pbr_bloom_histogram": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32, C.POINTER(_u32 * 4), _f32, _f32, _vp]),
     "pbr_lum_histogram": (_int, [_vp, _vp, _u32, _u32, _u32, _f32, _f32, _vp]),

@@ -68,6 +68,17 @@ class PbrContext:
             msg = self.lib.pbr_last_error(self.h)
             raise PbrError(f"status {st}: {msg.decode() if msg else '?'}")
 
+    def side_begin(self):
+        """Calls until side_end() enqueue on the context's high-priority side stream (after all earlier work)."""
+        self._check(self.lib.pbr_ctx_side_begin(self.h))
+
+    def side_end(self):
+        self._check(self.lib.pbr_ctx_side_end(self.h))
+
+    def side_join(self):
+        """The context's stream waits for the side stream."""
+        self._check(self.lib.pbr_ctx_side_join(self.h))
+
     def sync(self):
         self._check(self.lib.pbr_sync(self.h))
 
@@ -150,6 +161,23 @@ class PbrContext:
                                                 _ptr(env), env_size, env_mips, _ptr(clusters), _ptr(lights),
                                                 int(num_lights), _ptr(hdr), hdr_pitch))
 
+    @staticmethod
+    def _rects(rects):
+        arr = ((C.c_uint32 * 4) * len(rects))()
+        for i, r in enumerate(rects):
+            arr[i] = (C.c_uint32 * 4)(*[int(v) for v in r])
+        return arr
+
+    def deferred_shade_rects(self, g: Global, tile: Tile, gb, pitch, lut, lut_res, env, env_size, env_mips,
+                             clusters, lights, num_lights, hdr, hdr_pitch, rects):
+        """deferred_shade on up to 5 rectangles (tile-local x, y, w, h) of the tile in one launch."""
+        s = GBuffer(gb["A"].data_ptr(), gb["B"].data_ptr(), gb["C"].data_ptr(), gb["depth"].data_ptr(),
+                    gb["stencil"].data_ptr(), pitch)
+        arr = self._rects(rects)
+        self._check(self.lib.pbr_deferred_shade_rects(self.h, C.byref(g), C.byref(tile), C.byref(s), _ptr(lut), lut_res,
+                                                      _ptr(env), env_size, env_mips, _ptr(clusters), _ptr(lights),
+                                                      int(num_lights), _ptr(hdr), hdr_pitch, C.cast(arr, C.c_void_p), len(rects)))
+
     def deferred_shade_f32(self, g: Global, tile: Tile, gb, pitch, lut, lut_res, env, env_size, env_mips,
                            clusters, lights, num_lights, hdr_f32, hdr_pitch):
         """Parity probe: deferred_shade with a float32 [h, w, 4] output (the colour before the fp16 store)."""
@@ -207,6 +235,11 @@ class PbrContext:
         r = (C.c_uint32 * 4)(*[int(v) for v in rect])
         self._check(self.lib.pbr_bloom_prefilter_rect(self.h, _ptr(hdr), w, h, pitch, _ptr(out), out_pitch, out_x, out_y,
                                                       C.byref(r), threshold, knee))
+
+    def bloom_prefilter_rects(self, hdr, w, h, pitch, out, out_pitch, out_x, out_y, rects, threshold=BLOOM_THRESHOLD, knee=BLOOM_KNEE):
+        arr = self._rects(rects)
+        self._check(self.lib.pbr_bloom_prefilter_rects(self.h, _ptr(hdr), w, h, pitch, _ptr(out), out_pitch, out_x, out_y,
+                                                       C.cast(arr, C.c_void_p), len(rects), threshold, knee))
 
     def bloom_tiled(self, hdr, hdr_pitch, hdr_rect, ew, eh, chain_a, chain_b, merge_rect, hist=None,
                     min_log=MIN_LOG_LUMINANCE, inv_range=INV_LOG_LUMINANCE_RANGE):

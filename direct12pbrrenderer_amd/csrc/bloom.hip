@@ -36,6 +36,13 @@ __device__ __forceinline__ F4 from4(float4 v) { return f4(v.x, v.y, v.z, v.w); }
 // out[(y + oy) * out_pitch + (x + ox)] — the whole image into a dense plane is {0,0,ow,oh}, pitch ow, offset 0;
 // a tile's interior into the level-1 plane of its extended rectangle is the multi-GPU halo path.
 struct OutRect { int x0, y0, x1, y1, ox, oy, pitch; };
+// several output rectangles in one launch of the shared-sample kernel (1-D grid; the overlapped multi-GPU frame
+// prefilters the four bands of its border ring at once): rectangle r owns blocks first[r] .. first[r+1]-1
+constexpr int PF_MAX_RECTS = 5;
+struct OutRects {
+    int n, ox, oy, pitch;
+    int x0[PF_MAX_RECTS], y0[PF_MAX_RECTS], x1[PF_MAX_RECTS], y1[PF_MAX_RECTS], tiles_x[PF_MAX_RECTS], first[PF_MAX_RECTS + 1];
+};
 __global__ __launch_bounds__(256) void k_bloom_prefilter(const pbr_half* __restrict__ hdr, int w, int h, int pitch,
                                                            pbr_half* __restrict__ out, int ow, int oh, OutRect rc,
                                                            float tx, float ty, float threshold, float knee) {
@@ -279,10 +286,14 @@ __global__ __launch_bounds__(256) void k_bloom_merge(pbr_half* __restrict__ hdr,
 
 constexpr int PF_TW = 64, PF_TH = 16;
 __global__ __launch_bounds__(256) void k_bloom_prefilter_2x(const pbr_half* __restrict__ hdr, int w, int h, int pitch,
-                                                              pbr_half* __restrict__ out, int ow, int oh, OutRect rc, float threshold, float knee) {
+                                                              pbr_half* __restrict__ out, int ow, int oh, OutRects rs, float threshold, float knee) {
     __shared__ float4 pos[PF_TH + 2][PF_TW + 2];   // (colour * weight, weight) of every sample position the tile touches
     const int tid = threadIdx.x;
-    const int bx0 = rc.x0 + blockIdx.x * PF_TW, by0 = rc.y0 + blockIdx.y * PF_TH;   // tiles are laid over the output rect
+    int r = 0;
+    while (r + 1 < rs.n && (int)blockIdx.x >= rs.first[r + 1]) r++;
+    const int lb = (int)blockIdx.x - rs.first[r];
+    const OutRect rc{rs.x0[r], rs.y0[r], rs.x1[r], rs.y1[r], rs.ox, rs.oy, rs.pitch};
+    const int bx0 = rc.x0 + (lb % rs.tiles_x[r]) * PF_TW, by0 = rc.y0 + (lb / rs.tiles_x[r]) * PF_TH;   // tiles are laid over the output rect
     const int px0 = bx0 - 1, py0 = by0 - 1;
     for (int e = tid; e < (PF_TH + 2) * (PF_TW + 2); e += 256) {
         const int r = e / (PF_TW + 2), c = e - r * (PF_TW + 2);
@@ -585,19 +596,33 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
 
 extern "C" {
 
+// rcs: n output rectangles sharing one destination offset / pitch
 static pbr_status prefilter_launch(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
-                                   pbr_half* out, const OutRect& rc, float threshold, float knee) {
+                                   pbr_half* out, const OutRect* rcs, int n, float threshold, float knee) {
     const uint32_t ow = w >> 1, oh = h >> 1;
-    const uint32_t rw = (uint32_t)(rc.x1 - rc.x0), rh = (uint32_t)(rc.y1 - rc.y0);
     const float tx = 1.0f / (float)ow, ty = 1.0f / (float)oh;   // DeferredPipeline.cpp:418
-    if (exact_half(w) && exact_half(h) && !force_staged()) {   // shared-sample kernel (bit-identical)
-        dim3 g2((rw + PF_TW - 1) / PF_TW, (rh + PF_TH - 1) / PF_TH);
-        hipLaunchKernelGGL(k_bloom_prefilter_2x, g2, dim3(256), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, rc, threshold, knee);
+    if (exact_half(w) && exact_half(h) && !force_staged()) {   // shared-sample kernel (bit-identical), all rectangles in one launch
+        OutRects rs{};
+        rs.n = n; rs.ox = rcs[0].ox; rs.oy = rcs[0].oy; rs.pitch = rcs[0].pitch;
+        int blocks = 0;
+        for (int r = 0; r < n; r++) {
+            rs.x0[r] = rcs[r].x0; rs.y0[r] = rcs[r].y0; rs.x1[r] = rcs[r].x1; rs.y1[r] = rcs[r].y1;
+            rs.tiles_x[r] = (rcs[r].x1 - rcs[r].x0 + PF_TW - 1) / PF_TW;
+            rs.first[r] = blocks;
+            blocks += rs.tiles_x[r] * ((rcs[r].y1 - rcs[r].y0 + PF_TH - 1) / PF_TH);
+        }
+        rs.first[n] = blocks;
+        hipLaunchKernelGGL(k_bloom_prefilter_2x, dim3(blocks), dim3(256), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, rs, threshold, knee);
         return launched(ctx, "k_bloom_prefilter_2x");
     }
-    dim3 grid((rw + 63) / 64, (rh + 3) / 4);
-    hipLaunchKernelGGL(k_bloom_prefilter, grid, dim3(64, 4), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, rc, tx, ty, threshold, knee);
-    return launched(ctx, "k_bloom_prefilter");
+    for (int r = 0; r < n; r++) {
+        const uint32_t rw = (uint32_t)(rcs[r].x1 - rcs[r].x0), rh = (uint32_t)(rcs[r].y1 - rcs[r].y0);
+        dim3 grid((rw + 63) / 64, (rh + 3) / 4);
+        hipLaunchKernelGGL(k_bloom_prefilter, grid, dim3(64, 4), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, rcs[r], tx, ty, threshold, knee);
+        pbr_status st = launched(ctx, "k_bloom_prefilter");
+        if (st) return st;
+    }
+    return PBR_OK;
 }
 
 pbr_status pbr_bloom_prefilter(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
@@ -606,7 +631,7 @@ pbr_status pbr_bloom_prefilter(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, ui
     PBR_REQUIRE(ctx, hdr && out, "pbr_bloom_prefilter: null pointer");
     PBR_REQUIRE(ctx, (w >> 1) >= 1 && (h >> 1) >= 1 && w <= 65535 && h <= 65535 && pitch >= w, "pbr_bloom_prefilter: bad size");
     const OutRect rc{0, 0, (int)(w >> 1), (int)(h >> 1), 0, 0, (int)(w >> 1)};
-    return prefilter_launch(ctx, hdr, w, h, pitch, out, rc, threshold, knee);
+    return prefilter_launch(ctx, hdr, w, h, pitch, out, &rc, 1, threshold, knee);
 }
 
 pbr_status pbr_bloom_prefilter_rect(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
@@ -618,7 +643,23 @@ pbr_status pbr_bloom_prefilter_rect(pbr_ctx* ctx, const pbr_half* hdr, uint32_t 
     PBR_REQUIRE(ctx, rect[2] >= 1 && rect[3] >= 1 && rect[0] + rect[2] <= (w >> 1) && rect[1] + rect[3] <= (h >> 1), "pbr_bloom_prefilter_rect: rect outside the half-res image");
     PBR_REQUIRE(ctx, out_pitch >= out_x + rect[0] + rect[2] && out_pitch <= 65535 && out_y <= 65535, "pbr_bloom_prefilter_rect: rect does not fit the output pitch");
     const OutRect rc{(int)rect[0], (int)rect[1], (int)(rect[0] + rect[2]), (int)(rect[1] + rect[3]), (int)out_x, (int)out_y, (int)out_pitch};
-    return prefilter_launch(ctx, hdr, w, h, pitch, out, rc, threshold, knee);
+    return prefilter_launch(ctx, hdr, w, h, pitch, out, &rc, 1, threshold, knee);
+}
+
+pbr_status pbr_bloom_prefilter_rects(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                     pbr_half* out, uint32_t out_pitch, uint32_t out_x, uint32_t out_y,
+                                     const uint32_t (*rects)[4], uint32_t n_rects, float threshold, float knee) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hdr && out && rects && n_rects >= 1 && n_rects <= (uint32_t)PF_MAX_RECTS, "pbr_bloom_prefilter_rects: null pointer / 1 .. 5 rectangles");
+    PBR_REQUIRE(ctx, (w >> 1) >= 1 && (h >> 1) >= 1 && w <= 65535 && h <= 65535 && pitch >= w && out_pitch <= 65535 && out_y <= 65535, "pbr_bloom_prefilter_rects: bad size");
+    OutRect rcs[PF_MAX_RECTS];
+    for (uint32_t r = 0; r < n_rects; r++) {
+        const uint32_t* q = rects[r];
+        PBR_REQUIRE(ctx, q[2] >= 1 && q[3] >= 1 && q[0] + q[2] <= (w >> 1) && q[1] + q[3] <= (h >> 1) && out_pitch >= out_x + q[0] + q[2],
+                    "pbr_bloom_prefilter_rects: rectangle outside the half-res image / the output pitch");
+        rcs[r] = OutRect{(int)q[0], (int)q[1], (int)(q[0] + q[2]), (int)(q[1] + q[3]), (int)out_x, (int)out_y, (int)out_pitch};
+    }
+    return prefilter_launch(ctx, hdr, w, h, pitch, out, rcs, (int)n_rects, threshold, knee);
 }
 
 pbr_status pbr_blur_h(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih, pbr_half* out, uint32_t ow, uint32_t oh) {

@@ -83,6 +83,9 @@ void pbr_ctx_destroy(pbr_ctx* ctx) {
         if (d) d(ctx->comm);
     }
     if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_side_fork) (void)hipEventDestroy(ctx->ev_side_fork);
+    if (ctx->ev_side_join) (void)hipEventDestroy(ctx->ev_side_join);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -92,6 +95,7 @@ void pbr_ctx_destroy(pbr_ctx* ctx) {
 
 pbr_status pbr_ctx_set_stream(pbr_ctx* ctx, void* hip_stream) {
     if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, !ctx->on_side, "pbr_ctx_set_stream: on the side stream (pbr_ctx_side_end first)");
     ctx->stream = (hipStream_t)hip_stream;   // NULL is HIP's default (null) stream, a legal target
     return PBR_OK;
 }
@@ -332,6 +336,58 @@ pbr_status pbr_halo_exchange_begin(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch
     if (r) return r;
     PBR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->comm_stream));
     ctx->exchange_in_flight = true;
+    return PBR_OK;
+}
+
+// ---- side stream: a second, HIGH-PRIORITY stream of the context ------------------------------------------------------
+// pbr_ctx_side_begin : the side stream waits for everything enqueued so far; calls made until _end enqueue THERE;
+// pbr_ctx_side_end   : back to the context's stream — what follows runs concurrently with the side stream's work;
+// pbr_ctx_side_join  : the context's stream waits for the side stream.
+// The overlapped multi-GPU frame puts the tile's border ring (shade, level-1 strips, halo exchange) on the side stream
+// and shades the core on the main one: the dispatcher serves the high-priority queue first, the core's blocks fill
+// whatever the ring leaves free, and the strips travel while the core is still being shaded.
+static pbr_status ensure_side(pbr_ctx* ctx) {
+    if (ctx->side_stream) return PBR_OK;
+    PBR_HIP(ctx, hipSetDevice(ctx->device));
+    int lo = 0, hi = 0;
+    PBR_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = greatest priority
+    PBR_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+    PBR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_fork, hipEventDisableTiming));
+    PBR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_join, hipEventDisableTiming));
+    return PBR_OK;
+}
+
+pbr_status pbr_ctx_side_begin(pbr_ctx* ctx) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, ctx->main_saved == nullptr && !ctx->on_side, "pbr_ctx_side_begin: already on the side stream");
+    pbr_status r = ensure_side(ctx);
+    if (r) return r;
+    PBR_HIP(ctx, hipEventRecord(ctx->ev_side_fork, ctx->stream));
+    PBR_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_side_fork, 0));
+    ctx->main_saved = ctx->stream;
+    ctx->main_was_null = ctx->stream == nullptr;
+    ctx->stream = ctx->side_stream;
+    ctx->on_side = true;
+    return PBR_OK;
+}
+
+pbr_status pbr_ctx_side_end(pbr_ctx* ctx) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, ctx->on_side, "pbr_ctx_side_end: not on the side stream");
+    PBR_HIP(ctx, hipEventRecord(ctx->ev_side_join, ctx->side_stream));
+    ctx->stream = ctx->main_saved;
+    ctx->main_saved = nullptr;
+    ctx->on_side = false;
+    ctx->side_pending = true;
+    return PBR_OK;
+}
+
+pbr_status pbr_ctx_side_join(pbr_ctx* ctx) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, !ctx->on_side, "pbr_ctx_side_join: still on the side stream (pbr_ctx_side_end first)");
+    if (!ctx->side_pending) return PBR_OK;
+    ctx->side_pending = false;
+    PBR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side_join, 0));
     return PBR_OK;
 }
 

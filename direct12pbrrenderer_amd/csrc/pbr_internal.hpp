@@ -23,6 +23,10 @@ struct pbr_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool exchange_in_flight = false;
+    // high-priority side stream of pbr_ctx_side_begin / _end / _join
+    hipStream_t side_stream = nullptr, main_saved = nullptr;
+    hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
+    bool on_side = false, side_pending = false, main_was_null = false;
 };
 
 namespace pbr {

@@ -104,6 +104,16 @@ __global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ sr
 // moves; the plane stride is a compile-time constant so the plane offset rides in the DS offset field.
 constexpr int LIGHT_PLANES = 9;
 
+// Which pixels of the tile a launch shades: up to SHADE_MAX_RECTS rectangles (tile-local), walked by ONE 1-D grid — a
+// whole tile is one rectangle; the overlapped multi-GPU frame shades the tile's border ring (<= 4 rectangles) in one
+// launch and its core in another.  Per rectangle the two-zone schedule of the kernel applies.
+constexpr int SHADE_MAX_RECTS = 5;
+struct ShadeRects {
+    uint32_t n, rows_small;
+    uint32_t x0[SHADE_MAX_RECTS], y0[SHADE_MAX_RECTS], w[SHADE_MAX_RECTS], h[SHADE_MAX_RECTS];
+    uint32_t cols[SHADE_MAX_RECTS], nb_big[SHADE_MAX_RECTS], first[SHADE_MAX_RECTS + 1];   // first block of rect r; [n] = total
+};
+
 constexpr int SHADE_BLOCK = 256;
 constexpr int SHADE_ROWS = 8;          // rows of 256 pixels one block walks after staging its tables
 constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per block
@@ -397,8 +407,7 @@ template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
 #endif
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters,
-                                                                                 uint32_t nb_big, uint32_t rows_small) {
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
     extern __shared__ float4 lds_raw[];
     __shared__ uint32_t s_mip_off[16];
     if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
@@ -423,18 +432,22 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         llds[7 * LSTRIDE + i] = l.C1;
         llds[8 * LSTRIDE + i] = l.C2;
     }
-    const uint32_t bx0 = blockIdx.x * SHADE_BLOCK;
+    // block -> rectangle -> (column block, row block); wave-uniform scalar arithmetic
+    uint32_t r = 0;
+    while (r + 1 < rc.n && blockIdx.x >= rc.first[r + 1]) r++;
+    const uint32_t lb = blockIdx.x - rc.first[r];
+    const uint32_t bx0 = rc.x0[r] + (lb % rc.cols[r]) * SHADE_BLOCK, x_end = rc.x0[r] + rc.w[r];
     // two-zone schedule: the first nb_big block rows walk SHADE_ROWS rows each, the rest rows_small — the short
     // blocks are dispatched last and fill the tail of the launch (a 4K frame is only ~3.2 waves of resident blocks)
-    const uint32_t by = blockIdx.y;
-    const uint32_t y_begin = by < nb_big ? by * SHADE_ROWS : nb_big * SHADE_ROWS + (by - nb_big) * rows_small;
-    const uint32_t y_end = min(y_begin + (by < nb_big ? (uint32_t)SHADE_ROWS : rows_small), p.h);
+    const uint32_t by = lb / rc.cols[r], nb_big = rc.nb_big[r], rows_small = rc.rows_small;
+    const uint32_t y_begin = rc.y0[r] + (by < nb_big ? by * SHADE_ROWS : nb_big * SHADE_ROWS + (by - nb_big) * rows_small);
+    const uint32_t y_end = min(y_begin + (by < nb_big ? (uint32_t)SHADE_ROWS : rows_small), rc.y0[r] + rc.h[r]);
     int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;   // < 64 KiB: the whole light table (<= 9 x 1025 floats) stays addressable in 16 bits
     if (STAGED_LISTS) {
         // cluster (x,y) tiles the block's pixel rectangle can fall into — same arithmetic as the per-pixel
         // ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners bound it
-        const uint32_t bx1 = min(bx0 + SHADE_BLOCK, p.w) - 1;
+        const uint32_t bx1 = min(bx0 + SHADE_BLOCK, x_end) - 1;
         auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
         auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
         tile_x0 = tx(bx0);
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     }
     const bool q_safe = __syncthreads_and(my_safe) != 0;
     const uint32_t px = bx0 + threadIdx.x;
-    if (px >= p.w) return;
+    if (px >= x_end) return;
     for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py);
 }
 
@@ -489,7 +502,8 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
                                const pbr_half* lut, uint32_t lut_res,
                                const pbr_half* env, uint32_t env_size, uint32_t env_mips,
                                const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
-                               pbr_half* hdr, float* hdr_f32, uint32_t hdr_pitch) {
+                               pbr_half* hdr, float* hdr_f32, uint32_t hdr_pitch,
+                               const uint32_t (*rects)[4] = nullptr, uint32_t n_rects = 0) {
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, g && tile && gb && lut && env && clusters && (F32OUT ? (const void*)hdr_f32 : (const void*)hdr), "pbr_deferred_shade: null pointer");
     PBR_REQUIRE(ctx, gb->A && gb->B && gb->C && gb->depth && gb->stencil, "pbr_deferred_shade: null G-buffer plane");
@@ -519,9 +533,24 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     static const float big_frac = getenv("PBR_SHADE_BIGFRAC") ? (float)atof(getenv("PBR_SHADE_BIGFRAC")) : 0.85f;
     static const uint32_t rows_small_cfg = getenv("PBR_SHADE_ROWS_SMALL") ? (uint32_t)atoi(getenv("PBR_SHADE_ROWS_SMALL")) : 2u;
     const uint32_t rows_small = rows_small_cfg >= 1 && rows_small_cfg <= (uint32_t)SHADE_ROWS ? rows_small_cfg : 2u;
-    uint32_t nb_big = (uint32_t)((float)(tile->h / SHADE_ROWS) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
-    const uint32_t rest = tile->h - nb_big * SHADE_ROWS;
-    dim3 grid((tile->w + SHADE_BLOCK - 1) / SHADE_BLOCK, nb_big + (rest + rows_small - 1) / rows_small);
+    const uint32_t whole[1][4] = {{0, 0, tile->w, tile->h}};
+    if (!rects) { rects = whole; n_rects = 1; }
+    PBR_REQUIRE(ctx, n_rects >= 1 && n_rects <= (uint32_t)SHADE_MAX_RECTS, "pbr_deferred_shade: 1 .. 5 rectangles");
+    ShadeRects rc{};
+    rc.n = n_rects; rc.rows_small = rows_small;
+    uint32_t blocks = 0;
+    for (uint32_t r = 0; r < n_rects; r++) {
+        const uint32_t* q = rects[r];
+        PBR_REQUIRE(ctx, q[2] >= 1 && q[3] >= 1 && q[0] + q[2] <= tile->w && q[1] + q[3] <= tile->h, "pbr_deferred_shade: rectangle outside the tile");
+        rc.x0[r] = q[0]; rc.y0[r] = q[1]; rc.w[r] = q[2]; rc.h[r] = q[3];
+        rc.cols[r] = (q[2] + SHADE_BLOCK - 1) / SHADE_BLOCK;
+        rc.nb_big[r] = (uint32_t)((float)(q[3] / SHADE_ROWS) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
+        const uint32_t rest = q[3] - rc.nb_big[r] * SHADE_ROWS;
+        rc.first[r] = blocks;
+        blocks += rc.cols[r] * (rc.nb_big[r] + (rest + rows_small - 1) / rows_small);
+    }
+    rc.first[n_rects] = blocks;
+    dim3 grid(blocks);
     // A block covers 256 x 8 pixels.  It can stage its cluster lists when that rectangle spans at most
     // MAX_STAGED_TILES cluster tiles: a tile is full_w/24 x full_h/16 pixels, +1 per axis for straddling.
     const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
@@ -531,10 +560,10 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
     const size_t lds = (size_t)LIGHT_PLANES * lstride * sizeof(float) + (size_t)max_clusters * LIST_STRIDE_U16 * sizeof(uint16_t);
     const dim3 blk(SHADE_BLOCK);
-    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, nb_big, rows_small);
-    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, nb_big, rows_small);
-    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, nb_big, rows_small);
-    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, nb_big, rows_small);
+    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
+    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
+    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
+    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
     return launched(ctx, "k_deferred_shade");
 }
 
@@ -546,6 +575,17 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
                               const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
                               pbr_half* hdr, uint32_t hdr_pitch) {
     return shade_launch<false>(ctx, g, tile, gb, lut, lut_res, env, env_size, env_mips, clusters, lights, num_lights, hdr, nullptr, hdr_pitch);
+}
+
+// The same pass on up to 5 rectangles of the tile (tile-local {x, y, w, h}) in ONE launch; pixels outside are left
+// untouched.  Multi-GPU overlap: the tile's border ring first, its core while the ring's bloom strips travel.
+pbr_status pbr_deferred_shade_rects(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
+                                    const pbr_half* lut, uint32_t lut_res,
+                                    const pbr_half* env, uint32_t env_size, uint32_t env_mips,
+                                    const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
+                                    pbr_half* hdr, uint32_t hdr_pitch, const uint32_t (*rects)[4], uint32_t n_rects) {
+    if (ctx && !rects) return pbr::fail(ctx, PBR_ERR_INVALID, "pbr_deferred_shade_rects: null rectangle list");
+    return shade_launch<false>(ctx, g, tile, gb, lut, lut_res, env, env_size, env_mips, clusters, lights, num_lights, hdr, nullptr, hdr_pitch, rects, n_rects);
 }
 
 // Parity probe: the same kernel body, storing float4 instead of rounding to the R16G16B16A16_FLOAT target — what the

@@ -359,30 +359,41 @@ class DeferredFrame:
         self.ctx.deferred_shade(self.g, self.tile, self.gb, s.sw, self.lut, self.lut_res, self.env, self.env_size,
                                 self.env_mips, self.clusters, self.lights, self.n_lights, self.hdr, s.sw)
 
-    def shade_rect(self, rect):
-        """The shade on rect = (x, y, w, h) of the shaded rectangle S only (pointer offsets + the rect's own pbr_tile)."""
+    def shade_rects(self, rects):
+        """The shade on rectangles (x, y, w, h) of the shaded rectangle S, ONE launch (pbr_deferred_shade_rects)."""
         s = self.spec
-        x, y, w, h = rect
-        gb = {k: v[y:y + h, x:x + w] for k, v in self.gb.items()}
-        self.ctx.deferred_shade(self.g, Tile(s.sx0 + x, s.sy0 + y, w, h, s.full_w, s.full_h), gb, s.sw, self.lut, self.lut_res,
-                                self.env, self.env_size, self.env_mips, self.clusters, self.lights, self.n_lights,
-                                self.hdr.data_ptr() + 8 * (y * s.sw + x), s.sw)
+        self.ctx.deferred_shade_rects(self.g, self.tile, self.gb, s.sw, self.lut, self.lut_res, self.env, self.env_size,
+                                      self.env_mips, self.clusters, self.lights, self.n_lights, self.hdr, s.sw, rects)
 
-    def prefilter_l1_rect(self, rect):
+    def prefilter_l1_rects(self, rects):
         s = self.spec
-        self.ctx.bloom_prefilter_rect(self.hdr, s.sw, s.sh, s.sw, self.level1, s.ew // 2, (s.sx0 - s.ex0) // 2, (s.sy0 - s.ey0) // 2, rect)
+        self.ctx.bloom_prefilter_rects(self.hdr, s.sw, s.sh, s.sw, self.level1, s.ew // 2, (s.sx0 - s.ex0) // 2, (s.sy0 - s.ey0) // 2, rects)
 
     def shade_and_bloom_overlapped(self, histogram=True):
-        """Halo frame with the exchange hidden behind the core's shade: ring -> strips -> exchange || core -> pyramid."""
+        """Halo frame with the exchange hidden behind the core's shade: ring -> strips -> exchange || core -> pyramid
+        (two shade launches and two prefilter launches instead of one each)."""
         ring, core, l1_ring, l1_core = self.split
-        for r in ring:
-            self.shade_rect(r)
-        for q in l1_ring:
-            self.prefilter_l1_rect(q)
-        self.halo_transport.begin(self)
-        self.shade_rect(core)
-        self.prefilter_l1_rect(l1_core)
-        self.halo_transport.end(self)
+        ctx, tr = self.ctx, self.halo_transport
+        if tr.kind == "torch":     # torch's P2P ops follow torch's current stream: plain fork / join around the exchange
+            self.shade_rects(ring)
+            self.prefilter_l1_rects(l1_ring)
+            tr.begin(self)
+            self.shade_rects([core])
+            tr.end(self)
+        else:                      # ring + its strips + the exchange on the context's high-priority side stream,
+            ctx.side_begin()       # the core on the main stream at the same time
+            self.shade_rects(ring)
+            self.prefilter_l1_rects(l1_ring)
+            if tr.kind == "host":
+                ctx.side_end()     # the host stand-in synchronises the device anyway
+                ctx.side_join()
+                tr.exchange(self)
+            else:
+                tr.exchange(self)  # pbr_halo_exchange, enqueued on the side stream
+                ctx.side_end()
+            self.shade_rects([core])
+            ctx.side_join()
+        self.prefilter_l1_rects([l1_core])   # reads 3 px into the ring: after the join
         self.halo_pyramid(histogram)
 
     def bloom(self):

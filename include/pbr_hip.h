@@ -146,6 +146,13 @@ void        pbr_ctx_destroy(pbr_ctx* ctx);
 pbr_status  pbr_ctx_set_stream(pbr_ctx* ctx, void* hip_stream);
 /* go back to the context's private stream */
 pbr_status  pbr_ctx_use_own_stream(pbr_ctx* ctx);
+/* A second, high-priority stream of the context.  _begin: it waits for everything enqueued so far, and the calls made
+ * until _end enqueue on it; _end: back to the context's stream — what follows runs concurrently with the side stream's
+ * work; _join: the context's stream waits for the side stream.  (Multi-GPU: the tile's border ring and its halo exchange
+ * on the side stream, the tile's core on the main one.) */
+pbr_status  pbr_ctx_side_begin(pbr_ctx* ctx);
+pbr_status  pbr_ctx_side_end(pbr_ctx* ctx);
+pbr_status  pbr_ctx_side_join(pbr_ctx* ctx);
 const char* pbr_last_error(const pbr_ctx* ctx);
 pbr_status  pbr_sync(pbr_ctx* ctx);
 const char* pbr_version(void);
@@ -215,6 +222,16 @@ pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile*
                               const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
                               pbr_half* hdr, uint32_t hdr_pitch);
 
+/* pbr_deferred_shade on up to 5 rectangles of the tile (tile-local {x, y, w, h}) in ONE launch; pixels outside are left
+ * untouched.  The overlapped multi-GPU frame shades the tile's border ring first (<= 4 rectangles), starts the halo
+ * exchange of its bloom strips, and shades the core while they travel. */
+pbr_status pbr_deferred_shade_rects(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile,
+                                    const pbr_gbuffer* gb,
+                                    const pbr_half* lut, uint32_t lut_res,
+                                    const pbr_half* env_padded, uint32_t env_size, uint32_t env_mips,
+                                    const pbr_cluster* clusters, const pbr_light* lights, int num_lights,
+                                    pbr_half* hdr, uint32_t hdr_pitch, const uint32_t (*rects)[4], uint32_t n_rects);
+
 /* Parity probe (not a product path): the same shade, storing the fp32 colour (float4 per pixel, alpha 1, pitch
  * hdr_pitch pixels, 16-byte aligned) instead of rounding it to the half4 target — the buffer the <= 1e-4 relative
  * L-inf parity bound is stated on. */
@@ -273,6 +290,10 @@ pbr_status pbr_bloom(pbr_ctx* ctx, pbr_half* hdr, uint32_t w, uint32_t h, uint32
 pbr_status pbr_bloom_prefilter_rect(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                                     pbr_half* out, uint32_t out_pitch, uint32_t out_x, uint32_t out_y,
                                     const uint32_t rect[4], float threshold, float knee);
+/* the same for up to 5 rectangles in one launch (the four bands of a tile's border ring) */
+pbr_status pbr_bloom_prefilter_rects(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                     pbr_half* out, uint32_t out_pitch, uint32_t out_x, uint32_t out_y,
+                                     const uint32_t (*rects)[4], uint32_t n_rects, float threshold, float knee);
 /* BloomPass::Execute minus its first dispatch, on the extended rectangle E (ew x eh, a multiple of 16 and <= 8192 on
  * a side) of a tile: level 1 of chain_a (offset pbr_bloom_level_offset(ew, eh, 1)) must hold the prefiltered image of
  * ALL of E — the interior from pbr_bloom_prefilter_rect, the rest from the neighbouring tiles (pbr_halo_exchange).

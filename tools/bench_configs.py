@@ -97,8 +97,8 @@ for halo in (False, True):
                 all_specs=specs5, rank=1)
 specs5 = [tile_of_frame(r, 8, 7680, 4320, layout=lay, halo=True) for r in range(8)]
 frame_times("cfg5-halo-ring-first", specs5[1], 256,
-            "the same tile, border ring shaded first (5 shade + 5 prefilter launches instead of 1 + 1) so that the exchange can overlap the core's shade "
-            "(exchange itself not included: one GPU) — the single-GPU cost of the split", all_specs=specs5, rank=1, overlap=True)
+            "the same tile, border ring shaded first on the high-priority side stream (2 shade + 2 prefilter launches instead of 1 + 1) so that the exchange "
+            "can overlap the core's shade (exchange itself not included: one GPU) — the single-GPU cost of the split", all_specs=specs5, rank=1, overlap=True)
 frame_times("cfg5-1gpu", TileSpec(0, 0, 7680, 4320, 7680, 4320, 0), 256, "the whole 7680x4320 frame on one GPU (the strong-scaling denominator)")
 
 # ---- SURVEY 8f "next" rows at the headline size: G-buffer encode (48 B in + 12 B out per pixel) and a full-screen sky
