@@ -67,8 +67,6 @@ SIGNATURES = {
     "pbr_allreduce_hist": (_int, [_vp, _vp]),
     "pbr_halo_staging_bytes": (_sz, [C.POINTER(HaloPeer), _u32]),
     "pbr_halo_exchange": (_int, [_vp, _vp, _u32, _u32, C.POINTER(HaloPeer), _u32, _vp, _sz]),
-    "pbr_halo_exchange_begin": (_int, [_vp, _vp, _u32, _u32, C.POINTER(HaloPeer), _u32, _vp, _sz]),
-    "pbr_halo_exchange_end": (_int, [_vp]),
     "pbr_halo_pack": (_int, [_vp, _vp, _u32, _u32, C.POINTER(HaloPeer), _u32, _vp, _sz, _int]),
     "pbr_runtime_error": (C.c_char_p, []),
     "pbr_membench_read": (_int, [_vp, _vp, _sz, _vp, _u32]),

@@ -287,14 +287,6 @@ class PbrContext:
         """RCCL send/recv of the plan's rectangles on the ctx communicator (pbr_comm_init first)."""
         self._check(self.lib.pbr_halo_exchange(self.h, _ptr(plane), pitch, rows, peers, n, _ptr(staging), staging.numel() * staging.element_size()))
 
-    def halo_exchange_begin(self, plane, pitch, rows, peers, n, staging):
-        """pbr_halo_exchange on the context's side stream (overlaps what is enqueued until halo_exchange_end)."""
-        self._check(self.lib.pbr_halo_exchange_begin(self.h, _ptr(plane), pitch, rows, peers, n, _ptr(staging),
-                                                     staging.numel() * staging.element_size()))
-
-    def halo_exchange_end(self):
-        self._check(self.lib.pbr_halo_exchange_end(self.h))
-
     def halo_pack(self, plane, pitch, rows, peers, n, staging, unpack=False):
         self._check(self.lib.pbr_halo_pack(self.h, _ptr(plane), pitch, rows, peers, n, _ptr(staging),
                                            staging.numel() * staging.element_size(), 1 if unpack else 0))

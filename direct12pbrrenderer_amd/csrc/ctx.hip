@@ -82,12 +82,9 @@ void pbr_ctx_destroy(pbr_ctx* ctx) {
         nccl_destroy_fn d = (nccl_destroy_fn)dlsym(ctx->rccl_lib, "ncclCommDestroy");
         if (d) d(ctx->comm);
     }
-    if (ctx->comm_stream) { (void)hipStreamSynchronize(ctx->comm_stream); (void)hipStreamDestroy(ctx->comm_stream); }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->ev_side_fork) (void)hipEventDestroy(ctx->ev_side_fork);
     if (ctx->ev_side_join) (void)hipEventDestroy(ctx->ev_side_join);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -315,30 +312,6 @@ pbr_status pbr_halo_exchange(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint
     return halo_exchange_on(ctx, ctx->stream, plane, pitch, rows, peers, n_peers, staging, staging_bytes);
 }
 
-// The same exchange on the context's SIDE stream, so that it overlaps whatever the caller enqueues on the context's
-// stream between _begin and _end (the shade of the tile's core, while the strips of its border ring travel):
-//   _begin: the side stream waits for everything enqueued so far, then packs, sends / receives, unpacks;
-//   _end:   the context's stream waits for the exchange.
-// Between the two calls the caller must not touch the rectangles being sent or received, nor the staging area.
-pbr_status pbr_halo_exchange_begin(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
-                                   const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes) {
-    if (!ctx) return PBR_ERR_INVALID;
-    PBR_REQUIRE(ctx, !ctx->exchange_in_flight, "pbr_halo_exchange_begin: the previous exchange was not ended");
-    PBR_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->comm_stream) {
-        PBR_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-        PBR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        PBR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
-    PBR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    PBR_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_fork, 0));
-    pbr_status r = halo_exchange_on(ctx, ctx->comm_stream, plane, pitch, rows, peers, n_peers, staging, staging_bytes);
-    if (r) return r;
-    PBR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->comm_stream));
-    ctx->exchange_in_flight = true;
-    return PBR_OK;
-}
-
 // ---- side stream: a second, HIGH-PRIORITY stream of the context ------------------------------------------------------
 // pbr_ctx_side_begin : the side stream waits for everything enqueued so far; calls made until _end enqueue THERE;
 // pbr_ctx_side_end   : back to the context's stream — what follows runs concurrently with the side stream's work;
@@ -388,14 +361,6 @@ pbr_status pbr_ctx_side_join(pbr_ctx* ctx) {
     if (!ctx->side_pending) return PBR_OK;
     ctx->side_pending = false;
     PBR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_side_join, 0));
-    return PBR_OK;
-}
-
-pbr_status pbr_halo_exchange_end(pbr_ctx* ctx) {
-    if (!ctx) return PBR_ERR_INVALID;
-    PBR_REQUIRE(ctx, ctx->exchange_in_flight, "pbr_halo_exchange_end: no exchange in flight");
-    ctx->exchange_in_flight = false;
-    PBR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return PBR_OK;
 }
 

@@ -19,10 +19,6 @@ struct pbr_ctx {
     void* comm = nullptr;
     int world = 1;
     int rank = 0;
-    // side stream + events of pbr_halo_exchange_begin / _end (created on first use)
-    hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool exchange_in_flight = false;
     // high-priority side stream of pbr_ctx_side_begin / _end / _join
     hipStream_t side_stream = nullptr, main_saved = nullptr;
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;

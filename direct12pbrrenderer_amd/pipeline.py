@@ -206,30 +206,22 @@ class HaloTransport:
         self.kind, self.dist = kind, dist
 
     def begin(self, fr):
-        """Start the exchange so that it overlaps what the caller enqueues until end(): capi -> the context's side
-        stream (pbr_halo_exchange_begin); torch -> a torch side stream; host -> done synchronously here."""
+        """torch transport only: run the exchange on a torch side stream so that it overlaps what the caller enqueues until
+        end() (the capi transport is enqueued on the context's own side stream instead: DeferredFrame.shade_and_bloom_overlapped)."""
+        assert self.kind == "torch"
         if not fr.halo_n:
             return
-        if self.kind == "capi":
-            fr.ctx.halo_exchange_begin(fr.level1, fr.spec.ew // 2, fr.spec.eh // 2, fr.halo_peers, fr.halo_n, fr.halo_staging)
-        elif self.kind == "torch":
-            main = torch.cuda.current_stream(fr.ctx.torch_device)
-            if getattr(self, "side", None) is None:
-                self.side = torch.cuda.Stream(fr.ctx.torch_device)
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                fr.ctx.bind_torch_stream()
-                self.exchange(fr)
+        main = torch.cuda.current_stream(fr.ctx.torch_device)
+        if getattr(self, "side", None) is None:
+            self.side = torch.cuda.Stream(fr.ctx.torch_device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
             fr.ctx.bind_torch_stream()
-        else:
             self.exchange(fr)
+        fr.ctx.bind_torch_stream()
 
     def end(self, fr):
-        if not fr.halo_n:
-            return
-        if self.kind == "capi":
-            fr.ctx.halo_exchange_end()
-        elif self.kind == "torch":
+        if fr.halo_n:
             torch.cuda.current_stream(fr.ctx.torch_device).wait_stream(self.side)
 
     def exchange(self, fr):

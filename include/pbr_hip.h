@@ -341,13 +341,6 @@ typedef struct pbr_halo_peer {
 size_t     pbr_halo_staging_bytes(const pbr_halo_peer* peers, uint32_t n_peers);
 pbr_status pbr_halo_exchange(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
                              const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes);
-/* The same exchange on the context's side stream: it overlaps what the caller enqueues between _begin and _end (the
- * shade of the tile's core while the strips of its border ring travel).  _begin: the side stream first waits for
- * everything enqueued so far on the context's stream; _end: the context's stream waits for the exchange.  In between the
- * caller must not touch the rectangles involved, nor the staging area. */
-pbr_status pbr_halo_exchange_begin(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t rows,
-                                   const pbr_halo_peer* peers, uint32_t n_peers, void* staging, size_t staging_bytes);
-pbr_status pbr_halo_exchange_end(pbr_ctx* ctx);
 /* the pack (unpack = 0: send rectangles -> staging) and unpack (unpack = 1: staging -> recv rectangles) halves on
  * their own, for a transport other than the context's communicator.  Staging layout: all send rectangles in peer
  * order, then all recv rectangles. */

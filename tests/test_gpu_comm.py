@@ -59,23 +59,26 @@ want = before.copy()
 want[20:29, 50:67] = before[2:11, 3:20]
 want[0:40, 30:38] = before[0:40, 70:78]
 assert np.array_equal(after, want), "self halo exchange moved the wrong texels"
-# the same exchange on the side stream (pbr_halo_exchange_begin / _end), with work enqueued in between
+# the same exchange on the context's high-priority side stream, with work on the main stream meanwhile
 before = after.copy()
 other = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
-ctx.halo_exchange_begin(plane.view(torch.float16), W, H, peers, n, st.view(torch.float16))
+ctx.side_begin()
+ctx.halo_exchange(plane.view(torch.float16), W, H, peers, n, st.view(torch.float16))
+ctx.side_end()
 other.add_(1.0)                               # on the context's (= torch's current) stream while the strips travel
-ctx.halo_exchange_end()
+ctx.side_join()
 ctx.sync()
 after = plane.cpu().numpy()
 want = before.copy()
 want[20:29, 50:67] = before[2:11, 3:20]
 want[0:40, 30:38] = before[0:40, 70:78]
 assert np.array_equal(after, want) and float(other[0]) == 1.0
+ctx.side_join()                               # nothing pending: a no-op
 try:
-    ctx.halo_exchange_end()
-    raise SystemExit("a second _end must be refused")
+    ctx.side_end()
+    raise SystemExit("side_end without side_begin must be refused")
 except Exception as e:
-    assert "no exchange in flight" in str(e)
+    assert "not on the side stream" in str(e)
 ctx.close()
 print("self-comm ok")
 """
