@@ -51,3 +51,15 @@ def test_bench_spawner_refuses_when_no_device_is_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 2 and "device(s) visible" in r.stderr, (r.returncode, r.stderr[-1000:])
+
+
+def test_host_library_exports_every_declared_symbol():
+    """libpbr_host.so (the C++ pass graph) exports what direct12pbrrenderer_amd/host/pbr_host.h declares."""
+    import ctypes
+    import torch  # noqa: F401  (its ROCm runtime first: see _lib.load)
+    lib = ctypes.CDLL(os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_host.so"))
+    header = open(os.path.join(ROOT, "direct12pbrrenderer_amd", "host", "pbr_host.h")).read()
+    declared = set(re.findall(r"\b(pbrh_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in pbr_host.h but not exported"
