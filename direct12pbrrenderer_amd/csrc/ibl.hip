@@ -541,8 +541,8 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     // ---- wave-parallel path: padded source chain + per-mip sample tables (stream-ordered scratch)
     PfLaunch pl{};
     pl.mips = mips; pl.size = size; pl.sky_size = sky->size; pl.sky_mips = sky->mips;
-    for (uint32_t l = 0; l < sky->mips; l++) pl.src_off[l] = (uint32_t)env_padded_mip_offset(sky->size, l);
-    const size_t padded_texels = env_padded_mip_offset(sky->size, sky->mips);
+    for (uint32_t l = 0; l < sky->mips; l++) pl.src_off[l] = (uint32_t)cube_border_mip_offset(sky->size, l);
+    const size_t padded_texels = cube_border_mip_offset(sky->size, sky->mips);
     PBR_REQUIRE(ctx, padded_texels <= 0xFFFFFFFFull, "pbr_prefilter_env: sky cube too large");
     ctx->host_tmp.assign((size_t)mips * PBR_SAMPLE_COUNT * 4, 0.0f);
     static const bool wave_per_texel = getenv("PBR_PREFILTER_WAVE") != nullptr;   // A/B switch: the other mapping

@@ -140,9 +140,20 @@ __host__ __device__ __forceinline__ size_t cube_mip_offset(uint32_t size, uint32
     return off;
 }
 
-__host__ __device__ __forceinline__ size_t env_padded_mip_offset(uint32_t size, uint32_t mip) {
+// border layout (the prefilter's padded fp32 source): every face of every mip with a 1-texel border, (s+2)^2 texels
+__host__ __device__ __forceinline__ size_t cube_border_mip_offset(uint32_t size, uint32_t mip) {
     size_t off = 0;
     for (uint32_t m = 0; m < mip; m++) { size_t s = (size >> m) + 2; off += 6 * s * s; }
+    return off;
+}
+// FOOTPRINT layout (the shade's env chain, pbr_env_pad): for every bilinear footprint origin (x, y) in [-1, s-1]^2 of
+// every face of every mip the four texels (x,y), (x+1,y), (x,y+1), (x+1,y+1) — already resolved by the seamless rule —
+// stored together: 32 contiguous bytes, ONE cache line per trilinear level instead of two rows 4 KB apart.  4 x the
+// plain chain (67 MB at 512^2 x 5): HBM capacity is what this part has to spare; the per-pixel IBL gathers with random
+// reflection vectors are bound by the lines they pull, not by arithmetic.
+__host__ __device__ __forceinline__ size_t env_padded_mip_offset(uint32_t size, uint32_t mip) {
+    size_t off = 0;
+    for (uint32_t m = 0; m < mip; m++) { size_t s = (size >> m) + 1; off += 6 * s * s * 4; }
     return off;
 }
 

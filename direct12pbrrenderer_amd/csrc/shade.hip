@@ -74,16 +74,17 @@ __device__ __forceinline__ V3 decode_octahedron(float u, float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Padded env chain: face f of mip m is (s+2) x (s+2); padded texel (xp,yp) holds the texel the
-// seamless-cube rule selects for tap (xp-1, yp-1) — interior texels are themselves.
+// "Padded" env chain = the footprint layout of pbr_device.hpp::env_padded_mip_offset: entry (face, yq, xq), xq, yq in
+// [0, s], holds the four texels of the bilinear footprint whose origin is tap (xq-1, yq-1), each resolved by the
+// seamless-cube rule.  One thread per stored texel.
 __global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ src, pbr_half* __restrict__ dst, int s) {
-    const int sp = s + 2;
-    const size_t n = (size_t)6 * sp * sp;
+    const int sq = s + 1;
+    const size_t n = (size_t)6 * sq * sq * 4;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    const int xp = (int)(t % sp), yp = (int)((t / sp) % sp);
-    uint32_t face = (uint32_t)(t / ((size_t)sp * sp));
-    int x = xp - 1, y = yp - 1;
+    const int k = (int)(t & 3), xq = (int)((t >> 2) % sq), yq = (int)(((t >> 2) / sq) % sq);
+    uint32_t face = (uint32_t)((t >> 2) / ((size_t)sq * sq));
+    int x = xq - 1 + (k & 1), y = yq - 1 + (k >> 1);
     const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
     if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
         if (xo & yo) y = clampi(y, 0, s - 1);
@@ -352,15 +353,16 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             cv = (tc * inv + 1.0f) * 0.5f;
         }
         auto fetch = [&](uint32_t l, uint32_t mip_off) {
-            const int s = (int)(p.env_size >> l), sp = s + 2;
+            const int s = (int)(p.env_size >> l), sq = s + 1;
             // u in [0,1] -> texel coordinate in [-0.5, s-0.5]: no NaN / range guard needed here; x.8 fixed-point snap
             const float fxp = snap8(cu * (float)s) - 0.5f, fyp = snap8(cv * (float)s) - 0.5f;
             const float flx = floorf(fxp), fly = floorf(fyp);
             const float fx = fxp - flx, fy = fyp - fly;
             const H4* m = reinterpret_cast<const H4*>(p.env) + mip_off;
-            const uint32_t o = (face * (uint32_t)sp + (uint32_t)((int)fly + 1)) * (uint32_t)sp + (uint32_t)((int)flx + 1);
+            // footprint layout: the four texels of this tap are 32 contiguous bytes
+            const uint32_t o = ((face * (uint32_t)sq + (uint32_t)((int)fly + 1)) * (uint32_t)sq + (uint32_t)((int)flx + 1)) * 4u;
             const H4x2 r0 = *reinterpret_cast<const H4x2*>(m + o);
-            const H4x2 r1 = *reinterpret_cast<const H4x2*>(m + o + sp);
+            const H4x2 r1 = *reinterpret_cast<const H4x2*>(m + o + 2);
             const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
             const float tr = (float)r0.a.x * wx0 + (float)r0.b.x * fx, br = (float)r1.a.x * wx0 + (float)r1.b.x * fx;
             const float tg = (float)r0.a.y * wx0 + (float)r0.b.y * fx, bg = (float)r1.a.y * wx0 + (float)r1.b.y * fx;
@@ -486,7 +488,7 @@ pbr_status pbr_env_pad(pbr_ctx* ctx, const pbr_half* env, uint32_t size, uint32_
     PBR_REQUIRE(ctx, size >= 1 && size <= 8192 && mips >= 1 && mips <= 16 && (size >> (mips - 1)) >= 1, "pbr_env_pad: bad size/mips");
     for (uint32_t m = 0; m < mips; m++) {
         const int s = (int)(size >> m);
-        const size_t n = (size_t)6 * (s + 2) * (s + 2);
+        const size_t n = (size_t)6 * (s + 1) * (s + 1) * 4;
         hipLaunchKernelGGL(k_env_pad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            env + 4 * cube_mip_offset(size, m), out_padded + 4 * env_padded_mip_offset(size, m), s);
         pbr_status r = launched(ctx, "k_env_pad");

@@ -100,8 +100,9 @@ def cube_texels(size: int, mips: int) -> int:
 
 
 def env_padded_mip_offset(size: int, mip: int) -> int:
-    """Texel offset of mip `mip` in the padded env layout ((s+2)^2 per face, see pbr_env_pad)."""
-    return sum(6 * ((size >> m) + 2) ** 2 for m in range(mip))
+    """Texel offset of mip `mip` in the footprint layout of pbr_env_pad (4 texels per bilinear footprint origin,
+    (s+1)^2 origins per face)."""
+    return sum(6 * ((size >> m) + 1) ** 2 * 4 for m in range(mip))
 
 
 def env_padded_texels(size: int, mips: int) -> int:

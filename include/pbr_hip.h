@@ -128,10 +128,11 @@ typedef struct pbr_cube_f32 {
 size_t pbr_cube_texels(uint32_t size, uint32_t mips);
 /* texel offset of (mip, face 0) */
 size_t pbr_cube_mip_offset(uint32_t size, uint32_t mip);
-/* texels of the PADDED prefiltered-env layout pbr_deferred_shade samples: every face of every mip
- * carries a 1-texel border ((s+2) x (s+2)) holding the texel the seamless-cube rule selects for an
- * out-of-face tap, so the per-pixel trilinear fetch is branch-free and each bilinear row is one
- * contiguous 16-byte pair.  Offset of (mip, face 0) = pbr_env_padded_mip_offset. */
+/* texels of the "padded" prefiltered-env layout pbr_deferred_shade samples — a FOOTPRINT layout: for every bilinear
+ * footprint origin (x, y) in [-1, s-1]^2 of every face of every mip, the four texels (x,y), (x+1,y), (x,y+1), (x+1,y+1),
+ * each already resolved by the seamless-cube rule, stored together (32 contiguous bytes): the per-pixel trilinear fetch
+ * is branch-free and touches ONE cache line per level.  4 x the plain chain (67 MB at 512^2 x 5).  Entry (face, y+1, x+1)
+ * of mip m starts at texel pbr_env_padded_mip_offset(size, m) + ((face * (s+1) + y+1) * (s+1) + x+1) * 4. */
 size_t pbr_env_padded_texels(uint32_t size, uint32_t mips);
 size_t pbr_env_padded_mip_offset(uint32_t size, uint32_t mip);
 /* texels of a PBR_BLOOM_MIPS-level 2D chain of a w x h image (level l is (w>>l) x (h>>l)) */
