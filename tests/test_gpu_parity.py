@@ -886,3 +886,73 @@ def test_frame_4k_halo_tiles_full_size_vs_single_frame(ctx, ibl):
         assert d.max() <= 2 and (d > 0).mean() < 2e-3, (s.x0, s.y0, d.max(), (d > 0).mean())
         hist_sum += t.hist.cpu().numpy().view(np.uint32)
     assert hist_sum.sum() == W * H and np.abs(hist_sum - hist_full).sum() <= 64
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_frame_8k_cfg5_full_size_band_properties_and_tiles(ctx, orc, ibl):
+    """BASELINE cfg5 at its real size on one GPU: the 7680x4320 frame (256 clustered lights + IBL) — an oracle band of the
+    shade, size-independent properties of the whole frame, and ONE rank's 1920x2160 tile of the 2 rows x 4 cols layout
+    (rank 1: neighbours on three sides + two corners) in both border modes against the single-frame interior: apron mode
+    as it runs on a GPU of the node, halo mode with the level-1 strips taken from the full frame's own level 1 (what the
+    five neighbours would send: every level-1 texel is computed once, by its owner, from identical pixels)."""
+    from direct12pbrrenderer_amd.pipeline import DeferredFrame, HaloTransport, TileSpec, parse_layout, tile_of_frame
+    from direct12pbrrenderer_amd.structs import bloom_level_offset
+    sky, env, lut, sh = ibl
+    W, H = 7680, 4320
+    cam, g, lights, gb, _ = common.shade_scene(W, H, 256, sh, rough_min=48, coverage_mask=False)
+    dlut, denv = dev_half(ctx, lut), dev_half(ctx, env)
+
+    class Manual(HaloTransport):
+        def __init__(self):
+            self.kind = "manual"
+
+        def exchange(self, fr):
+            pass
+
+    def make(spec, specs=None, rank=0):
+        fr = DeferredFrame(ctx, spec, g, lights, dlut, lut.shape[0], denv, common.ENV_SIZE, common.ENV_MIPS,
+                           all_specs=specs, rank=rank, halo_transport=Manual() if spec.halo else None)
+        fr.upload_gbuffer({k: np.ascontiguousarray(v[spec.sy0:spec.sy1, spec.sx0:spec.sx1]) for k, v in gb.items()})
+        return fr
+
+    full = make(TileSpec(0, 0, W, H, W, H, 0))
+    full.clustered(); full.shade()
+    shaded = to_np_half(full.hdr)
+    assert np.isfinite(shaded.astype(np.float32)).all()
+    y0, rows = 2128, 32
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    band = {k: np.ascontiguousarray(v[y0:y0 + rows]) for k, v in gb.items()}
+    want, want_f32, sens = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights,
+                                              want_f32=True, want_sens=True)
+    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "8K band", hard_ulp=None, sens=sens)
+    # the full frame's level 1 (prefilter of the shaded frame), before bloom overwrites the chains
+    l1_full = ctx.zeros((H // 2, W // 2, 4), torch.float16)
+    ctx.bloom_prefilter(full.hdr, W, H, W, l1_full)
+    full.bloom_histogram()
+    hist_full = full.hist.cpu().numpy().view(np.uint32)
+    assert hist_full.sum() == W * H
+    hdr_full = to_np_half(full.hdr)
+    assert np.all(hdr_full.astype(np.float32)[..., :3] >= shaded.astype(np.float32)[..., :3] - 1e-3)   # bloom only adds light
+    del full, shaded
+    lay = parse_layout("2x4")
+    for halo in (False, True):
+        specs = [tile_of_frame(r, 8, W, H, layout=lay, halo=halo) for r in range(8)]
+        s = specs[1]
+        assert (s.x0, s.y0, s.w, s.h, s.ew, s.eh) == (1920, 0, 1920, 2160, 2432, 2416)
+        t = make(s, specs, 1)
+        t.clustered(); t.shade()
+        if halo:
+            t.halo_prefilter()
+            plane = t.level1.view(s.eh // 2, s.ew // 2, 4)
+            own = plane[s.iy // 2:(s.iy + s.h) // 2, s.ix // 2:(s.ix + s.w) // 2].clone()
+            plane.copy_(l1_full[s.ey0 // 2:s.ey1 // 2, s.ex0 // 2:s.ex1 // 2])          # the neighbours' strips ...
+            assert torch.equal(plane[s.iy // 2:(s.iy + s.h) // 2, s.ix // 2:(s.ix + s.w) // 2], own)   # ... and the owner's texels agree bit for bit
+            t.halo_pyramid(histogram=True)
+        else:
+            t.bloom_histogram()
+        d = common.half_ulp_diff(t.hdr_interior()[..., :3], hdr_full[s.y0:s.y0 + s.h, s.x0:s.x0 + s.w, :3])
+        assert d.max() <= 2 and (d > 0).mean() < 2e-3, (halo, d.max(), (d > 0).mean())
+        assert t.hist.cpu().numpy().view(np.uint32).sum() == s.w * s.h
+        del t
