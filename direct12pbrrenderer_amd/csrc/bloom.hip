@@ -20,6 +20,7 @@
 //  * V passes do NOT use the reference's 1x256 column groups (one texel per 8 KiB-strided row =
 //    64 cache lines per wave); they use 64x16 tiles: lanes run along x, the (16+8) sampled rows
 //    of the tile are staged through LDS, so global accesses stay 512-byte coalesced.
+#include <type_traits>
 #include "pbr_internal.hpp"
 #include "pbr_device.hpp"
 
@@ -469,23 +470,65 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     {
-        Tap2 taps[PER_T], htap;
+        Tap2 htap;
         H4 up[DUAL ? PER_T : 1], hup;   // DUAL: the same-size input of bloom_upsample_add, exact texels
-        float fx, hfx, hfy = 0.0f, fy[PER_T];
+        float fx, hfx, hfy = 0.0f;
+        float4 smp[PER_T];              // the wave's PER_T rows of samples at this lane's column (rgb)
         int ax0, ax1, bx0, bx1;
         tap1d<MODE>(x0 - 4 + lane, iw, ax0, ax1, fx);
         tap1d<MODE>(x0 - 4 + hc, iw, bx0, bx1, hfx);
         const int sx = clampi(x0 - 4 + lane, 0, ow - 1), shx = clampi(x0 - 4 + hc, 0, ow - 1);
+        const int first = y0 - 4 + r0;   // wave-uniform
+        // 2x-up sampling, rows that need no vertical clamping (every wave but those on the image's first / last rows): the
+        // PER_T consecutive output rows blend only 4 (5) distinct input rows — output row 2m takes (m-1, m) with weight 3/4,
+        // row 2m+1 takes (m, m+1) with 1/4 — and the bilinear sample lerps in x first: hrow[j] = the x-lerp of input row j
+        // is computed ONCE and shared by the output rows that use it.  Same operations on the same operands as
+        // finish_tap2_rgb, half the loads and converts.  (Index patterns are compile-time per parity of the first row.)
+        const bool shared_rows = MODE == M_UP && first >= 1 && first + PER_T - 1 <= oh - 2;
+        if (MODE == M_UP && shared_rows) {
+            constexpr int NR = PER_T / 2 + 2;   // distinct input rows: 4 for PER_T = 5; 5 (even start) / 4 (odd start) for 6
+            const int base = (first >> 1) - 1 + (first & 1);
+            V3 hrow[NR];
+            const float wx0 = 1.0f - fx;
 #pragma unroll
-        for (int k = 0; k < PER_T; k++) {
-            const int jj = clampi(y0 - 4 + r0 + k, 0, oh - 1);
-            int ay0, ay1;
-            tap1d<MODE>(jj, ih, ay0, ay1, fy[k]);
-            taps[k] = load_tap2<MODE>(in, iw, ax0, ax1, ay0, ay1);
-            if (DUAL) up[k] = reinterpret_cast<const H4*>(in2)[(size_t)jj * ow + sx];
+            for (int j = 0; j < NR; j++) {
+                const H4* row = reinterpret_cast<const H4*>(in) + (size_t)min(base + j, ih - 1) * iw;
+                const H4 c0 = row[ax0], c1 = row[ax1];
+                hrow[j] = fma3(h3f(c1), fx, h3f(c0) * wx0);
+            }
+            auto blend = [&](auto parity) {
+                constexpr int P = decltype(parity)::value;
+#pragma unroll
+                for (int k = 0; k < PER_T; k++) {
+                    // output row first + k = 2m (+1): input rows (i0, i0 + 1) relative to base, second-tap weight 3/4 (1/4)
+                    constexpr int dummy = 0; (void)dummy;
+                    const int odd = (P + k) & 1;
+                    const int i0 = (P + k + 1) / 2 - P;          // even start: 0,1,1,2,2,3   odd start: 0,0,1,1,2,2
+                    const float fyk = odd ? 0.25f : 0.75f, wy0 = 1.0f - fyk;
+                    const V3 r = fma3(hrow[i0 + 1], fyk, hrow[i0] * wy0);
+                    smp[k] = make_float4(r.x, r.y, r.z, 0.0f);
+                }
+            };
+            if (first & 1) blend(std::integral_constant<int, 1>{}); else blend(std::integral_constant<int, 0>{});
+#pragma unroll
+            for (int k = 0; k < PER_T; k++)
+                if (DUAL) up[k] = reinterpret_cast<const H4*>(in2)[(size_t)(first + k) * ow + sx];
+        } else {
+            Tap2 taps[PER_T];
+            float fy[PER_T];
+#pragma unroll
+            for (int k = 0; k < PER_T; k++) {
+                const int jj = clampi(first + k, 0, oh - 1);
+                int ay0, ay1;
+                tap1d<MODE>(jj, ih, ay0, ay1, fy[k]);
+                taps[k] = load_tap2<MODE>(in, iw, ax0, ax1, ay0, ay1);
+                if (DUAL) up[k] = reinterpret_cast<const H4*>(in2)[(size_t)jj * ow + sx];
+            }
+#pragma unroll
+            for (int k = 0; k < PER_T; k++) smp[k] = finish_tap2_rgb<MODE>(taps[k], fx, fy[k]);
         }
         if (has_halo) {
-            const int jj = clampi(y0 - 4 + r0 + hk, 0, oh - 1);
+            const int jj = clampi(first + hk, 0, oh - 1);
             int ay0, ay1;
             tap1d<MODE>(jj, ih, ay0, ay1, hfy);
             htap = load_tap2<MODE>(in, iw, bx0, bx1, ay0, ay1);
@@ -493,7 +536,7 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
         }
 #pragma unroll
         for (int k = 0; k < PER_T; k++) {
-            line[lane] = finish_tap2_rgb<MODE>(taps[k], fx, fy[k]);
+            line[lane] = smp[k];
             if (DUAL) line2[lane] = make_float4((float)up[k].x, (float)up[k].y, (float)up[k].z, 0.0f);
             if (has_halo && hk == k) {
                 line[hc] = finish_tap2_rgb<MODE>(htap, hfx, hfy);
