@@ -589,6 +589,215 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- 2x-up levels of large images: 128-wide tiles
+// The same passes as k_blur_hv<M_UP, ...> (bit-identical results), remapped so that the LDS carries half the traffic
+// per output — in k_blur_hv the H pass's nine ds_reads per output and the V pass's nine keep the LDS pipe as busy as
+// the VALU (~5K cycles each per tile) and the two serialise:
+//   * H pass: a lane owns the column PAIR (2p, 2p+1) of its wave's rows.  The two 2x-up samples of a pair blend the
+//     three level texels p-1, p, p+1 (3 loads per two samples instead of 4), a sample line is 68 float2 entries per
+//     channel, and the two outputs of a lane tap the five entries lane .. lane+4: 15 ds_read_b64 per two outputs
+//     instead of 18 ds_read_b96.
+//   * V pass: a thread owns a column and TH/4 CONSECUTIVE rows, so the rows it taps overlap: TH/4 + 8 reads of the
+//     fp16 tile for TH/4 outputs instead of nine per output.
+// One block (512 threads, 8 waves) = one 128 x TH tile.  Operation order per sample / tap is k_blur_hv's.
+__device__ __forceinline__ void pair_tap_up(const pbr_half* __restrict__ in, int iw, int cm, int c0, int cp, int ay0, int ay1, float fy,
+                                            V3& even, V3& odd) {
+    const H4* ra = reinterpret_cast<const H4*>(in) + (size_t)ay0 * iw;
+    const H4* rb = reinterpret_cast<const H4*>(in) + (size_t)ay1 * iw;
+    const V3 am = h3f(ra[cm]), a0 = h3f(ra[c0]), ap = h3f(ra[cp]);
+    const V3 bm = h3f(rb[cm]), b0 = h3f(rb[c0]), bp = h3f(rb[cp]);
+    const float wy0 = 1.0f - fy;
+    // even column 2p: taps (p-1, p), second-tap weight 3/4; odd column 2p+1: (p, p+1), 1/4 (tap1d<M_UP>; finish_tap2_rgb)
+    even = fma3(fma3(b0, 0.75f, bm * 0.25f), fy, fma3(a0, 0.75f, am * 0.25f) * wy0);
+    odd = fma3(fma3(bp, 0.25f, b0 * 0.75f), fy, fma3(ap, 0.25f, a0 * 0.75f) * wy0);
+}
+// the nine taps of the two outputs of a lane from the five pair entries e[0..4] of one channel
+__device__ __forceinline__ void gauss9_pair(const float2* e, float& ge, float& go) {
+    const float s[10] = {e[0].x, e[0].y, e[1].x, e[1].y, e[2].x, e[2].y, e[3].x, e[3].y, e[4].x, e[4].y};
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { a = __builtin_fmaf(s[i], c_gauss[i], a); b = __builtin_fmaf(s[i + 1], c_gauss[i], b); }
+    ge = a; go = b;
+}
+
+template <bool DUAL, int TAIL, int TH>
+__global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restrict__ in, int iw, int ih,
+                                                          const pbr_half* __restrict__ in2,   // DUAL: ow x oh, same-size
+                                                          pbr_half* __restrict__ out, int ow, int oh, int out_pitch,
+                                                          int tiles_x, int n_tiles,
+                                                          TailRect tr, float min_log, float inv_range,
+                                                          uint32_t* __restrict__ hist) {
+    constexpr int TW = 128, NP = TW / 2 + 4, SR = TH + 8, NT = 512, NW = NT / 64;
+    constexpr int PER_T = SR / NW;      // H rows per wave
+    constexpr int PER_O = TH / 4;       // V outputs per thread: column t & 127, rows (t >> 7) * PER_O ..
+    static_assert(SR % NW == 0 && TH % 4 == 0 && PER_T * 4 <= 64, "rows must split evenly over the waves; one halo pair per lane");
+    __shared__ float2 sLine[DUAL ? 2 : 1][NW][3][NP];
+    __shared__ H4 sT[SR][TW];
+    __shared__ uint32_t sh_hist[TAIL == 2 ? NW : 1][TAIL == 2 ? PBR_HISTOGRAM_BINS : 1];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int vc = t & 127, vg = __builtin_amdgcn_readfirstlane(t >> 7);
+    if (TAIL == 2) {
+        for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += NT) (&sh_hist[0][0])[i] = 0u;
+    }
+    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[0].w);
+    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[0].w);
+    const h16 alpha_t = to_half_rn(alpha_h);
+    const float alpha_v = gauss9_const((float)alpha_t);
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int x0 = (TAIL != 0 ? tr.tx0 + tile % tiles_x : tile % tiles_x) * TW, y0 = (TAIL != 0 ? tr.ty0 + tile / tiles_x : tile / tiles_x) * TH;
+    const int xv = x0 + vc, rbase = vg * PER_O;
+    H4 hdr_in[PER_O];
+    const bool in_mx = TAIL != 0 && xv >= tr.mx0 && xv < tr.mx1;
+    if (TAIL != 0) {
+#pragma unroll
+        for (int k = 0; k < PER_O; k++) {
+            const int y = y0 + rbase + k;
+            if (in_mx && y >= tr.my0 && y < tr.my1) hdr_in[k] = *reinterpret_cast<const H4*>(out + 4 * ((size_t)(y - tr.by) * out_pitch + (xv - tr.bx)));
+        }
+    }
+    // sample positions: columns x0-4 .. x0+131 = pair entries 0..67 (entry q = level texel pair index x0/2 - 2 + q),
+    // rows clamp(y0-4+r).  Main entry of a row: q = lane; the four halo entries 64..67 of the wave's PER_T rows are one
+    // extra tap: lane -> (row lane / 4, entry 64 + lane % 4).
+    const int r0 = wv * PER_T, first = y0 - 4 + r0;
+    const int pp = (x0 >> 1) - 2 + lane;
+    const int cm = clampi(pp - 1, 0, iw - 1), c0 = clampi(pp, 0, iw - 1), cp = clampi(pp + 1, 0, iw - 1);
+    const bool has_halo = lane < PER_T * 4;
+    const int hk = lane >> 2, hq = 64 + (lane & 3);
+    {
+        V3 sE[PER_T], sO[PER_T], hE = v3(0.0f, 0.0f, 0.0f), hO = hE;
+        H4 upE[DUAL ? PER_T : 1], upO[DUAL ? PER_T : 1], hupE{}, hupO{};
+        const int sxe = clampi(x0 - 4 + 2 * lane, 0, ow - 1), sxo = clampi(x0 - 3 + 2 * lane, 0, ow - 1);
+        const bool shared_rows = first >= 1 && first + PER_T - 1 <= oh - 2;   // see k_blur_hv
+        if (shared_rows) {
+            constexpr int NR = PER_T / 2 + 2;
+            const int base = (first >> 1) - 1 + (first & 1);
+            V3 hrE[NR], hrO[NR];
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const H4* row = reinterpret_cast<const H4*>(in) + (size_t)min(base + j, ih - 1) * iw;
+                const V3 tm = h3f(row[cm]), t0 = h3f(row[c0]), tp = h3f(row[cp]);
+                hrE[j] = fma3(t0, 0.75f, tm * 0.25f);
+                hrO[j] = fma3(tp, 0.25f, t0 * 0.75f);
+            }
+            auto blend = [&](auto parity) {
+                constexpr int P = decltype(parity)::value;
+#pragma unroll
+                for (int k = 0; k < PER_T; k++) {
+                    const int odd = (P + k) & 1;
+                    const int i0 = (P + k + 1) / 2 - P;
+                    const float fyk = odd ? 0.25f : 0.75f, wy0 = 1.0f - fyk;
+                    sE[k] = fma3(hrE[i0 + 1], fyk, hrE[i0] * wy0);
+                    sO[k] = fma3(hrO[i0 + 1], fyk, hrO[i0] * wy0);
+                }
+            };
+            if (first & 1) blend(std::integral_constant<int, 1>{}); else blend(std::integral_constant<int, 0>{});
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER_T; k++) {
+                const int jj = clampi(first + k, 0, oh - 1);
+                int ay0, ay1; float fy;
+                tap1d<M_UP>(jj, ih, ay0, ay1, fy);
+                pair_tap_up(in, iw, cm, c0, cp, ay0, ay1, fy, sE[k], sO[k]);
+            }
+        }
+        if (DUAL) {
+#pragma unroll
+            for (int k = 0; k < PER_T; k++) {
+                const H4* row = reinterpret_cast<const H4*>(in2) + (size_t)clampi(first + k, 0, oh - 1) * ow;
+                upE[k] = row[sxe]; upO[k] = row[sxo];
+            }
+        }
+        if (has_halo) {
+            const int jj = clampi(first + hk, 0, oh - 1);
+            const int hp = (x0 >> 1) - 2 + hq;
+            int ay0, ay1; float fy;
+            tap1d<M_UP>(jj, ih, ay0, ay1, fy);
+            pair_tap_up(in, iw, clampi(hp - 1, 0, iw - 1), clampi(hp, 0, iw - 1), clampi(hp + 1, 0, iw - 1), ay0, ay1, fy, hE, hO);
+            if (DUAL) {
+                const H4* row = reinterpret_cast<const H4*>(in2) + (size_t)jj * ow;
+                hupE = row[clampi(x0 - 4 + 2 * hq, 0, ow - 1)]; hupO = row[clampi(x0 - 3 + 2 * hq, 0, ow - 1)];
+            }
+        }
+        float2 (*line)[NP] = sLine[0][wv];
+        float2 (*line2)[NP] = sLine[DUAL ? 1 : 0][wv];
+#pragma unroll
+        for (int k = 0; k < PER_T; k++) {
+            line[0][lane] = make_float2(sE[k].x, sO[k].x); line[1][lane] = make_float2(sE[k].y, sO[k].y); line[2][lane] = make_float2(sE[k].z, sO[k].z);
+            if (DUAL) {
+                line2[0][lane] = make_float2((float)upE[k].x, (float)upO[k].x); line2[1][lane] = make_float2((float)upE[k].y, (float)upO[k].y);
+                line2[2][lane] = make_float2((float)upE[k].z, (float)upO[k].z);
+            }
+            if (has_halo && hk == k) {
+                line[0][hq] = make_float2(hE.x, hO.x); line[1][hq] = make_float2(hE.y, hO.y); line[2][hq] = make_float2(hE.z, hO.z);
+                if (DUAL) {
+                    line2[0][hq] = make_float2((float)hupE.x, (float)hupO.x); line2[1][hq] = make_float2((float)hupE.y, (float)hupO.y);
+                    line2[2][hq] = make_float2((float)hupE.z, (float)hupO.z);
+                }
+            }
+            wave_sync();
+            V3 gE, gO;
+            gauss9_pair(line[0] + lane, gE.x, gO.x); gauss9_pair(line[1] + lane, gE.y, gO.y); gauss9_pair(line[2] + lane, gE.z, gO.z);
+            if (DUAL) {   // bloom_upsample_add: lower first, then upper
+                V3 uE, uO;
+                gauss9_pair(line2[0] + lane, uE.x, uO.x); gauss9_pair(line2[1] + lane, uE.y, uO.y); gauss9_pair(line2[2] + lane, uE.z, uO.z);
+                gE = gE + uE; gO = gO + uO;
+            }
+            wave_sync();
+            struct alignas(16) H8 { H4 a, b; } th;   // the H pass's fp16 store, both columns of the lane
+            th.a.x = to_half_rn(gE.x); th.a.y = to_half_rn(gE.y); th.a.z = to_half_rn(gE.z); th.a.w = alpha_t;
+            th.b.x = to_half_rn(gO.x); th.b.y = to_half_rn(gO.y); th.b.z = to_half_rn(gO.z); th.b.w = alpha_t;
+            *reinterpret_cast<H8*>(&sT[r0 + k][2 * lane]) = th;
+        }
+    }
+    __syncthreads();
+    // ---- V-gauss over a sliding window of the fp16 tile + tail
+    {
+        H4 win[PER_O + 8];
+#pragma unroll
+        for (int i = 0; i < PER_O + 8; i++) win[i] = sT[rbase + i][vc];
+#pragma unroll
+        for (int k = 0; k < PER_O; k++) {
+            const int y = y0 + rbase + k;
+            if (xv >= ow || y >= oh) continue;
+            V3 a3 = v3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int i = 0; i < 9; i++) a3 = fma3(h3f(win[k + i]), c_gauss[i], a3);
+            const F4 a = f4(a3.x, a3.y, a3.z, alpha_v);
+            if (TAIL == 0) {
+                store_h4(out + 4 * ((size_t)y * out_pitch + xv), a);
+            } else {
+                if (!(in_mx && y >= tr.my0 && y < tr.my1)) continue;
+                const half4v a0 = round_h4(a);   // A0 texel as the separate V pass would have stored it
+                const F4 s = h4f(hdr_in[k]);
+                H4 o;
+                o.x = to_half_rn(s.x + (float)a0.x); o.y = to_half_rn(s.y + (float)a0.y); o.z = to_half_rn(s.z + (float)a0.z); o.w = to_half_rn(s.w + (float)a0.w);
+                *reinterpret_cast<H4*>(out + 4 * ((size_t)(y - tr.by) * out_pitch + (xv - tr.bx))) = o;
+                if (TAIL == 2) {
+                    if (xv >= tr.hx0 && xv < tr.hx1 && y >= tr.hy0 && y < tr.hy1)
+                        atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.x, (float)o.y, (float)o.z, min_log, inv_range)], 1u);
+                }
+            }
+        }
+    }
+    if (tile + (int)gridDim.x < n_tiles) __syncthreads();   // the next tile overwrites sT
+    }
+    if (TAIL == 2) {
+        __syncthreads();
+        for (int i = t; i < PBR_HISTOGRAM_BINS; i += NT) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) sum += sh_hist[w2][i];
+            if (sum) atomicAdd(&hist[i], sum);
+        }
+    }
+}
+
 // rows a k_blur_h block pipelines: as many as keep >= ~2048 blocks (8 per CU) in the grid
 static int blur_h_rows(uint32_t ow, uint32_t oh) {
     const uint64_t row_blocks = (uint64_t)((ow + 255) / 256) * oh;
@@ -614,13 +823,25 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
     tr.mx0 = merge_rect ? (int)merge_rect[0] : 0; tr.my0 = merge_rect ? (int)merge_rect[1] : 0;
     tr.mx1 = merge_rect ? (int)(merge_rect[0] + merge_rect[2]) : (int)ow; tr.my1 = merge_rect ? (int)(merge_rect[1] + merge_rect[3]) : (int)oh;
     tr.bx = buf_origin ? (int)buf_origin[0] : 0; tr.by = buf_origin ? (int)buf_origin[1] : 0;
-    // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 (256) below
-    static const int forced = getenv("PBR_BLOOM_TILE") ? atoi(getenv("PBR_BLOOM_TILE")) : 0;
-    const bool big = forced ? forced == 32 : (uint64_t)((tr.mx1 + 63) / 64 - tr.mx0 / 64) * ((tr.my1 + 31) / 32 - tr.my0 / 32) >= 900;
     // histogram instance: ~1024 blocks that each walk the same number of tiles (an uneven split leaves the chip
     // half empty for the last round; one block per tile costs 256 contended global atomics per tile)
     static const int hist_blocks = getenv("PBR_BLOOM_HIST_BLOCKS") ? atoi(getenv("PBR_BLOOM_HIST_BLOCKS")) : 1024;
     auto even_blocks = [](int n_tiles) { const int per = (n_tiles + hist_blocks - 1) / hist_blocks; return (n_tiles + per - 1) / per; };
+    if constexpr (MODE == M_UP) {
+        // 2x-up levels big enough to fill the chip with 128 x 32 tiles: the two-columns-per-lane kernel (PBR_BLOOM_WIDE=0|1 forces)
+        static const int wide_forced = getenv("PBR_BLOOM_WIDE") ? atoi(getenv("PBR_BLOOM_WIDE")) : -1;
+        const int wtx0 = tr.mx0 / 128, wty0 = tr.my0 / 32;
+        const int wtiles_x = (tr.mx1 + 127) / 128 - wtx0, wn = wtiles_x * ((tr.my1 + 31) / 32 - wty0);
+        if (wide_forced >= 0 ? wide_forced == 1 : wn >= 400) {
+            tr.tx0 = wtx0; tr.ty0 = wty0;
+            hipLaunchKernelGGL((k_blur_up_wide<DUAL, TAIL, 32>), dim3(TAIL == 2 ? even_blocks(wn) : wn), dim3(512), 0, ctx->stream,
+                               in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, wtiles_x, wn, tr, min_log, inv_range, hist);
+            return launched(ctx, "k_blur_up_wide");
+        }
+    }
+    // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 (256) below
+    static const int forced = getenv("PBR_BLOOM_TILE") ? atoi(getenv("PBR_BLOOM_TILE")) : 0;
+    const bool big = forced ? forced == 32 : (uint64_t)((tr.mx1 + 63) / 64 - tr.mx0 / 64) * ((tr.my1 + 31) / 32 - tr.my0 / 32) >= 900;
     // tiles that intersect the merge rect (TAIL 0 has no rect: every tile of the level)
     const int th = big ? 32 : 16;
     tr.tx0 = tr.mx0 / 64; tr.ty0 = tr.my0 / th;

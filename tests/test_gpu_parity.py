@@ -736,6 +736,68 @@ def test_bloom_fused_exact_pyramid_bit_exact(ctx, orc, w, h):
     assert np.array_equal(to_np_half(hdr2).view(np.uint16), want.view(np.uint16))
 
 
+_WIDE_BLOOM = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import binding as orc
+from direct12pbrrenderer_amd import synth
+from direct12pbrrenderer_amd.api import PbrContext
+ctx = PbrContext(0)
+up = lambda a: ctx.upload(np.ascontiguousarray(a, dtype=np.float16).view(np.uint16)).view(torch.float16)
+down = lambda t: t.cpu().view(torch.int16).numpy().view(np.float16)
+for (w, h) in %r:
+    img = synth.hdr_noise_image(w, h, seed=w + h)
+    want = img.copy()
+    orc.bloom(want)
+    ca, cb = ctx.alloc_bloom_chain(w, h), ctx.alloc_bloom_chain(w, h)
+    hdr, hist = up(img), ctx.zeros((256,), torch.int32)
+    ctx.bloom_histogram(hdr, w, h, w, ca, cb, (0, 0, w, h), hist)
+    got = down(hdr)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), ("bloom+histogram", w, h, int((got.view(np.uint16) != want.view(np.uint16)).sum()))
+    ref = ctx.zeros((256,), torch.int32)
+    ctx.lum_histogram(hdr, w, h, w, ref)
+    assert np.array_equal(hist.cpu().numpy(), ref.cpu().numpy()), ("histogram", w, h)
+    hdr2 = up(img)
+    ctx.bloom(hdr2, w, h, w, ca, cb)
+    assert np.array_equal(down(hdr2).view(np.uint16), want.view(np.uint16)), ("bloom", w, h)
+    # a histogram rectangle that is not the frame
+    hdr3, hist3, ref3 = up(img), ctx.zeros((256,), torch.int32), ctx.zeros((256,), torch.int32)
+    rect = (w // 8, h // 16, w // 2 + 3, h // 2 + 1)
+    ctx.bloom_histogram(hdr3, w, h, w, ca, cb, rect, hist3)
+    ctx.sync()
+    sub = down(hdr3)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
+    ctx.lum_histogram(up(sub), rect[2], rect[3], rect[2], ref3)
+    assert np.array_equal(hist3.cpu().numpy(), ref3.cpu().numpy()), ("histogram rect", w, h)
+ctx.close()
+print("wide bloom ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("force,sizes", [
+    ("1", [(2048, 64), (1040, 48), (512, 288), (304, 176), (320, 180), (96, 32), (400, 304), (160, 2080)]),
+    ("0", [(512, 288), (2080, 1296)]),
+    ("", [(2080, 1296), (3328, 2048)]),
+])
+def test_bloom_wide_2x_up_kernel_bit_exact(force, sizes):
+    """k_blur_up_wide (128-wide tiles, two columns per lane; what 2x-up levels of >= 400 such tiles take) against the
+    oracle's staged chain, bit for bit: forced on at small and ragged sizes (every M_UP level of the pyramid then runs
+    it: widths below one tile, widths that are no multiple of 128, a 5-texel-wide level, image edges inside the first
+    and last rows of waves), forced off (k_blur_hv at a size that would pick it), and chosen by the threshold —
+    2080x1296: the final level only; 3328x2048: level 1 (DUAL instance) as well.  The switch is read once per process,
+    hence the child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("PBR_BLOOM_WIDE", None)
+    if force:
+        env["PBR_BLOOM_WIDE"] = force
+    r = subprocess.run(["timeout", "-k", "10", "500", sys.executable, "-c", _WIDE_BLOOM % (root, os.path.join(root, "tests"), sizes)],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "wide bloom ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
 @pytest.mark.gpu
 def test_deferred_shade_attenuation_floor_and_odd_lists(ctx, orc, ibl):
     """Lights whose attenuation polynomial can drop below the shader's 1e-6 floor (C0 = 0: the floor binds near the
