@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void k_blur_v(const pbr_half* __restrict__ in,
 __device__ __forceinline__ uint32_t luminance_bin_exact(float r, float g, float b, float min_log, float inv_range) {
     const float lum = (r * 0.2126f + g * 0.7152f) + b * 0.0722f;
     if (lum < EPSILON_F) return 0u;
-    const float l = saturatef((log2f(lum) - min_log) * inv_range);
+    // lum >= 1e-6 is a normal number: log2f's subnormal pre-scaling never applies, so the bare v_log_f32 it wraps gives the same bits
+    const float l = saturatef((__builtin_amdgcn_logf(lum) - min_log) * inv_range);
     return (uint32_t)floorf(l * 254.0f + 1.0f);
 }
 
@@ -364,6 +365,14 @@ __device__ __forceinline__ float4 finish_tap2(const Tap2& t, float fx, float fy)
 }
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+// two to_half_rn in one v_cvt_pk_f16_f32 (same rounding); the halves are read back out of the packed register
+__device__ __forceinline__ half2v round_h2(float a, float b) {
+    asm volatile("" : "+v"(a), "+v"(b));
+    float2v f; f.x = a; f.y = b;
+    return __builtin_convertvector(f, half2v);
+}
 __device__ __forceinline__ half4v round_h4(F4 v) {
     half4v r;
     r.x = to_half_rn(v.x); r.y = to_half_rn(v.y); r.z = to_half_rn(v.z); r.w = to_half_rn(v.w);
@@ -620,6 +629,15 @@ __device__ __forceinline__ void gauss9_pair(const float2* e, float& ge, float& g
     ge = a; go = b;
 }
 
+#ifdef PBR_BLOOM_TIMING   // experiment only (-DPBR_BLOOM_TIMING=<n>, tools/debug/tail_timing.py): shader-clock stamps of wave 0 of every block's n-th tile
+__device__ unsigned long long g_tail_stamp[8 * 4096];
+#define TSTAMP(i) do { if (TAIL == 2 && t == 0 && tile == (int)blockIdx.x + PBR_BLOOM_TIMING * (int)gridDim.x && blockIdx.x < 4096) g_tail_stamp[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define TWAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+extern "C" int pbr_debug_tail_stamps(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tail_stamp), sizeof(unsigned long long) * n); }
+#else
+#define TSTAMP(i) do {} while (0)
+#define TWAIT_VM() do {} while (0)
+#endif
 template <bool DUAL, int TAIL, int TH>
 __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restrict__ in, int iw, int ih,
                                                           const pbr_half* __restrict__ in2,   // DUAL: ow x oh, same-size
@@ -644,6 +662,7 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
     if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[0].w);
     const h16 alpha_t = to_half_rn(alpha_h);
     const float alpha_v = gauss9_const((float)alpha_t);
+    const float a0w = (float)to_half_rn(alpha_v);   // alpha of the A0 texel the separate V pass would have stored
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -652,15 +671,11 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int x0 = (TAIL != 0 ? tr.tx0 + tile % tiles_x : tile % tiles_x) * TW, y0 = (TAIL != 0 ? tr.ty0 + tile / tiles_x : tile / tiles_x) * TH;
     const int xv = x0 + vc, rbase = vg * PER_O;
+    TSTAMP(0);
     H4 hdr_in[PER_O];
     const bool in_mx = TAIL != 0 && xv >= tr.mx0 && xv < tr.mx1;
-    if (TAIL != 0) {
-#pragma unroll
-        for (int k = 0; k < PER_O; k++) {
-            const int y = y0 + rbase + k;
-            if (in_mx && y >= tr.my0 && y < tr.my1) hdr_in[k] = *reinterpret_cast<const H4*>(out + 4 * ((size_t)(y - tr.by) * out_pitch + (xv - tr.bx)));
-        }
-    }
+    // this thread's first HDR texel (dereferenced only inside the merge rect); rows follow at out_pitch
+    H4* const hdr_px = reinterpret_cast<H4*>(out) + ((ptrdiff_t)(y0 + rbase - tr.by) * out_pitch + (xv - tr.bx));
     // sample positions: columns x0-4 .. x0+131 = pair entries 0..67 (entry q = level texel pair index x0/2 - 2 + q),
     // rows clamp(y0-4+r).  Main entry of a row: q = lane; the four halo entries 64..67 of the wave's PER_T rows are one
     // extra tap: lane -> (row lane / 4, entry 64 + lane % 4).
@@ -724,6 +739,18 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
                 hupE = row[clampi(x0 - 4 + 2 * hq, 0, ow - 1)]; hupO = row[clampi(x0 - 3 + 2 * hq, 0, ow - 1)];
             }
         }
+        // the HDR texels of the merge: issued AFTER the level's texels (loads return in order, and the samples below wait
+        // for the level's only), consumed after the H pass
+        if (TAIL != 0) {
+#pragma unroll
+            for (int k = 0; k < PER_O; k++) {
+                const int y = y0 + rbase + k;
+                if (in_mx && y >= tr.my0 && y < tr.my1) hdr_in[k] = hdr_px[(ptrdiff_t)k * out_pitch];
+            }
+        }
+        TSTAMP(1);
+        TWAIT_VM();
+        TSTAMP(2);
         float2 (*line)[NP] = sLine[0][wv];
         float2 (*line2)[NP] = sLine[DUAL ? 1 : 0][wv];
 #pragma unroll
@@ -755,7 +782,9 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
             *reinterpret_cast<H8*>(&sT[r0 + k][2 * lane]) = th;
         }
     }
+    TSTAMP(3);
     __syncthreads();
+    TSTAMP(4);
     // ---- V-gauss over a sliding window of the fp16 tile + tail
     {
         H4 win[PER_O + 8];
@@ -773,19 +802,24 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
                 store_h4(out + 4 * ((size_t)y * out_pitch + xv), a);
             } else {
                 if (!(in_mx && y >= tr.my0 && y < tr.my1)) continue;
-                const half4v a0 = round_h4(a);   // A0 texel as the separate V pass would have stored it
+                // A0 texel as the separate V pass would have stored it (fp16), then the merge's fp16 sum
+                const half2v a01 = round_h2(a3.x, a3.y);
+                const h16 a2 = to_half_rn(a3.z);
                 const F4 s = h4f(hdr_in[k]);
-                H4 o;
-                o.x = to_half_rn(s.x + (float)a0.x); o.y = to_half_rn(s.y + (float)a0.y); o.z = to_half_rn(s.z + (float)a0.z); o.w = to_half_rn(s.w + (float)a0.w);
-                *reinterpret_cast<H4*>(out + 4 * ((size_t)(y - tr.by) * out_pitch + (xv - tr.bx))) = o;
+                struct alignas(8) O4 { half2v lo, hi; } o;
+                o.lo = round_h2(s.x + (float)a01.x, s.y + (float)a01.y);
+                o.hi = round_h2(s.z + (float)a2, s.w + a0w);
+                *reinterpret_cast<O4*>(hdr_px + (ptrdiff_t)k * out_pitch) = o;
                 if (TAIL == 2) {
                     if (xv >= tr.hx0 && xv < tr.hx1 && y >= tr.hy0 && y < tr.hy1)
-                        atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.x, (float)o.y, (float)o.z, min_log, inv_range)], 1u);
+                        atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.lo.x, (float)o.lo.y, (float)o.hi.x, min_log, inv_range)], 1u);
                 }
             }
         }
     }
+    TSTAMP(5);
     if (tile + (int)gridDim.x < n_tiles) __syncthreads();   // the next tile overwrites sT
+    TSTAMP(6);
     }
     if (TAIL == 2) {
         __syncthreads();
