@@ -810,7 +810,7 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
                 o.lo = round_h2(s.x + (float)a01.x, s.y + (float)a01.y);
                 o.hi = round_h2(s.z + (float)a2, s.w + a0w);
                 *reinterpret_cast<O4*>(hdr_px + (ptrdiff_t)k * out_pitch) = o;
-                if (TAIL == 2) {
+                if (TAIL == 2) {   // plain per-lane LDS atomics: wave-aggregating equal bins first (exposure.hip) costs more VALU here than it saves
                     if (xv >= tr.hx0 && xv < tr.hx1 && y >= tr.hy0 && y < tr.hy1)
                         atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.lo.x, (float)o.lo.y, (float)o.hi.x, min_log, inv_range)], 1u);
                 }

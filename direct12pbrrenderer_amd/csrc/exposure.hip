@@ -22,38 +22,56 @@ __device__ __forceinline__ uint32_t luminance_bin(float r, float g, float b, flo
     return (uint32_t)floorf(l * 254.0f + 1.0f);
 }
 
-constexpr int HIST_BLOCKS = 1024;
+// Few, large blocks: every block ends with up to 256 global atomics on the same 256 addresses, which the L2 serialises
+// per address — with 1024 blocks of 256 threads that flush, not the 66 MB read, set the kernel's time (31 us at 4K).
+constexpr int HIST_BLOCKS = 512, HIST_NT = 1024, HIST_NW = HIST_NT / 64;
 
-__global__ __launch_bounds__(256) void k_lum_histogram(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
-                                                         float min_log, float inv_range, uint32_t* __restrict__ hist, bool vec2) {
-    __shared__ uint32_t sh[4][PBR_HISTOGRAM_BINS];
+__global__ __launch_bounds__(HIST_NT) void k_lum_histogram(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                                             float min_log, float inv_range, uint32_t* __restrict__ hist, bool vec2) {
+    __shared__ uint32_t sh[HIST_NW][PBR_HISTOGRAM_BINS];
     const int wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4 * PBR_HISTOGRAM_BINS; i += 256) (&sh[0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < HIST_NW * PBR_HISTOGRAM_BINS; i += HIST_NT) (&sh[0][0])[i] = 0u;
     __syncthreads();
     uint32_t* my = sh[wave];
+    // Work unit = one 256-lane segment of a row; a block takes four at a time (one per 256-thread group), grid-stride.  The
+    // row / segment split is one group-uniform 32-bit division per unit (a per-pixel 64-bit t / w cost more than the binning).
+    const uint32_t group = threadIdx.x >> 8, gl = threadIdx.x & 255u, stride = gridDim.x * 4u;
     // vec2 (host-checked): base 16-byte aligned, w and pitch even -> rows are whole 16-byte pixel pairs
     if (vec2) {
-        const uint32_t wp = w >> 1;
-        const size_t n = (size_t)wp * h;
-        for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
-            const uint32_t y = (uint32_t)(t / wp), xp = (uint32_t)(t % wp);
-            const uint4 raw = *reinterpret_cast<const uint4*>(hdr + 4 * ((size_t)y * pitch + 2 * xp));
-            const H4 p0 = *reinterpret_cast<const H4*>(&raw.x);
-            const H4 p1 = *reinterpret_cast<const H4*>(&raw.z);
-            atomicAdd(&my[luminance_bin((float)p0.x, (float)p0.y, (float)p0.z, min_log, inv_range)], 1u);
-            atomicAdd(&my[luminance_bin((float)p1.x, (float)p1.y, (float)p1.z, min_log, inv_range)], 1u);
+        // two units per trip: both 16-byte loads are in flight before either is binned
+        const uint32_t wp = w >> 1, upr = (wp + 255u) >> 8, units = upr * h;
+        for (uint32_t u = blockIdx.x * 4u + group; u < units; u += 2 * stride) {
+            const uint32_t u2 = u + stride;
+            const uint32_t ya = u / upr, xa = (u - ya * upr) * 256u + gl;
+            const uint32_t yb = u2 / upr, xb = (u2 - yb * upr) * 256u + gl;
+            const bool ina = xa < wp, inb = u2 < units && xb < wp;
+            uint4 ra = make_uint4(0u, 0u, 0u, 0u), rb = ra;
+            if (ina) ra = *reinterpret_cast<const uint4*>(hdr + 4 * ((size_t)ya * pitch + 2 * xa));
+            if (inb) rb = *reinterpret_cast<const uint4*>(hdr + 4 * ((size_t)yb * pitch + 2 * xb));
+            const H4 p0 = *reinterpret_cast<const H4*>(&ra.x), p1 = *reinterpret_cast<const H4*>(&ra.z);
+            const H4 p2 = *reinterpret_cast<const H4*>(&rb.x), p3 = *reinterpret_cast<const H4*>(&rb.z);
+            hist_count(my, luminance_bin((float)p0.x, (float)p0.y, (float)p0.z, min_log, inv_range), ina);
+            hist_count(my, luminance_bin((float)p1.x, (float)p1.y, (float)p1.z, min_log, inv_range), ina);
+            hist_count(my, luminance_bin((float)p2.x, (float)p2.y, (float)p2.z, min_log, inv_range), inb);
+            hist_count(my, luminance_bin((float)p3.x, (float)p3.y, (float)p3.z, min_log, inv_range), inb);
         }
     } else {
-        const size_t n = (size_t)w * h;
-        for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
-            const uint32_t y = (uint32_t)(t / w), x = (uint32_t)(t % w);
-            const F4 c = load_h4(hdr + 4 * ((size_t)y * pitch + x));
-            atomicAdd(&my[luminance_bin(c.x, c.y, c.z, min_log, inv_range)], 1u);
+        const uint32_t upr = (w + 255u) >> 8, units = upr * h;
+        for (uint32_t u = blockIdx.x * 4u + group; u < units; u += stride) {
+            const uint32_t y = u / upr, x = (u - y * upr) * 256u + gl;
+            const bool in = x < w;
+            F4 c = f4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (in) c = load_h4(hdr + 4 * ((size_t)y * pitch + x));
+            hist_count(my, luminance_bin(c.x, c.y, c.z, min_log, inv_range), in);
         }
     }
     __syncthreads();
-    const uint32_t s = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-    if (s) atomicAdd(&hist[threadIdx.x], s);
+    if (threadIdx.x < PBR_HISTOGRAM_BINS) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < HIST_NW; k++) s += sh[k][threadIdx.x];
+        if (s) atomicAdd(&hist[threadIdx.x], s);
+    }
 }
 
 // hdr_average_histogram.hlsl:26-73 — one 256-thread group, the same LDS tree (fixed fp32 order).
@@ -117,9 +135,12 @@ __device__ __forceinline__ void tonemap_pixels(const pbr_half* __restrict__ hdr,
     const float l_max = 9.6f * avg_lum;
     const float inv_den = 1.0f / (l_max + 0.001f);
     const uint32_t wp = (w + 1) >> 1;   // pixel pairs per row
-    const size_t n = (size_t)wp * h;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
-        const uint32_t y = (uint32_t)(t / wp), x = (uint32_t)(t % wp) * 2;
+    // work unit = one 256-lane segment of a row (one wave-uniform 32-bit division per unit, none per pixel)
+    const uint32_t upr = (wp + 255u) >> 8, units = upr * h;
+    for (uint32_t u = blockIdx.x; u < units; u += gridDim.x) {
+        const uint32_t y = u / upr, xp = (u - y * upr) * 256u + threadIdx.x;
+        if (xp >= wp) continue;
+        const uint32_t x = xp * 2;
         if (aligned && x + 1 < w) {
             const uint4 raw = *reinterpret_cast<const uint4*>(hdr + 4 * ((size_t)y * pitch + x));
             const H4 p0 = *reinterpret_cast<const H4*>(&raw.x);
@@ -149,12 +170,13 @@ pbr_status pbr_lum_histogram(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, hdr && hist256, "pbr_lum_histogram: null pointer");
     PBR_REQUIRE(ctx, w && h && w <= 65535 && h <= 65535 && pitch >= w, "pbr_lum_histogram: bad size");
+    static const int max_blocks = getenv("PBR_HIST_BLOCKS") ? atoi(getenv("PBR_HIST_BLOCKS")) : HIST_BLOCKS;   // sweep switch
     size_t n = (size_t)w * h;
-    int blocks = (int)((n + 511) / 512);
-    if (blocks > HIST_BLOCKS) blocks = HIST_BLOCKS;
+    int blocks = (int)((n + 4095) / 4096);   // >= two trips of a block's four 256-pair segments
+    if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     const bool vec2 = (((uintptr_t)hdr & 15u) == 0u) && (((w | pitch) & 1u) == 0u);
-    hipLaunchKernelGGL(k_lum_histogram, dim3(blocks), dim3(256), 0, ctx->stream, hdr, w, h, pitch, min_log, inv_range, hist256, vec2);
+    hipLaunchKernelGGL(k_lum_histogram, dim3(blocks), dim3(HIST_NT), 0, ctx->stream, hdr, w, h, pitch, min_log, inv_range, hist256, vec2);
     return launched(ctx, "k_lum_histogram");
 }
 

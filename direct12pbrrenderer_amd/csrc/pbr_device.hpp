@@ -244,4 +244,24 @@ __device__ __forceinline__ float luminance(float r, float g, float b) {   // glo
     return r * 0.2126f + g * 0.7152f + b * 0.0722f;
 }
 
+// ---- one histogram count per active lane into a per-wave LDS histogram ---------------------------------------------
+// LDS atomics of one wave on the SAME address serialise (up to 64 deep), and neighbouring pixels of a rendered frame
+// mostly fall into the same few luminance bins.  Two rounds of leader aggregation first: the lowest pending lane's
+// bin is broadcast, every lane with that bin is counted by ballot and the leader adds the popcount once; lanes still
+// pending afterwards (noise-like content) add their own 1.  Same counts, whatever the content.
+__device__ __forceinline__ void hist_count(uint32_t* wave_hist, uint32_t bin, bool valid) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned long long todo = __ballot(valid);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (todo == 0ull) return;   // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long m = __ballot(valid && bin == b) & todo;
+        if ((int)lane == leader) atomicAdd(&wave_hist[b], (uint32_t)__popcll(m));
+        todo &= ~m;
+    }
+    if (valid && ((todo >> lane) & 1ull)) atomicAdd(&wave_hist[bin], 1u);
+}
+
 }  // namespace pbr
