@@ -1,4 +1,4 @@
-tag=r02_i
+tag=${1:-r02_l}
 bash tools/collect_profiles.sh $tag > gpurun_out/collect_$tag.log 2>&1; rc=$?
 tail -n 5 gpurun_out/collect_$tag.log
 [ $rc -eq 0 ] || exit $rc
