@@ -105,8 +105,9 @@ def _worker(rank, world, port, outdir, layout, halo, tile_w, tile_h):
 
 # world 3: the middle rank carries an apron on both sides; world 4 = 2x2: aprons on two axes incl. the corner
 # (BASELINE cfg5 cuts its 8K frame 2x4 the same way); halo: level-1 strips from the neighbours instead of a shaded apron
+# world 8 = 2 rows x 4 cols: the BASELINE cfg5 layout itself (inner columns have neighbours on three sides + two corners), halo mode
 CASES = [(2, None, False, 512, 64), (3, None, False, 512, 64), (4, (2, 2), False, 320, 272), (4, (2, 2), True, 320, 272),
-         (2, None, True, 512, 64)]
+         (2, None, True, 512, 64), (8, (2, 4), True, 272, 272)]
 
 
 @pytest.mark.timeout(900)
