@@ -26,8 +26,10 @@ n = 8 * 1020
 buf = (ctypes.c_ulonglong * n)()
 assert lib.pbr_debug_tail_stamps(buf, n) == 0
 a = np.array(buf, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+a = a[(a[:, 0] > 0) & (a[:, 6] > a[:, 0])]          # blocks that stamped
+names = ["0 tile start", "1 loads issued, samples computed", "2 all global loads arrived", "3 H pass done", "4 barrier passed",
+         "5 V pass + merge + histogram done", "6 end-of-tile barrier passed"]
 d = np.diff(a[:, :7], axis=1)
-print("blocks", len(a), "mean cycles per interval 0-1 .. 5-6:", d.mean(axis=0).round(0), "total", (a[:, 6] - a[:, 0]).mean().round(0))
-print("median:", np.median(d, axis=0), "p90:", np.percentile(d, 90, axis=0))
-start = a[:, 0] - a[:, 0].min()
-print("block start spread: median", np.median(start), "max", start.max(), "end max", (a[:, 6] - a[:, 0].min()).max())
+print("blocks", len(a), "total cycles per tile: mean", (a[:, 6] - a[:, 0]).mean().round(0), "median", np.median(a[:, 6] - a[:, 0]))
+for i in range(6):
+    print(f"  {names[i]:36s} -> {names[i + 1][:1]}: mean {d[:, i].mean():8.0f}  median {np.median(d[:, i]):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f}")
