@@ -183,7 +183,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // ViewSpaceDepth :74-77, ReconstructWorldPosition :79-83
         z_vs = view_space_depth(depth_ndc, p.Near, p.Far);
         const V3 cam = v3(p.CameraPos[0], p.CameraPos[1], p.CameraPos[2]);
-        const float zs = z_vs / p.Near;
+        const float zs = z_vs * rcp(p.Near);   // v_rcp (1 ulp) instead of an IEEE divide sequence: the position is continuous in it (the slice index below is not, and keeps its divides)
         pos = v3(cam.x + camera_vec.x * zs, cam.y + camera_vec.y * zs, cam.z + camera_vec.z * zs);
         view = normalize3(cam - pos);
     }
@@ -212,7 +212,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         const float a4m1 = ra * ra - 1.0f;
         const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
         const float one_k = 1.0f - k;
-        const float inv_ndv4 = 1.0f / (4.0f * NdotV);   // +inf at NdotV = 0: min() then picks 1e4 NdotL, as the shader's floor does
+        const float inv_ndv4 = rcp(4.0f * NdotV);   // +inf at NdotV = 0: min() then picks 1e4 NdotL, as the shader's floor does
         const float t_floor = EPSILON_F * INV_PI_F;
         // Instruction budget of the loop, from the measured issue costs (tools/valu_rate3.hip -> profiles/r02_valu_rate3.txt,
         // 5 waves per SIMD, cycles per wave-instruction per SIMD): v_pk_{fma,mul,add}_f32 4.7 (two lights per instruction),
@@ -306,7 +306,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     {
         const float ra = roughness * roughness;
         const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
-        const float gv = NdotV / fmaxf(NdotV * (1.0f - k) + k, EPSILON_F);
+        const float gv = NdotV * rcp(fmaxf(NdotV * (1.0f - k) + k, EPSILON_F));
         const float spec_pix = ra * ra * INV_PI_F * gv;
         const float kd = (1.0f - metallic) * INV_PI_F;   // Kd*albedo/pi = (1-F0)(1-m) albedo/pi * (1-f5)
         out.x = (1.0f - F0.x) * (kd * albedo.x * s1x + spec_pix * s3x) + F0.x * spec_pix * s2x;
@@ -343,11 +343,13 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         uint32_t face;
         float cu, cv;
         {
-            const float ax = fabsf(R.x), ay = fabsf(R.y), az = fabsf(R.z);
-            float sc, tc, ma;
-            if (ax >= ay && ax >= az) { ma = ax; face = R.x >= 0.0f ? 0u : 1u; sc = R.x >= 0.0f ? -R.z : R.z; tc = -R.y; }
-            else if (ay >= az)        { ma = ay; face = R.y >= 0.0f ? 2u : 3u; sc = R.x; tc = R.y >= 0.0f ? R.z : -R.z; }
-            else                      { ma = az; face = R.z >= 0.0f ? 4u : 5u; sc = R.z >= 0.0f ? R.x : -R.x; tc = -R.y; }
+            // the cube-map coordinate instructions (v_cubeid / v_cubesc / v_cubetc / v_cubema: D3D face order and (sc, tc)
+            // table; ma = 2 x the signed major axis): 4 instructions for the three-way compare-and-select.  On an exact tie
+            // of two |components| they pick z, then y, then x where the shader's HLSL picks x, then y, then z — the same
+            // point on the shared edge of two faces, which the seamless footprints filter alike.
+            const float ma = 0.5f * fabsf(__builtin_amdgcn_cubema(R.x, R.y, R.z));
+            const float sc = __builtin_amdgcn_cubesc(R.x, R.y, R.z), tc = __builtin_amdgcn_cubetc(R.x, R.y, R.z);
+            face = (uint32_t)__builtin_amdgcn_cubeid(R.x, R.y, R.z);
             const float inv = rcp(ma);
             cu = (sc * inv + 1.0f) * 0.5f;
             cv = (tc * inv + 1.0f) * 0.5f;
