@@ -27,6 +27,7 @@ struct ShadeParams {
     float Near, Far;
     float near_width, near_height;   // 2 Near tan(Fov/2) [* Ratio]  (vs_main :94-95), host libm
     float log_far_near;              // log(Far/Near) of ClusterIndex (clustered.hlsli:53), host libm
+    float inv_near, slice_k;         // 1 / Near and PBR_CLUSTER_Z / log2(Far/Near) (host, from double): the slice index's quick estimate
     uint32_t x0, y0, w, h, full_w, full_h;
     const uint32_t* A;
     const uint32_t* B;
@@ -197,7 +198,16 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         int sx = (int)floorf(u * (float)PBR_CLUSTER_X);
         int sy = (int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y);
         const float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
-        int sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
+        // Slice index = (int)(Z * logf(zc / Near) / log(Far / Near)), a discontinuous function of the depth: its value must be the
+        // shader's / the oracle's to the bit, which takes two IEEE divides and a full-precision logf (~45 instructions).  A quick
+        // estimate t = slice_k * v_log_f32(zc * inv_near) is within 5e-6 of that expression's real value (1-ulp log2 of
+        // magnitude <= ~14, two rounded constants), and so is the exact sequence's own result: wherever t is further than 1e-4
+        // from an integer both truncate alike.  Only waves with a lane inside that band (2e-4 of the pixels) run the sequence.
+        const float t_quick = p.slice_k * __builtin_amdgcn_logf(zc * p.inv_near);
+        const float t_frac = t_quick - floorf(t_quick);
+        int sz = (int)t_quick;
+        if (__any(!(t_frac > 1.0e-4f && t_frac < 1.0f - 1.0e-4f)))
+            sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
         sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
         sy = clampi(sy, 0, PBR_CLUSTER_Y - 1);
         sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
@@ -528,6 +538,8 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     p.near_height = 2.0f * g->Near * tanf(g->Fov / 2.0f);
     p.near_width = p.near_height * g->Ratio;
     p.log_far_near = logf(g->Far / g->Near);
+    p.inv_near = (float)(1.0 / (double)g->Near);
+    p.slice_k = (float)((double)PBR_CLUSTER_Z / log2((double)g->Far / (double)g->Near));
     p.x0 = tile->x0; p.y0 = tile->y0; p.w = tile->w; p.h = tile->h; p.full_w = tile->full_w; p.full_h = tile->full_h;
     p.A = gb->A; p.B = gb->B; p.C = gb->C; p.depth = gb->depth; p.stencil = gb->stencil; p.pitch = gb->pitch;
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;

@@ -316,3 +316,27 @@ def test_ring_core_split_of_the_overlapped_halo_frame():
     small = Stub()
     small.spec = tile_for_rank(0, 4, 384, 288, layout=(2, 2), halo=True)
     assert pipeline.DeferredFrame._ring_core_split(small) is None      # too small to split: plain sequence
+
+
+def test_quick_slice_estimate_agrees_with_the_exact_index_outside_its_band():
+    """csrc/shade.hip takes the cluster z-slice from t = slice_k * v_log_f32(zc * inv_near) wherever t is further than 1e-4
+    from an integer, and from the shader's expression (int)(Z * logf(zc / Near) / log(Far / Near)) otherwise.  Numeric model of
+    that rule in fp32 (hardware log2 modelled as the correctly rounded value +/- 1 ulp): no depth outside the band — random
+    ones and ones within a few ppm of every slice boundary — may truncate differently; the two values stay within 1e-5."""
+    import numpy as np
+    f32 = np.float32
+    rng = np.random.default_rng(0x511CE)
+    for near, far in [(0.1, 1000.0), (0.01, 10000.0), (1.0, 100.0), (0.5, 1.0), (0.001, 100000.0)]:
+        n = 400_000
+        zb = near * (far / near) ** (rng.integers(0, 25, n) / 24.0)
+        z = np.concatenate([zb * (1 + rng.normal(0, 3e-6, n)), near * (far / near) ** rng.random(n)]).astype(f32)
+        zc = np.minimum(np.maximum(z, f32(near)), f32(far))
+        exact = (f32(24.0) * np.log((zc / f32(near)).astype(f32)).astype(f32) / f32(np.log(f32(far) / f32(near)))).astype(f32)
+        inv_near, slice_k = f32(1.0 / float(f32(near))), f32(24.0 / np.log2(float(f32(far)) / float(f32(near))))
+        l2 = np.log2((zc * inv_near).astype(f32).astype(np.float64)).astype(f32)
+        for l2p in (l2, np.nextafter(l2, f32(np.inf)), np.nextafter(l2, f32(-np.inf))):
+            t = (slice_k * l2p).astype(f32)
+            fr = t - np.floor(t)
+            outside = (fr > 1e-4) & (fr < 1 - 1e-4)
+            assert not (outside & (np.trunc(t) != np.trunc(exact))).any()
+            assert np.abs(t.astype(np.float64) - exact.astype(np.float64)).max() < 1e-5
