@@ -161,21 +161,22 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 //   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint16_t* lists, const uint32_t* mip_off,
-                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, bool q_safe, uint32_t px, uint32_t py) {
+                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, bool q_safe, uint32_t px, uint32_t py, float4 row) {
     const size_t gi = (size_t)py * p.pitch + px;
     if (p.stencil[gi] == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
     const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
 
     // ---- phase 1: geometry (vs_main :91-121, screen triangle D3D12Device.cpp:167-176; uv from the GLOBAL pixel)
     const float u = ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
-    const float v = ((float)(p.y0 + py) + 0.5f) / (float)p.full_h;
+    // v, cvv.y and the cluster row depend on the pixel ROW only: evaluated once per block row (k_deferred_shade, the same
+    // expressions) and handed in as row = {v, cvv.y, cluster row} — an IEEE divide, a floor and their neighbours less per pixel
     V3 pos, view, n;
     float z_vs, roughness;
     {
         const uint32_t b = p.B[gi], c = p.C[gi];
         const float depth_ndc = p.depth[gi];
-        const float ndc_x = 2.0f * u - 1.0f, ndc_y = 1.0f - 2.0f * v;
-        const V3 cvv = v3(ndc_x * 0.5f * p.near_width, ndc_y * 0.5f * p.near_height, p.Near);
+        const float ndc_x = 2.0f * u - 1.0f;
+        const V3 cvv = v3(ndc_x * 0.5f * p.near_width, row.y, p.Near);
         const V3 camera_vec = v3(p.InvView[0] * cvv.x + p.InvView[1] * cvv.y + p.InvView[2] * cvv.z,
                                  p.InvView[3] * cvv.x + p.InvView[4] * cvv.y + p.InvView[5] * cvv.z,
                                  p.InvView[6] * cvv.x + p.InvView[7] * cvv.y + p.InvView[8] * cvv.z);
@@ -184,7 +185,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // ViewSpaceDepth :74-77, ReconstructWorldPosition :79-83
         z_vs = view_space_depth(depth_ndc, p.Near, p.Far);
         const V3 cam = v3(p.CameraPos[0], p.CameraPos[1], p.CameraPos[2]);
-        const float zs = z_vs * rcp(p.Near);   // v_rcp (1 ulp) instead of an IEEE divide sequence: the position is continuous in it (the slice index below is not, and keeps its divides)
+        const float zs = z_vs * p.inv_near;   // not an IEEE divide: the position is continuous in it (the slice index below is not, and keeps its divides)
         pos = v3(cam.x + camera_vec.x * zs, cam.y + camera_vec.y * zs, cam.z + camera_vec.z * zs);
         view = normalize3(cam - pos);
     }
@@ -196,7 +197,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     float s1x = 0.0f, s1y = 0.0f, s1z = 0.0f, s2x = 0.0f, s2y = 0.0f, s2z = 0.0f, s3x = 0.0f, s3y = 0.0f, s3z = 0.0f;
     if (n_lights > 0) {
         int sx = (int)floorf(u * (float)PBR_CLUSTER_X);
-        int sy = (int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y);
+        int sy = (int)row.z;
         const float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
         // Slice index = (int)(Z * logf(zc / Near) / log(Far / Near)), a discontinuous function of the depth: its value must be the
         // shader's / the oracle's to the bit, which takes two IEEE divides and a full-precision logf (~45 instructions).  A quick
@@ -209,7 +210,6 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         if (__any(!(t_frac > 1.0e-4f && t_frac < 1.0f - 1.0e-4f)))
             sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
         sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
-        sy = clampi(sy, 0, PBR_CLUSTER_Y - 1);
         sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
         // brdf() (brdf.hlsli:47-67) with D, G, the 4 NdotL NdotV denominator AND the attenuation under ONE reciprocal:
         //   D G / max(4 NdotL NdotV, 1e-4) = [a^2/pi * gV] * gl / (T * A),   a = roughness^2 (the shader's `a * a`),
@@ -387,11 +387,17 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         const V3 envc = v3(ea.x * w0 + eb.x * env_f, ea.y * w0 + eb.y * env_f, ea.z * w0 + eb.z * env_f);
         // LUT bilinear with clamp addressing (Q5): one 8-byte pair per row; at the borders both taps are
         // the same texel, picked out of the pair that stays inside the row
+        // Both coordinates lie in [0, 1] (UNORM8 roughness, clamped N.V): no NaN / range guard; x.8 fixed-point snap as in
+        // pbr_device.hpp::bilinear_coord.  The row pair (xb, xb + 1) always lies inside the row; where the sampler's clamp makes
+        // both taps the SAME texel (the first / last half texel) the weight is moved onto it (0 or 1) instead of selecting texels.
         const int lr = (int)p.lut_res;
-        const BilinearCoord cx = bilinear_coord(roughness, lr), cy = bilinear_coord(NdotV, lr);
-        const int x0 = clampi(cx.i0, 0, lr - 1), x1 = clampi(cx.i1, 0, lr - 1);
-        const int y0 = clampi(cy.i0, 0, lr - 1), y1 = clampi(cy.i1, 0, lr - 1);
-        const int xb = lr > 1 ? min(x0, lr - 2) : 0;
+        const float lrf = (float)lr;
+        const float xs = snap8(roughness * lrf) - 0.5f, ys = snap8(NdotV * lrf) - 0.5f;
+        const float xfl = floorf(xs), yfl = floorf(ys);
+        const int xi = (int)xfl, yi = (int)yfl;
+        const int y0 = clampi(yi, 0, lr - 1), y1 = clampi(yi + 1, 0, lr - 1);
+        const int xb = clampi(xi, 0, max(lr - 2, 0));
+        const float fx = xi < 0 ? 0.0f : (xi > lr - 2 ? 1.0f : xs - xfl), fy = ys - yfl;
         const H2* lut = reinterpret_cast<const H2*>(p.lut);
         H2x2 lt0, lt1;
         if (lr > 1) {
@@ -401,11 +407,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             lt0.a = lt0.b = lut[0];
             lt1 = lt0;
         }
-        const H2 l00 = x0 != xb ? lt0.b : lt0.a, l10 = x1 != xb ? lt0.b : lt0.a;
-        const H2 l01 = x0 != xb ? lt1.b : lt1.a, l11 = x1 != xb ? lt1.b : lt1.a;
-        const float wx0 = 1.0f - cx.f, wy0 = 1.0f - cy.f;
-        const float la = ((float)l00.x * wx0 + (float)l10.x * cx.f) * wy0 + ((float)l01.x * wx0 + (float)l11.x * cx.f) * cy.f;
-        const float lb = ((float)l00.y * wx0 + (float)l10.y * cx.f) * wy0 + ((float)l01.y * wx0 + (float)l11.y * cx.f) * cy.f;
+        const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
+        const float la = ((float)lt0.a.x * wx0 + (float)lt0.b.x * fx) * wy0 + ((float)lt1.a.x * wx0 + (float)lt1.b.x * fx) * fy;
+        const float lb = ((float)lt0.a.y * wx0 + (float)lt0.b.y * fx) * wy0 + ((float)lt1.a.y * wx0 + (float)lt1.b.y * fx) * fy;
         out.x += envc.x * (F0.x * la + lb);
         out.y += envc.y * (F0.y * la + lb);
         out.z += envc.z * (F0.z * la + lb);
@@ -486,10 +490,18 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
             lists[e] = (uint16_t)val;
         }
     }
+    // per-row terms of the block's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
+    __shared__ float4 s_row[SHADE_ROWS];
+    if (threadIdx.x < (uint32_t)SHADE_ROWS) {
+        const float v = ((float)(p.y0 + y_begin + threadIdx.x) + 0.5f) / (float)p.full_h;
+        const float ndc_y = 1.0f - 2.0f * v;
+        s_row[threadIdx.x] = make_float4(v, ndc_y * 0.5f * p.near_height, (float)clampi((int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1), 0.0f);
+    }
     const bool q_safe = __syncthreads_and(my_safe) != 0;
     const uint32_t px = bx0 + threadIdx.x;
     if (px >= x_end) return;
-    for (uint32_t py = y_begin; py < y_end; py++) shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py);
+    for (uint32_t py = y_begin; py < y_end; py++)
+        shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin]);
 }
 
 extern "C" {
