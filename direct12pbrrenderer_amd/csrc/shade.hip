@@ -216,13 +216,16 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         //   T  = max(t^2, 1e-6/pi), t = NdotH^2 (a^2 - 1) + 1,
         //   A  = NdotL(1-k)+k (>= 1/8: the shader's max(.,1e-6) never binds),
         //   gl = NdotL / max(4 NdotL NdotV, 1e-4) = min(1 / (4 NdotV), 1e4 NdotL)      (1 / max(a,b) = min(1/a, 1/b))
+        //      = [1 / (4 NdotV)] * sat(NdotL * 4e4 NdotV): the saturation rides on a packed multiply (clamp modifier) where
+        //      the min took two unpacked v_min, and the per-pixel factor 1 / (4 NdotV) moves out of the loop into spec_pix
+        //      (where it cancels gV's NdotV: no division by NdotV is left),
         //   attenuation * NdotL = NdotL / Q;  with r = 1 / (Q T A):  1/Q = r T A,  so one v_rcp serves both; and T is
         //   carried as t^2 h2^2 (h2 = |L + V|^2), which removes the normalisation of H: 4 transcendentals per pair of lights.
         const float ra = roughness * roughness;
         const float a4m1 = ra * ra - 1.0f;
         const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
         const float one_k = 1.0f - k;
-        const float inv_ndv4 = rcp(4.0f * NdotV);   // +inf at NdotV = 0: min() then picks 1e4 NdotL, as the shader's floor does
+        const float c4 = 4.0e4f * NdotV;   // NdotV = 0: sat(0) = 0 here and spec_pix = 0 below, as gV = 0 makes the shader's term
         const float t_floor = EPSILON_F * INV_PI_F;
         // Instruction budget of the loop, from the measured issue costs (tools/valu_rate3.hip -> profiles/r02_valu_rate3.txt,
         // 5 waves per SIMD, cycles per wave-instruction per SIMD): v_pk_{fma,mul,add}_f32 4.7 (two lights per instruction),
@@ -266,13 +269,13 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const f2 TA = Tn * A;
             const f2 r = rcp2(Q * TA);                       // 1 / (Q A t^2 h2^2)
             const f2 X = NdotL * (r * TA);                   // attenuation * NdotL = NdotL / Q
-            const f2 gl = min2(f2s(inv_ndv4), NdotL * 1.0e4f);
+            const f2 gs = mul2_sat(NdotL, f2s(c4));          // gl * 4 NdotV
             // fresnel on NdotL (Q3).  The shader's max(1-NdotL, 1e-6) only matters within 1e-6 of NdotL = 1, where it
             // changes f5 by < 1e-30: dropped.
             const f2 fm = f2s(1.0f) - NdotL;
             const f2 fm2 = fm * fm;
             const f2 f5 = fm2 * fm2 * fm;
-            const f2 w2 = (NdotL * gl) * (h4 * r);           // X * gl / (t^2 A)
+            const f2 w2 = (NdotL * gs) * (h4 * r);           // X * gl / (t^2 A) * 4 NdotV
             const f2 w1 = X - X * f5;                        // X * (1 - f5)
             const f2 w3 = w2 * f5;
             const f2 cr = comp(3), cg = comp(4), cb = comp(5);
@@ -316,8 +319,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     {
         const float ra = roughness * roughness;
         const float k = (roughness + 1.0f) * (roughness + 1.0f) * 0.125f;
-        const float gv = NdotV * rcp(fmaxf(NdotV * (1.0f - k) + k, EPSILON_F));
-        const float spec_pix = ra * ra * INV_PI_F * gv;
+        // a^2 / pi * gV / (4 NdotV), gV = NdotV / max(NdotV (1-k) + k, 1e-6): the light sums S2, S3 carry gl * 4 NdotV
+        const float spec_pix = NdotV > 0.0f ? ra * ra * (0.25f * INV_PI_F) * rcp(fmaxf(NdotV * (1.0f - k) + k, EPSILON_F)) : 0.0f;
         const float kd = (1.0f - metallic) * INV_PI_F;   // Kd*albedo/pi = (1-F0)(1-m) albedo/pi * (1-f5)
         out.x = (1.0f - F0.x) * (kd * albedo.x * s1x + spec_pix * s3x) + F0.x * spec_pix * s2x;
         out.y = (1.0f - F0.y) * (kd * albedo.y * s1y + spec_pix * s3y) + F0.y * spec_pix * s2y;
