@@ -7,9 +7,10 @@
 //    is one 512-byte store; a block walks SHADE_ROWS rows after staging its tables once;
 //  * the light table is staged in LDS as nine structure-of-arrays planes (position, colour * intensity, attenuation):
 //    the same component of two lights lands in an adjacent VGPR pair straight from two ds_read_b32;
-//  * the light lists of the clusters the block can touch are staged in LDS as 16-bit LDS byte addresses, so the
-//    divergent per-lane list walk is an LDS read, not a global gather (blocks that span too many
-//    cluster tiles — tiny render targets — fall back to the global list);
+//  * the light lists of the clusters the block can touch are staged in LDS as LDS byte addresses of the lights (one
+//    dword each: a trip's two entries are ONE ds_read_b64, each address in its own register), so the divergent per-lane
+//    list walk is an LDS read, not a global gather (blocks that span too many cluster tiles — tiny render targets —
+//    fall back to the global list);
 //  * the env chain is sampled from its padded layout (pbr_env_pad): no seam branches, each bilinear row is one
 //    16-byte load;
 //  * with 256 lights the kernel is FP32-VALU-issue-bound (48 packed + 4 transcendental instructions per pair of
@@ -120,7 +121,7 @@ constexpr int SHADE_BLOCK = 256;
 constexpr int SHADE_ROWS = 8;          // rows of 256 pixels one block walks after staging its tables
 constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per block
 // staged list: count, pad, 32 u16 indices = 34 halfwords (68 B) per cluster
-constexpr int LIST_STRIDE_U16 = 34;
+constexpr int LIST_STRIDE = 34;         // dwords per staged cluster list: count, pad, 32 entries (8-byte aligned pairs)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2s(float a) { return f2{a, a}; }
@@ -160,7 +161,7 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 //   3. material: re-reads the A/C planes (L2 hits) and folds the sums;
 //   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
-__device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint16_t* lists, const uint32_t* mip_off,
+__device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint32_t* lists, const uint32_t* mip_off,
                                             int tile_x0, int tile_y0, int tiles_x, int n_lights, bool q_safe, uint32_t px, uint32_t py, float4 row) {
     const size_t gi = (size_t)py * p.pitch + px;
     if (p.stencil[gi] == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
@@ -268,14 +269,15 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             if constexpr (!QSAFE) Q = max2(Q, f2s(EPSILON_F));
             const f2 TA = Tn * A;
             const f2 r = rcp2(Q * TA);                       // 1 / (Q A t^2 h2^2)
-            const f2 X = NdotL * (r * TA);                   // attenuation * NdotL = NdotL / Q
+            const f2 q = NdotL * r;
+            const f2 X = q * TA;                             // attenuation * NdotL = NdotL / Q
             const f2 gs = mul2_sat(NdotL, f2s(c4));          // gl * 4 NdotV
             // fresnel on NdotL (Q3).  The shader's max(1-NdotL, 1e-6) only matters within 1e-6 of NdotL = 1, where it
             // changes f5 by < 1e-30: dropped.
             const f2 fm = f2s(1.0f) - NdotL;
             const f2 fm2 = fm * fm;
             const f2 f5 = fm2 * fm2 * fm;
-            const f2 w2 = (NdotL * gs) * (h4 * r);           // X * gl / (t^2 A) * 4 NdotV
+            const f2 w2 = (q * gs) * h4;                     // X * gl / (t^2 A) * 4 NdotV
             const f2 w1 = X - X * f5;                        // X * (1 - f5)
             const f2 w3 = w2 * f5;
             const f2 cr = comp(3), cg = comp(4), cb = comp(5);
@@ -285,15 +287,16 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         };
         const lds_cf* const ltab = (const lds_cf*)llds;      // the staged light planes, as an LDS (address space 3) pointer
         if (STAGED_LISTS) {
-            const uint16_t* my = lists + (((sy - tile_y0) * tiles_x + (sx - tile_x0)) * PBR_CLUSTER_Z + sz) * LIST_STRIDE_U16;
+            const uint32_t* my = lists + (((sy - tile_y0) * tiles_x + (sx - tile_x0)) * PBR_CLUSTER_Z + sz) * LIST_STRIDE;
             // staged lists are padded to an even count with the null light (black, far away): no odd tail.  An entry is
-            // the LDS BYTE ADDRESS of the light's first plane (table base + 4 * index, < 64 KiB): one mask / shift per light
+            // the LDS BYTE ADDRESS of the light's first plane (table base + 4 * index), a dword of its own: packed two to a dword
+            // the unpacking mask + shift were two more VALU issues per trip
             const int nl = my[0];
             const bool t_ok = __all(ra * ra >= 6.0e-4f) != 0;
             auto walk = [&](auto qs, auto ts) {
-                for (int i = 0; i < nl; i += 2) {   // two entries per LDS read
-                    const uint32_t pair = *reinterpret_cast<const uint32_t*>(my + 2 + i);   // i even -> 4-byte aligned
-                    light2(qs, ts, (const lds_cf*)(uintptr_t)(pair & 0xFFFFu), (const lds_cf*)(uintptr_t)(pair >> 16));
+                for (int i = 0; i < nl; i += 2) {   // one 8-byte LDS read = the two addresses of the trip, each in its own register
+                    const uint2 pair = *reinterpret_cast<const uint2*>(my + 2 + i);   // i even -> 8-byte aligned
+                    light2(qs, ts, (const lds_cf*)(uintptr_t)pair.x, (const lds_cf*)(uintptr_t)pair.y);
                 }
             };
             if (q_safe) { if (t_ok) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{}); }
@@ -423,7 +426,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
 }
 
 // grid (ceil(w/256), ceil(h/SHADE_ROWS)), block 256.
-// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 68 B of light lists.
+// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 136 B of light lists.
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     __shared__ uint32_t s_mip_off[16];
     if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
     float* llds = reinterpret_cast<float*>(lds_raw);
-    uint16_t* lists = reinterpret_cast<uint16_t*>(llds + LIGHT_PLANES * LSTRIDE);
+    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));   // 8-byte aligned
     int my_safe = 1;
     if (threadIdx.x == 0) {   // the null light: pads odd lists; black, so its pair lane contributes exactly 0
         llds[0 * LSTRIDE + n_lights] = 1.0e15f; llds[1 * LSTRIDE + n_lights] = 1.0e15f; llds[2 * LSTRIDE + n_lights] = 1.0e15f;
@@ -478,8 +481,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         const int tile_y1 = max(ty_a, ty_b);
         tiles_x = tile_x1 - tile_x0 + 1;
         const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
-        for (int e = threadIdx.x; e < n_cl * LIST_STRIDE_U16; e += SHADE_BLOCK) {
-            const int c = e / LIST_STRIDE_U16, j = e % LIST_STRIDE_U16;
+        for (int e = threadIdx.x; e < n_cl * LIST_STRIDE; e += SHADE_BLOCK) {
+            const int c = e / LIST_STRIDE, j = e % LIST_STRIDE;
             const int z = c % PBR_CLUSTER_Z, t = c / PBR_CLUSTER_Z;
             const int cx = tile_x0 + t % tiles_x, cy = tile_y0 + t / tiles_x;
             const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
                 const int li = (j - 2) < cnt ? min(max(cl->LightIndex[j - 2], 0), n_lights - 1) : n_lights;   // never index past the staged table
                 val = (int)(lds_base + 4u * (uint32_t)li);   // LDS byte address of the light's first plane
             }
-            lists[e] = (uint16_t)val;
+            lists[e] = (uint32_t)val;
         }
     }
     // per-row terms of the block's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
@@ -586,10 +589,13 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     // MAX_STAGED_TILES cluster tiles: a tile is full_w/24 x full_h/16 pixels, +1 per axis for straddling.
     const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
     const uint32_t span_y = (uint32_t)((uint64_t)(SHADE_ROWS - 1) * PBR_CLUSTER_Y / tile->full_h) + 2;
-    const bool staged = num_lights > 0 && span_x * span_y <= (uint32_t)MAX_STAGED_TILES;
-    const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
     const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
-    const size_t lds = (size_t)LIGHT_PLANES * lstride * sizeof(float) + (size_t)max_clusters * LIST_STRIDE_U16 * sizeof(uint16_t);
+    const size_t plane_bytes = (size_t)((LIGHT_PLANES * lstride + 1) & ~1) * sizeof(float);
+    // staged lists must also fit the 64 KiB a block may ask for (1 024 lights: 36 KiB of planes leave room for 8 tiles)
+    const bool staged = num_lights > 0 && span_x * span_y <= (uint32_t)MAX_STAGED_TILES &&
+                        plane_bytes + (size_t)span_x * span_y * PBR_CLUSTER_Z * LIST_STRIDE * sizeof(uint32_t) <= 65536;
+    const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
+    const size_t lds = plane_bytes + (size_t)max_clusters * LIST_STRIDE * sizeof(uint32_t);
     const dim3 blk(SHADE_BLOCK);
     if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
     else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
