@@ -13,8 +13,8 @@
 //    fall back to the global list);
 //  * the env chain is sampled from its padded layout (pbr_env_pad): no seam branches, each bilinear row is one
 //    16-byte load;
-//  * with 256 lights the kernel is FP32-VALU-issue-bound (48 packed + 4 transcendental instructions per pair of
-//    lights), not HBM-bound.
+//  * with 256 lights the kernel is FP32-VALU-issue-bound (47 packed + 4 transcendental + 2 plain instructions per pair
+//    of lights, ~500 per pixel around the loop), not HBM-bound.
 #include <type_traits>
 #include "pbr_internal.hpp"
 #include "pbr_device.hpp"
@@ -163,8 +163,11 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint32_t* lists, const uint32_t* mip_off,
                                             int tile_x0, int tile_y0, int tiles_x, int n_lights, bool q_safe, uint32_t px, uint32_t py, float4 row) {
-    const size_t gi = (size_t)py * p.pitch + px;
-    if (p.stencil[gi] == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
+    // 32-bit element index (host-checked: pitch * rows * 16 < 2^32): a uniform base + one 32-bit lane offset per access instead of
+    // 64-bit address arithmetic for every plane
+    const uint32_t gi = py * p.pitch + px;
+    auto at = [](const auto* base, uint32_t byte_off) { return *reinterpret_cast<std::remove_reference_t<decltype(*base)>*>(reinterpret_cast<const char*>(base) + byte_off); };
+    if (at(p.stencil, gi) == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
     const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
 
     // ---- phase 1: geometry (vs_main :91-121, screen triangle D3D12Device.cpp:167-176; uv from the GLOBAL pixel)
@@ -174,8 +177,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     V3 pos, view, n;
     float z_vs, roughness;
     {
-        const uint32_t b = p.B[gi], c = p.C[gi];
-        const float depth_ndc = p.depth[gi];
+        const uint32_t b = at(p.B, gi * 4u), c = at(p.C, gi * 4u);
+        const float depth_ndc = at(p.depth, gi * 4u);
         const float ndc_x = 2.0f * u - 1.0f;
         const V3 cvv = v3(ndc_x * 0.5f * p.near_width, row.y, p.Near);
         const V3 camera_vec = v3(p.InvView[0] * cvv.x + p.InvView[1] * cvv.y + p.InvView[2] * cvv.z,
@@ -232,7 +235,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // 5 waves per SIMD, cycles per wave-instruction per SIMD): v_pk_{fma,mul,add}_f32 4.7 (two lights per instruction),
         // plain v_fma 2.6 / v_mul 3.0, v_max / v_min 4.6, v_rsq / v_rcp 8.5.  Two lights per trip in the halves of packed
         // registers therefore buy ~1.2x per flop, not 2x; the SoA light planes put the same component of both lights into
-        // an adjacent VGPR pair with no moves.  Per trip: 48 packed + 4 transcendental + 2 min (+ 2 max on the slow paths).
+        // an adjacent VGPR pair with no moves.  Per trip: 47 packed + 4 transcendental + the loop's compare and pointer step (+ 2 / 4 v_max on the slow paths).
         f2 a1x = f2s(0.0f), a1y = f2s(0.0f), a1z = f2s(0.0f), a2x = f2s(0.0f), a2y = f2s(0.0f), a2z = f2s(0.0f), a3x = f2s(0.0f), a3y = f2s(0.0f), a3z = f2s(0.0f);
         auto light2 = [&](auto q_safe, auto t_safe, const lds_cf* la, const lds_cf* lb) {
             constexpr bool QSAFE = decltype(q_safe)::value, TSAFE = decltype(t_safe)::value;
@@ -313,8 +316,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     }
 
     // ---- phase 3: material terms (planes A and C re-read: L2 hits, keeps them out of the loop's registers)
-    const uint32_t a = p.A[gi];
-    const float metallic = (float)((p.C[gi] >> 8) & 255u) * inv255;
+    const uint32_t a = at(p.A, gi * 4u);
+    const float metallic = (float)((at(p.C, gi * 4u) >> 8) & 255u) * inv255;
     const V3 albedo = v3((float)(a & 255u) * inv255, (float)((a >> 8) & 255u) * inv255, (float)((a >> 16) & 255u) * inv255);
     const float emission = (float)(a >> 24) * inv255;
     const V3 F0 = v3(0.04f + metallic * (albedo.x - 0.04f), 0.04f + metallic * (albedo.y - 0.04f), 0.04f + metallic * (albedo.z - 0.04f));
@@ -421,8 +424,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         out.z += envc.z * (F0.z * la + lb);
     }
 #endif
-    if (F32OUT) *reinterpret_cast<float4*>(p.hdr_f32 + 4 * ((size_t)py * p.hdr_pitch + px)) = make_float4(out.x, out.y, out.z, 1.0f);
-    else store_h4(p.hdr + 4 * ((size_t)py * p.hdr_pitch + px), f4(out.x, out.y, out.z, 1.0f));
+    const uint32_t ho = py * p.hdr_pitch + px;
+    if (F32OUT) *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.hdr_f32) + ho * 16u) = make_float4(out.x, out.y, out.z, 1.0f);
+    else store_h4(reinterpret_cast<pbr_half*>(reinterpret_cast<char*>(p.hdr) + ho * 8u), f4(out.x, out.y, out.z, 1.0f));
 }
 
 // grid (ceil(w/256), ceil(h/SHADE_ROWS)), block 256.
@@ -542,6 +546,9 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     PBR_REQUIRE(ctx, tile->w >= 1 && tile->h >= 1 && tile->w <= 65535 && tile->h <= 65535, "pbr_deferred_shade: bad tile size");
     PBR_REQUIRE(ctx, tile->x0 + tile->w <= tile->full_w && tile->y0 + tile->h <= tile->full_h, "pbr_deferred_shade: tile outside frame");
     PBR_REQUIRE(ctx, gb->pitch >= tile->w && hdr_pitch >= tile->w, "pbr_deferred_shade: pitch < width");
+    // the kernel addresses every plane with 32-bit byte offsets (16 B per pixel for the fp32 probe's output)
+    PBR_REQUIRE(ctx, (uint64_t)gb->pitch * tile->h * 4u < (1ull << 32) && (uint64_t)hdr_pitch * tile->h * 16u < (1ull << 32),
+                "pbr_deferred_shade: tile too large for 32-bit plane offsets (pitch x rows x 16 bytes must stay below 4 GiB)");
     PBR_REQUIRE(ctx, lut_res >= 1 && env_size >= 1 && env_mips >= 1 && env_mips <= 16 && (env_size >> (env_mips - 1)) >= 1, "pbr_deferred_shade: bad LUT/env size");
     PBR_REQUIRE(ctx, ((uintptr_t)env & 7u) == 0 && ((uintptr_t)lut & 3u) == 0, "pbr_deferred_shade: env must be 8-byte and lut 4-byte aligned");
     PBR_REQUIRE(ctx, g->Near > 0.0f && g->Far > g->Near, "pbr_deferred_shade: need 0 < Near < Far");
