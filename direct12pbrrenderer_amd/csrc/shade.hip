@@ -126,7 +126,6 @@ constexpr int LIST_STRIDE = 34;         // dwords per staged cluster list: count
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2s(float a) { return f2{a, a}; }
 __device__ __forceinline__ f2 max2(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
-__device__ __forceinline__ f2 min2(f2 a, f2 b) { return f2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
 typedef __attribute__((address_space(3))) const float lds_cf;   // a float in LDS: 32-bit addresses, ds_read with an immediate plane offset
 __device__ __forceinline__ f2 rsq2(f2 a) { return f2{rsq(a.x), rsq(a.y)}; }
 __device__ __forceinline__ f2 rcp2(f2 a) { return f2{rcp(a.x), rcp(a.y)}; }
