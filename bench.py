@@ -67,6 +67,9 @@ def parse():
                    help="halo mode: shade the tile's border ring first (side stream) and exchange its strips while the core is shaded. "
                         "Off by default: on one GPU the split costs 73 us (cfg5 tile) / 120 us (4K-equivalent tile) because the ring's "
                         "264-px-wide bands shade at half the whole tile's rate — it pays only where the exchange takes longer than that")
+    p.add_argument("--settle", type=int, default=300,
+                   help="untimed frames rendered before the W warm-up steps so that the device's clock has ramped (DVFS: a fresh process "
+                        "runs its first ~100 ms at a lower clock; with the default K the timed region is only ~25 ms).  Reported in config")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     return p.parse_args()
@@ -419,7 +422,7 @@ def main():
     lights_px = mean_lights_per_pixel(g, gb_np, spec, frame.clusters)
     torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(a.settle + a.warmup):   # the same count on every rank: frames carry collectives
         frame.render()
     torch.cuda.synchronize()
     if dist:
@@ -467,7 +470,7 @@ def main():
                    "tile": [spec.x0, spec.y0, spec.w, spec.h], "shaded_rect": [spec.sx0, spec.sy0, spec.sw, spec.sh],
                    "bloom_rect": [spec.ex0, spec.ey0, spec.ew, spec.eh],
                    "bloom_borders": "none" if world == 1 else (mode + (" (ring first: exchange overlaps the core's shade)" if frame.split is not None else "")), "collectives": "none" if world == 1 else ("gloo-rehearsal" if rehearsal else f"rccl-{transport}"),
-                   "mean_lights_per_pixel_by_rank": lp},
+                   "mean_lights_per_pixel_by_rank": lp, "clock_settle_frames": a.settle},
     }
     if rehearsal:
         out["rehearsal"] = "all ranks share cuda:0 (gloo + host copies): functional run, not a measurement"
