@@ -250,6 +250,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE line, the JSON record of rank 0: whatever libraries print meanwhile (gloo's "[Gloo] Rank 0 is connected
+    # to ..." goes to the C stdout) is sent to stderr by pointing fd 1 there; the record is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # PBR_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives + host copies — exercises this file's
     # multi-rank path on a one-GPU box; not a measurement
     rehearsal = os.environ.get("PBR_BENCH_REHEARSAL", "0") == "1"
@@ -564,7 +569,9 @@ def main():
         except Exception as e:   # the baseline is reporting only; never fail the GPU measurement on it
             out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

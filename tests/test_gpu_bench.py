@@ -1,0 +1,28 @@
+"""bench.py's output contract on the GPU box: exactly ONE line on stdout — the JSON record — whether the process is the
+single-GPU bench or spawns its own ranks (`--gpus 2` on a one-GPU box = rehearsal mode: both ranks on cuda:0, gloo + host
+copies, which makes gloo print its connection banner to the C stdout), with the keys the driver reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline"}
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("extra,n", [([], 1), (["--gpus", "2"], 2)])
+def test_bench_prints_one_json_line(extra, n):
+    cmd = ["timeout", "-k", "10", "500", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--settle", "5", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, lines[:5]
+    rec = json.loads(lines[0])
+    assert KEYS <= set(rec) and rec["n_gpus"] == n and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0
+    assert rec["config"]["clock_settle_frames"] == 5 and "workload" in rec["config"]
+    assert rec["roofline"]["bound"] in ("hbm", "mfma") and rec["roofline"]["achieved"] > 0
