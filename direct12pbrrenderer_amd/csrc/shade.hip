@@ -384,9 +384,12 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const H4x2 r0 = *reinterpret_cast<const H4x2*>(m + o);
             const H4x2 r1 = *reinterpret_cast<const H4x2*>(m + o + 2);
             const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-            const float tr = (float)r0.a.x * wx0 + (float)r0.b.x * fx, br = (float)r1.a.x * wx0 + (float)r1.b.x * fx;
-            const float tg = (float)r0.a.y * wx0 + (float)r0.b.y * fx, bg = (float)r1.a.y * wx0 + (float)r1.b.y * fx;
-            const float tb = (float)r0.a.z * wx0 + (float)r0.b.z * fx, bb = (float)r1.a.z * wx0 + (float)r1.b.z * fx;
+            // a * wx0 + b * fx with BOTH products as v_fma_mix_f32 (the fp16 -> fp32 conversion rides in the instruction): written
+            // as fma(a, wx0, 0) the first product keeps its rounding and loses its separate v_cvt
+            auto xl = [&](h16 a, h16 b) { return __builtin_fmaf((float)b, fx, __builtin_fmaf((float)a, wx0, 0.0f)); };
+            const float tr = xl(r0.a.x, r0.b.x), br = xl(r1.a.x, r1.b.x);
+            const float tg = xl(r0.a.y, r0.b.y), bg = xl(r1.a.y, r1.b.y);
+            const float tb = xl(r0.a.z, r0.b.z), bb = xl(r1.a.z, r1.b.z);
             return v3(tr * wy0 + br * fy, tg * wy0 + bg * fy, tb * wy0 + bb * fy);
         };
         const V3 ea = fetch(l0, mip_off[l0]);   // per-lane index: the table sits in LDS (an SGPR array would spill to scratch)
@@ -416,8 +419,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             lt1 = lt0;
         }
         const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-        const float la = ((float)lt0.a.x * wx0 + (float)lt0.b.x * fx) * wy0 + ((float)lt1.a.x * wx0 + (float)lt1.b.x * fx) * fy;
-        const float lb = ((float)lt0.a.y * wx0 + (float)lt0.b.y * fx) * wy0 + ((float)lt1.a.y * wx0 + (float)lt1.b.y * fx) * fy;
+        auto xl = [&](h16 a, h16 b) { return __builtin_fmaf((float)b, fx, __builtin_fmaf((float)a, wx0, 0.0f)); };   // two v_fma_mix_f32, see fetch
+        const float la = xl(lt0.a.x, lt0.b.x) * wy0 + xl(lt1.a.x, lt1.b.x) * fy;
+        const float lb = xl(lt0.a.y, lt0.b.y) * wy0 + xl(lt1.a.y, lt1.b.y) * fy;
         out.x += envc.x * (F0.x * la + lb);
         out.y += envc.y * (F0.y * la + lb);
         out.z += envc.z * (F0.z * la + lb);
