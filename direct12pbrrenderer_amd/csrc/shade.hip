@@ -164,7 +164,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
                                             int tile_x0, int tile_y0, int tiles_x, int n_lights, bool q_safe, uint32_t px, uint32_t py, float4 row) {
     // 32-bit element index (host-checked: pitch * rows * 16 < 2^32): a uniform base + one 32-bit lane offset per access instead of
     // 64-bit address arithmetic for every plane
-    const uint32_t gi = py * p.pitch + px;
+    const uint32_t gi = __umul24(py, p.pitch) + px;
     auto at = [](const auto* base, uint32_t byte_off) { return *reinterpret_cast<std::remove_reference_t<decltype(*base)>*>(reinterpret_cast<const char*>(base) + byte_off); };
     if (at(p.stencil, gi) == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
     const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
@@ -291,7 +291,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         };
         const lds_cf* const ltab = (const lds_cf*)llds;      // the staged light planes, as an LDS (address space 3) pointer
         if (STAGED_LISTS) {
-            const uint32_t* my = lists + (((sy - tile_y0) * tiles_x + (sx - tile_x0)) * PBR_CLUSTER_Z + sz) * LIST_STRIDE;
+            const uint32_t* my = lists + __mul24(__mul24(__mul24(sy - tile_y0, tiles_x) + (sx - tile_x0), PBR_CLUSTER_Z) + sz, LIST_STRIDE);
             // staged lists are padded to an even count with the null light (black, far away): no odd tail.  An entry is
             // the LDS BYTE ADDRESS of the light's first plane (table base + 4 * index), a dword of its own: packed two to a dword
             // the unpacking mask + shift were two more VALU issues per trip
@@ -382,11 +382,13 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const float fxp = snap8(cu * (float)s) - 0.5f, fyp = snap8(cv * (float)s) - 0.5f;
             const float flx = floorf(fxp), fly = floorf(fyp);
             const float fx = fxp - flx, fy = fyp - fly;
-            const H4* m = reinterpret_cast<const H4*>(p.env) + mip_off;
-            // footprint layout: the four texels of this tap are 32 contiguous bytes
-            const uint32_t o = ((face * (uint32_t)sq + (uint32_t)((int)fly + 1)) * (uint32_t)sq + (uint32_t)((int)flx + 1)) * 4u;
-            const H4x2 r0 = *reinterpret_cast<const H4x2*>(m + o);
-            const H4x2 r1 = *reinterpret_cast<const H4x2*>(m + o + 2);
+            // footprint layout: the four texels of this tap are 32 contiguous bytes.  24-bit multiplies (every factor < 2^24;
+            // v_mul_lo_u32 / v_mad_u64_u32 are multi-pass instructions) and a 32-bit byte offset from the chain's base
+            // (host-checked: the padded chain is smaller than 4 GiB)
+            const uint32_t o = __umul24(__umul24(face, (uint32_t)sq) + (uint32_t)((int)fly + 1), (uint32_t)sq) + (uint32_t)((int)flx + 1);
+            const char* q = reinterpret_cast<const char*>(p.env) + (mip_off + o * 4u) * 8u;
+            const H4x2 r0 = *reinterpret_cast<const H4x2*>(q);
+            const H4x2 r1 = *reinterpret_cast<const H4x2*>(q + 16);
             const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
             // a * wx0 + b * fx with BOTH products as v_fma_mix_f32 (the fp16 -> fp32 conversion rides in the instruction): written
             // as fma(a, wx0, 0) the first product keeps its rounding and loses its separate v_cvt
@@ -416,8 +418,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         const H2* lut = reinterpret_cast<const H2*>(p.lut);
         H2x2 lt0, lt1;
         if (lr > 1) {
-            lt0 = *reinterpret_cast<const H2x2*>(lut + (size_t)y0 * lr + xb);
-            lt1 = *reinterpret_cast<const H2x2*>(lut + (size_t)y1 * lr + xb);
+            const char* lb8 = reinterpret_cast<const char*>(lut);   // 32-bit byte offsets: lr <= 16384 (host-checked)
+            lt0 = *reinterpret_cast<const H2x2*>(lb8 + (__umul24((uint32_t)y0, (uint32_t)lr) + (uint32_t)xb) * 4u);
+            lt1 = *reinterpret_cast<const H2x2*>(lb8 + (__umul24((uint32_t)y1, (uint32_t)lr) + (uint32_t)xb) * 4u);
         } else {
             lt0.a = lt0.b = lut[0];
             lt1 = lt0;
@@ -431,7 +434,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         out.z += envc.z * (F0.z * la + lb);
     }
 #endif
-    const uint32_t ho = py * p.hdr_pitch + px;
+    const uint32_t ho = __umul24(py, p.hdr_pitch) + px;
     if (F32OUT) *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.hdr_f32) + ho * 16u) = make_float4(out.x, out.y, out.z, 1.0f);
     else store_h4(reinterpret_cast<pbr_half*>(reinterpret_cast<char*>(p.hdr) + ho * 8u), f4(out.x, out.y, out.z, 1.0f));
 }
@@ -557,6 +560,8 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     PBR_REQUIRE(ctx, (uint64_t)gb->pitch * tile->h * 4u < (1ull << 32) && (uint64_t)hdr_pitch * tile->h * 16u < (1ull << 32),
                 "pbr_deferred_shade: tile too large for 32-bit plane offsets (pitch x rows x 16 bytes must stay below 4 GiB)");
     PBR_REQUIRE(ctx, lut_res >= 1 && env_size >= 1 && env_mips >= 1 && env_mips <= 16 && (env_size >> (env_mips - 1)) >= 1, "pbr_deferred_shade: bad LUT/env size");
+    PBR_REQUIRE(ctx, lut_res >= 1 && lut_res <= 16384 && (uint64_t)pbr_env_padded_texels(env_size, env_mips) * 8u < (1ull << 32),
+                "pbr_deferred_shade: LUT larger than 16384^2 or padded env chain of 4 GiB or more (32-bit texture offsets)");
     PBR_REQUIRE(ctx, ((uintptr_t)env & 7u) == 0 && ((uintptr_t)lut & 3u) == 0, "pbr_deferred_shade: env must be 8-byte and lut 4-byte aligned");
     PBR_REQUIRE(ctx, g->Near > 0.0f && g->Far > g->Near, "pbr_deferred_shade: need 0 < Near < Far");
     PBR_REQUIRE(ctx, num_lights >= 0 && num_lights <= PBR_MAX_SCENE_LIGHTS, "pbr_deferred_shade: light count out of [0, 1024]");
