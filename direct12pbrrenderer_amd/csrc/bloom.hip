@@ -873,7 +873,7 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
             return launched(ctx, "k_blur_up_wide");
         }
     }
-    // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 (256) below
+    // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 below (PBR_BLOOM_TILE=16: on 4 waves)
     static const int forced = getenv("PBR_BLOOM_TILE") ? atoi(getenv("PBR_BLOOM_TILE")) : 0;
     const bool big = forced ? forced == 32 : (uint64_t)((tr.mx1 + 63) / 64 - tr.mx0 / 64) * ((tr.my1 + 31) / 32 - tr.my0 / 32) >= 900;
     // tiles that intersect the merge rect (TAIL 0 has no rect: every tile of the level)
@@ -884,6 +884,11 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
     const int blocks = TAIL == 2 ? even_blocks(n_tiles) : n_tiles;
     if (big) {
         hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 32, 512>), dim3(blocks), dim3(512), 0, ctx->stream,
+                           in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, tr, min_log, inv_range, hist);
+    } else if (forced != 16) {
+        // small levels are latency-bound (one tile's dependent chain + the launch): 64 x 16 tiles on EIGHT waves — 3 H rows per
+        // wave, 2 outputs per thread — shorten the chain; the five small launches of a 4K frame take ~5 us less together
+        hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 16, 512>), dim3(blocks), dim3(512), 0, ctx->stream,
                            in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, tiles_x, n_tiles, tr, min_log, inv_range, hist);
     } else {
         hipLaunchKernelGGL((k_blur_hv<MODE, DUAL, TAIL, 16, 256>), dim3(blocks), dim3(256), 0, ctx->stream,
