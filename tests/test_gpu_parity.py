@@ -342,16 +342,38 @@ def test_deferred_shade_f32_within_1e4_relative_linf(ctx, orc, ibl, n_lights):
         print(f"fp32 shade vs oracle, {w}x{h}, {n_lights} lights: plain relative L-inf {rel:.3g}; {frac * 100:.3f} % of the pixels above 1e-4 (all inside the N.H conditioning allowance)")
 
 
-def test_deferred_shade_1024_lights_fp16_target(ctx, orc, ibl):
-    """257..1024 scene lights select the kernel instantiation with the 1025-float LDS plane stride."""
+@pytest.mark.parametrize("w,h", [(256, 144), (1920, 96)])
+def test_deferred_shade_1024_lights_fp16_target(ctx, orc, ibl, w, h):
+    """257..1024 scene lights select the kernel instantiation with the 1025-float LDS plane stride.  1920x96: a block spans
+    4 x 3 = 12 cluster tiles — within the staging limit, but 36 KiB of light planes + 12 x 24 dword lists pass the 64 KiB a
+    block may ask for, so the launch must fall back to the global lists instead of failing."""
     sky, env, lut, sh = ibl
-    cam, g, lights, gb, tile = common.shade_scene(256, 144, 1024, sh, rough_min=48)
+    cam, g, lights, gb, tile = common.shade_scene(w, h, 1024, sh, rough_min=48)
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     assert (cl["LightIndex"][cl["NumLights"] > 0].max() > 256)        # lists really index beyond the 257-stride table
     want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
-    _check_shade(got, want, want_f32, gb["stencil"], "1024 lights", hard_ulp=None, sens=sens)
+    _check_shade(got, want, want_f32, gb["stencil"], f"1024 lights {w}x{h}", hard_ulp=None, sens=sens)
+
+
+def test_deferred_shade_rejects_what_its_32bit_offsets_cannot_address(ctx, orc, ibl):
+    """The kernel addresses planes, LUT and env chain with 32-bit byte offsets: the host side refuses a LUT above 16384^2 and a
+    padded env chain of 4 GiB or more, and says why (nothing is launched)."""
+    from direct12pbrrenderer_amd.api import PbrError
+    sky, env, lut, sh = ibl
+    cam, g, lights, gb, tile = common.shade_scene(64, 64, 1, sh, rough_min=48)
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    gbd = {k: ctx.upload(v) for k, v in gb.items()}
+    hdr = ctx.zeros((64, 64, 4), torch.float16)
+    dlut, denv, dcl, dl = dev_half(ctx, lut), ctx.env_pad(dev_half(ctx, env), common.ENV_SIZE, common.ENV_MIPS), ctx.upload(cl), ctx.upload(lights)
+    with pytest.raises(PbrError, match="LUT larger than 16384"):
+        ctx.deferred_shade(g, tile, gbd, 64, dlut, 20000, denv, common.ENV_SIZE, common.ENV_MIPS, dcl, dl, len(lights), hdr, 64)
+    with pytest.raises(PbrError, match="4 GiB"):
+        ctx.deferred_shade(g, tile, gbd, 64, dlut, lut.shape[0], denv, 8192, 1, dcl, dl, len(lights), hdr, 64)
+    ctx.deferred_shade(g, tile, gbd, 64, dlut, lut.shape[0], denv, common.ENV_SIZE, common.ENV_MIPS, dcl, dl, len(lights), hdr, 64)   # and accepts the real thing
+    ctx.sync()
 
 
 @pytest.fixture(scope="module")
