@@ -215,7 +215,9 @@ pbr_status pbr_clustered(pbr_ctx* ctx, const pbr_global* g, const pbr_light* lig
  * produced by pbr_env_pad (the fixed-function seamless-cube addressing, done once instead of per tap).
  * lights / num_lights: the PointLights buffer the cluster lists index (num_lights <= 1024; the
  * kernel stages exactly num_lights records into LDS, indices are clamped to that range).
- * hdr: tile-local w x h half4, pitch hdr_pitch pixels; untouched where stencil == 0. */
+ * hdr: tile-local w x h half4, pitch hdr_pitch pixels; untouched where stencil == 0.
+ * Limits (32-bit offsets inside the kernel, PBR_ERR_INVALID beyond them): pitch x tile rows x 16 bytes < 4 GiB per plane,
+ * lut_res <= 16384, padded env chain < 4 GiB (env_size <= 4096 with a full mip chain). */
 pbr_status pbr_deferred_shade(pbr_ctx* ctx, const pbr_global* g, const pbr_tile* tile,
                               const pbr_gbuffer* gb,
                               const pbr_half* lut, uint32_t lut_res,
