@@ -568,14 +568,16 @@ def main():
                                                env.cpu().view(torch.int16).numpy().view(np.float16), a.width, a.height)
         except Exception as e:   # the baseline is reporting only; never fail the GPU measurement on it
             out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-    if rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    os.close(json_fd)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    # the record is the last thing this process writes (teardown messages of the libraries, if any, come before it)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
