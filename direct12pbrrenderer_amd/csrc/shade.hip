@@ -161,7 +161,7 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 //   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint32_t* lists, const uint32_t* mip_off,
-                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, bool q_safe, uint32_t px, uint32_t py, float4 row) {
+                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, int q_safe, uint32_t px, uint32_t py, float4 row) {
     // 32-bit element index (host-checked: pitch * rows * 16 < 2^32): a uniform base + one 32-bit lane offset per access instead of
     // 64-bit address arithmetic for every plane
     const uint32_t gi = __umul24(py, p.pitch) + px;
@@ -238,8 +238,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // registers therefore buy ~1.2x per flop, not 2x; the SoA light planes put the same component of both lights into
         // an adjacent VGPR pair with no moves.  Per trip: 47 packed + 4 transcendental + the loop's compare and pointer step (+ 2 / 4 v_max on the slow paths).
         f2 a1x = f2s(0.0f), a1y = f2s(0.0f), a1z = f2s(0.0f), a2x = f2s(0.0f), a2y = f2s(0.0f), a2z = f2s(0.0f), a3x = f2s(0.0f), a3y = f2s(0.0f), a3z = f2s(0.0f);
-        auto light2 = [&](auto q_safe, auto t_safe, const lds_cf* la, const lds_cf* lb) {
-            constexpr bool QSAFE = decltype(q_safe)::value, TSAFE = decltype(t_safe)::value;
+        const float att_c0 = llds[6 * LSTRIDE], att_c1 = llds[7 * LSTRIDE], att_c2 = llds[8 * LSTRIDE];   // light 0's polynomial (ATT: everyone's)
+        auto light2 = [&](auto q_safe, auto t_safe, const lds_cf* la, const lds_cf* lb, auto att_uniform) {
+            constexpr bool QSAFE = decltype(q_safe)::value, TSAFE = decltype(t_safe)::value, ATT = decltype(att_uniform)::value;
             auto comp = [&](int c) { return f2{la[c * LSTRIDE], lb[c * LSTRIDE]}; };
             const f2 dx = comp(0) - f2s(pos.x), dy = comp(1) - f2s(pos.y), dz = comp(2) - f2s(pos.z);
             const f2 d2 = dx * dx + dy * dy + dz * dz;
@@ -269,7 +270,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const f2 A = NdotL * one_k + f2s(k);
             // attenuation(): max(C0 + C1 d + C2 d^2, 1e-6).  QSAFE: every staged light has C0 >= 1e-6 and C1, C2 >= 0,
             // so the floor never binds (checked once per block while the table is staged)
-            f2 Q = comp(6) + comp(7) * dist + comp(8) * d2;
+            f2 Q;
+            if constexpr (ATT) Q = f2s(att_c0) + f2s(att_c1) * dist + f2s(att_c2) * d2;   // the scene's one polynomial (the null light takes it too: its colour is 0 and Q stays finite)
+            else Q = comp(6) + comp(7) * dist + comp(8) * d2;
             if constexpr (!QSAFE) Q = max2(Q, f2s(EPSILON_F));
             const f2 TA = Tn * A;
             const f2 r = rcp2(Q * TA);                       // 1 / (Q A t^2 h2^2)
@@ -297,21 +300,23 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             // the unpacking mask + shift were two more VALU issues per trip
             const int nl = my[0];
             const bool t_ok = __all(ra * ra >= 6.0e-4f) != 0;
-            auto walk = [&](auto qs, auto ts) {
+            auto walk = [&](auto qs, auto ts, auto au) {
                 int i = 0;
                 do {   // nl >= 2.  One 8-byte LDS read = the two addresses of the trip, each in its own register
                     const uint2 pair = *reinterpret_cast<const uint2*>(my + 2 + i);   // i even -> 8-byte aligned
-                    light2(qs, ts, (const lds_cf*)(uintptr_t)pair.x, (const lds_cf*)(uintptr_t)pair.y);
+                    light2(qs, ts, (const lds_cf*)(uintptr_t)pair.x, (const lds_cf*)(uintptr_t)pair.y, au);
                     i += 2;
                 } while (i < nl);
             };
-            if (q_safe) { if (t_ok) walk(std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::false_type{}); }
-            else walk(std::false_type{}, std::false_type{});
+            if (q_safe & 1) {
+                if (t_ok) { if (q_safe & 2) walk(std::true_type{}, std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::true_type{}, std::false_type{}); }
+                else walk(std::true_type{}, std::false_type{}, std::false_type{});
+            } else walk(std::false_type{}, std::false_type{}, std::false_type{});
         } else {
             const pbr_cluster* cl = p.clusters + (sz + sx * PBR_CLUSTER_Z + sy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
             const int nl = min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER);
             auto idx = [&](int q) { return q < nl ? min(max(cl->LightIndex[q], 0), n_lights - 1) : n_lights; };   // n_lights = the null light
-            for (int i = 0; i < nl; i += 2) light2(std::false_type{}, std::false_type{}, ltab + idx(i), ltab + idx(i + 1));
+            for (int i = 0; i < nl; i += 2) light2(std::false_type{}, std::false_type{}, ltab + idx(i), ltab + idx(i + 1), std::false_type{});
         }
         s1x = a1x.x + a1x.y; s1y = a1y.x + a1y.y; s1z = a1z.x + a1z.y;
         s2x = a2x.x + a2x.y; s2y = a2y.x + a2y.y; s2z = a2z.x + a2z.y;
@@ -451,7 +456,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
     float* llds = reinterpret_cast<float*>(lds_raw);
     uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));   // 8-byte aligned
-    int my_safe = 1;
+    int my_safe = 1, my_same = 1;
+    const float att0 = n_lights > 0 ? p.lights[0].C0 : 1.0f, att1 = n_lights > 0 ? p.lights[0].C1 : 0.0f, att2 = n_lights > 0 ? p.lights[0].C2 : 0.0f;
     if (threadIdx.x == 0) {   // the null light: pads odd lists; black, so its pair lane contributes exactly 0
         llds[0 * LSTRIDE + n_lights] = 1.0e15f; llds[1 * LSTRIDE + n_lights] = 1.0e15f; llds[2 * LSTRIDE + n_lights] = 1.0e15f;
         llds[3 * LSTRIDE + n_lights] = 0.0f; llds[4 * LSTRIDE + n_lights] = 0.0f; llds[5 * LSTRIDE + n_lights] = 0.0f;
@@ -460,6 +466,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     for (int i = threadIdx.x; i < n_lights; i += SHADE_BLOCK) {
         const pbr_light l = p.lights[i];
         my_safe &= (l.C0 >= EPSILON_F) & (l.C1 >= 0.0f) & (l.C2 >= 0.0f);
+        my_same &= (l.C0 == att0) & (l.C1 == att1) & (l.C2 == att2);
         llds[0 * LSTRIDE + i] = l.Position[0];
         llds[1 * LSTRIDE + i] = l.Position[1];
         llds[2 * LSTRIDE + i] = l.Position[2];
@@ -517,7 +524,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         const float ndc_y = 1.0f - 2.0f * v;
         s_row[threadIdx.x] = make_float4(v, ndc_y * 0.5f * p.near_height, (float)clampi((int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1), 0.0f);
     }
-    const bool q_safe = __syncthreads_and(my_safe) != 0;
+    // bit 0: the attenuation floor cannot bind; bit 1: every staged light has the SAME attenuation polynomial (one radius for the
+    // whole scene is common), so its three coefficients are per-kernel constants and a trip reads 13 LDS dwords instead of 19
+    const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
     const uint32_t px = bx0 + threadIdx.x;
     if (px >= x_end) return;
     for (uint32_t py = y_begin; py < y_end; py++)
