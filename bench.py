@@ -70,6 +70,9 @@ def parse():
     p.add_argument("--settle", type=int, default=300,
                    help="untimed frames rendered before the W warm-up steps so that the device's clock has ramped (DVFS: a fresh process "
                         "runs its first ~100 ms at a lower clock; with the default K the timed region is only ~25 ms).  Reported in config")
+    p.add_argument("--no-tail-overlap", action="store_true",
+                   help="N > 1: keep histogram all-reduce, average and tone-map of a frame on the frame's stream (default: on the context's side "
+                        "stream, beside the next frame's shade, HDR target and histogram double-buffered)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     return p.parse_args()
@@ -427,6 +430,34 @@ def main():
     lights_px = mean_lights_per_pixel(g, gb_np, spec, frame.clusters)
     torch.cuda.synchronize()
 
+    # ---- frame tail beside the next frame's shade (multi-GPU, C-ABI collectives): hides the all-reduce's latency.  Checked on
+    # every rank against the plain order (three frames each: same adapted luminance, same LDR image) before it is used.
+    tail_overlap = False
+    if world > 1 and not rehearsal and transport == "capi" and frame.split is None and not a.no_tail_overlap:
+        def three_frames():
+            frame.set_prev_luminance(0.18)
+            frame.hist.zero_()
+            for _ in range(3):
+                frame.render()
+            frame.finish()
+            torch.cuda.synchronize()
+            return float(frame.avg.cpu()[0]), int(frame.ldr.to(torch.int64).sum().item())
+        plain = three_frames()
+        ok = True
+        try:
+            frame.enable_tail_overlap()          # allocations only: no rank enters a collective the others do not
+        except Exception as e:   # noqa: BLE001
+            ok = False
+            notes.append(f"tail overlap not set up on rank {rank}: {e}")
+        if all_agree(ok):
+            tail_overlap = all_agree(three_frames() == plain)
+        if not tail_overlap:
+            frame._tail_overlap = False
+            notes.append("frame tail kept in order (the overlapped tail was not available or did not reproduce the plain order's frames)")
+        frame.set_prev_luminance(0.18)
+        frame.hist.zero_()
+        torch.cuda.synchronize()
+
     for _ in range(a.settle + a.warmup):   # the same count on every rank: frames carry collectives
         frame.render()
     torch.cuda.synchronize()
@@ -475,7 +506,8 @@ def main():
                    "tile": [spec.x0, spec.y0, spec.w, spec.h], "shaded_rect": [spec.sx0, spec.sy0, spec.sw, spec.sh],
                    "bloom_rect": [spec.ex0, spec.ey0, spec.ew, spec.eh],
                    "bloom_borders": "none" if world == 1 else (mode + (" (ring first: exchange overlaps the core's shade)" if frame.split is not None else "")), "collectives": "none" if world == 1 else ("gloo-rehearsal" if rehearsal else f"rccl-{transport}"),
-                   "mean_lights_per_pixel_by_rank": lp, "clock_settle_frames": a.settle},
+                   "mean_lights_per_pixel_by_rank": lp, "clock_settle_frames": a.settle,
+                   "frame_tail": "all-reduce + average + tone-map on a side stream, beside the next frame's shade" if tail_overlap else "in order"},
     }
     if rehearsal:
         out["rehearsal"] = "all ranks share cuda:0 (gloo + host copies): functional run, not a measurement"

@@ -279,6 +279,7 @@ class DeferredFrame:
         self.chain_a = ctx.alloc_bloom_chain(ew, eh)
         self.chain_b = ctx.alloc_bloom_chain(ew, eh)
         self.hist = ctx.zeros((HISTOGRAM_BINS,), torch.int32)
+        self._tail_overlap = False
         self.avg = ctx.zeros((1,), torch.float32)
         self.ldr = ctx.zeros((spec.h, spec.w), torch.int32)
         self.gb = None
@@ -463,10 +464,38 @@ class DeferredFrame:
             e1.record()
             shade_events.append((e0, e1))
         self.bloom_histogram()
+        if self._tail_overlap:
+            # the frame's tail — histogram all-reduce, average, tone-map — on the context's side stream: the collective's latency
+            # and the two small launches run beside the NEXT frame's cluster pass and shade, which write the other HDR /
+            # histogram buffer.  The join orders the side work of the frame BEFORE last ahead of this point (long finished).
+            self.ctx.side_join()
+            self.ctx.side_begin()
+            self.allreduce(self.hist)
+            self.average()
+            self.tonemap()
+            self.ctx.side_end()
+            self.hdr, self._hdr_alt = self._hdr_alt, self.hdr
+            self.hist, self._hist_alt = self._hist_alt, self.hist
+            return
         if self.allreduce is not None:
             self.allreduce(self.hist)
         self.average()
         self.tonemap()
+
+    def enable_tail_overlap(self):
+        """Multi-GPU frames whose histogram all-reduce runs on the context's own stream (the C ABI's RCCL communicator): double-
+        buffer the HDR target and the histogram so that a frame's tail can overlap the next frame's shade.  Throughput mode:
+        the LDR image of frame i is complete when frame i + 1's tail has been joined (or after a device synchronisation)."""
+        if self.allreduce is None or self.split is not None:
+            raise ValueError("tail overlap needs an all-reduce (world > 1) and the plain frame order")
+        self._hdr_alt = torch.zeros_like(self.hdr)
+        self._hist_alt = torch.zeros_like(self.hist)
+        self._tail_overlap = True
+
+    def finish(self):
+        """Wait (on the frame's stream) for an overlapped tail still in flight."""
+        if self._tail_overlap:
+            self.ctx.side_join()
 
     # ---- read-back helpers for tests ---------------------------------------------------------------
     def hdr_interior(self):

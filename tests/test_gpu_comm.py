@@ -91,6 +91,60 @@ def test_one_rank_communicator_runs_the_rccl_calls():
     assert r.returncode == 0 and "self-comm ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
 
+_TAIL_OVERLAP = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from direct12pbrrenderer_amd import scene, synth
+from direct12pbrrenderer_amd.api import PbrContext, comm_unique_id
+from direct12pbrrenderer_amd.pipeline import DeferredFrame, TileSpec
+import bench
+ctx = PbrContext(0)
+ctx.comm_init(1, 0, comm_unique_id())            # a real 1-rank RCCL communicator: the all-reduce is the C ABI's
+lut, env, sh = bench.build_ibl(ctx)
+W, H = 1280, 720
+cam = scene.Camera.reference_default(W, H)
+g = scene.make_global(cam, W, H, sh_pack=sh, delta_time=1.0 / 60.0)
+lights = synth.lights_in_view_box(64, cam)
+gbs = [synth.gbuffer_tile(0, 0, W, H, W, H), synth.gbuffer_tile(0, 0, W, H, W, H, rough_min=96)]
+def run(overlap):
+    fr = DeferredFrame(ctx, TileSpec(0, 0, W, H, W, H, 0), g, lights, lut, 512, env, 512, 5, allreduce=ctx.allreduce_hist)
+    fr.set_prev_luminance(0.18)
+    if overlap:
+        fr.enable_tail_overlap()
+    out = []
+    for i in range(7):
+        fr.upload_gbuffer(gbs[i %% 2])               # alternating inputs: a stale buffer would show
+        fr.render()
+        if overlap:
+            fr.finish()
+        ctx.sync()
+        out.append((fr.ldr.cpu().numpy().copy(), float(fr.avg.cpu()[0])))
+    # and back to back without a host synchronisation in between: the last frame must still be the same
+    for i in range(7, 12):
+        fr.upload_gbuffer(gbs[i %% 2])
+        fr.render()
+    fr.finish(); ctx.sync()
+    out.append((fr.ldr.cpu().numpy().copy(), float(fr.avg.cpu()[0])))
+    return out
+a, b = run(False), run(True)
+for i, ((la, va), (lb, vb)) in enumerate(zip(a, b)):
+    assert va == vb, (i, va, vb)
+    assert np.array_equal(la, lb), (i, int((la != lb).sum()))
+ctx.close()
+print("tail overlap ok")
+"""
+
+
+@pytest.mark.timeout(400)
+def test_overlapped_frame_tail_equals_the_plain_order():
+    """DeferredFrame.enable_tail_overlap (what bench.py's multi-GPU frames run when the histogram all-reduce is the C ABI's):
+    all-reduce + average + tone-map of frame i on the context's side stream beside frame i + 1's shade, HDR target and
+    histogram double-buffered.  With a 1-rank RCCL communicator on the one GPU: LDR image and adapted luminance of every
+    frame of an alternating input sequence identical to the plain order, synchronised frame by frame and back to back."""
+    r = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", _TAIL_OVERLAP % ROOT], capture_output=True, text=True)
+    assert r.returncode == 0 and "tail overlap ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_halo_pack_unpack_roundtrip(ctx):
     """The two halves of pbr_halo_exchange on their own (what a non-RCCL transport uses): staging layout = all send
     rectangles in peer order, then all recv rectangles."""

@@ -100,6 +100,15 @@ frame_times("cfg5-halo-ring-first", specs5[1], 256,
             "the same tile, border ring shaded first on the high-priority side stream (2 shade + 2 prefilter launches instead of 1 + 1) so that the exchange "
             "can overlap the core's shade (exchange itself not included: one GPU) — the single-GPU cost of the split", all_specs=specs5, rank=1, overlap=True)
 frame_times("cfg5-1gpu", TileSpec(0, 0, 7680, 4320, 7680, 4320, 0), 256, "the whole 7680x4320 frame on one GPU (the strong-scaling denominator)")
+# bench.py's DEFAULT multi-GPU workload (weak scaling: N x 8.3 Mpixel, 16:9): a rank's share of the N = 2 and N = 8 frames, halo mode
+from direct12pbrrenderer_amd.pipeline import grid_for_world, tile_for_rank  # noqa: E402
+for n_ranks, busiest in ((2, 0), (8, 1)):
+    cols, rows = grid_for_world(n_ranks)
+    tw, th = bench.weak_tile(n_ranks, cols, rows, 3840, 2160)
+    specs_w = [tile_for_rank(r, n_ranks, tw, th, layout=(cols, rows), halo=True) for r in range(n_ranks)]
+    frame_times(f"weak-N{n_ranks}-halo", specs_w[busiest], 256,
+                f"bench.py --gpus {n_ranks} (weak scaling): rank {busiest}'s {tw}x{th} tile of the {specs_w[0].full_w}x{specs_w[0].full_h} frame, halo mode "
+                "(exchange and all-reduce not included: one GPU); compare with cfg4 = the N = 1 frame", all_specs=specs_w, rank=busiest)
 
 # ---- SURVEY 8f "next" rows at the headline size: G-buffer encode (48 B in + 12 B out per pixel) and a full-screen sky
 W4, H4 = 3840, 2160
