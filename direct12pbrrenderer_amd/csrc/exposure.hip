@@ -129,6 +129,34 @@ __device__ __forceinline__ uint32_t tonemap_px(float r, float g, float b, float 
     return px;
 }
 
+// two pixels at once in the halves of packed-fp32 registers (v_pk_fma / v_pk_mul: half the VALU issues of the polynomial
+// part; the transcendentals stay one per value)
+typedef float tm2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ tm2 aces2(tm2 x) {
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    const tm2 num = x * (x * a + b), den = x * (x * c + d) + e;
+    tm2 q;
+    q.x = saturatef(num.x * rcp(den.x));
+    q.y = saturatef(num.y * rcp(den.y));
+    return q;
+}
+__device__ __forceinline__ void tonemap_px2(tm2 r, tm2 g, tm2 b, float inv_den, uint32_t& p0, uint32_t& p1) {
+    const tm2 m[3] = {aces2(r * inv_den), aces2(g * inv_den), aces2(b * inv_den)};
+    p0 = p1 = 0xFF000000u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        tm2 lg, gc;
+        lg.x = __builtin_amdgcn_logf(m[k].x); lg.y = __builtin_amdgcn_logf(m[k].y);
+        lg = lg * 0.454545f;
+        gc.x = m[k].x > 0.0f ? __builtin_amdgcn_exp2f(lg.x) : 0.0f;
+        gc.y = m[k].y > 0.0f ? __builtin_amdgcn_exp2f(lg.y) : 0.0f;
+        gc.x = saturatef(gc.x); gc.y = saturatef(gc.y);
+        const tm2 v = gc * 255.0f + 0.5f;
+        p0 |= (uint32_t)v.x << (8 * k);
+        p1 |= (uint32_t)v.y << (8 * k);
+    }
+}
+
 // persistent grid (<= 2048 blocks of 256), two pixels per lane per trip: 16-byte load, 8-byte store
 __device__ __forceinline__ void tonemap_pixels(const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
                                                float avg_lum, uint32_t* __restrict__ out, uint32_t out_pitch, bool aligned) {
@@ -146,8 +174,9 @@ __device__ __forceinline__ void tonemap_pixels(const pbr_half* __restrict__ hdr,
             const H4 p0 = *reinterpret_cast<const H4*>(&raw.x);
             const H4 p1 = *reinterpret_cast<const H4*>(&raw.z);
             uint2 o;
-            o.x = tonemap_px((float)p0.x, (float)p0.y, (float)p0.z, inv_den);
-            o.y = tonemap_px((float)p1.x, (float)p1.y, (float)p1.z, inv_den);
+            tm2 r2, g2, b2;
+            r2.x = (float)p0.x; r2.y = (float)p1.x; g2.x = (float)p0.y; g2.y = (float)p1.y; b2.x = (float)p0.z; b2.y = (float)p1.z;
+            tonemap_px2(r2, g2, b2, inv_den, o.x, o.y);
             *reinterpret_cast<uint2*>(out + (size_t)y * out_pitch + x) = o;
         } else {
             for (uint32_t xx = x; xx < min(x + 2, w); xx++) {
