@@ -6,14 +6,21 @@ A "step" is one frame of the hot path over one rank's tile: cluster build + cull
 histogram in its last kernel (+ RCCL all-reduce when N > 1), average, ACES tone-map — i.e. BASELINE.json configs[3]
 at N = 1.  Inputs (G-buffer, lights, LUT, prefiltered env, SH) are resident in HBM before the timed region.
 
-Multi-GPU (one process per GPU; `--gpus N` from a bare shell starts its own ranks through torch.distributed.run):
-  * default = WEAK scaling of the cfg4 scene: the same camera, lights and cluster grid rendered at a 16:9 frame of
+Multi-GPU (one process per GPU; `--gpus N` from a bare shell starts its own ranks through torch.distributed.run).  ONE launch
+measures both multi-GPU workloads:
+  * headline = WEAK scaling of the cfg4 scene: the same camera, lights and cluster grid rendered at a 16:9 frame of
     N x 8.3 Mpixel, cut into the most square tile grid (2x1, 2x2, 4x2 ...), one 4K-equivalent tile per GPU — per-pixel
     light lists are identical at every N because the scene is fixed in uv;
-  * `--frame 7680x4320 --layout 2x4` = BASELINE cfg5 (STRONG scaling: 2 rows x 4 cols of 1920x2160 tiles).
+  * `cfg5` sub-record = BASELINE configs[4] (STRONG scaling): the 7680x4320 frame cut over the N ranks (N = 8: 2 rows x 4
+    cols of 1920x2160), with the single-GPU time of the same 8K frame measured on rank 0 as the denominator.
+  `--cfg5` (= `--frame 7680x4320`) makes the strong-scaling frame the headline instead.
+Frames are timed IN ORDER at every N (the like-for-like figure `value` is computed from); for N > 1 the same frames with
+their tail — histogram all-reduce, average, tone-map — on a side stream beside the next frame's shade are timed as well
+and reported next to it (`ms_per_step_tail_overlapped`).
 Bloom across tile borders: `--mode halo` (default) shades interior + 4 px and exchanges prefiltered half-res strips
 (pbr_halo_exchange: RCCL send/recv over xGMI); `--mode apron` shades a 256-px apron instead (no data-path collective).
-The only other collective is the 256-bin histogram all-reduce.  `value` counts interior pixels only.
+The only other collective is the 256-bin histogram all-reduce (on its own communicator).  `value` counts interior pixels.
+`host_graph` = the same frames driven by the C++ pass graph (libpbr_host.so: RenderScheduler -> FrameGraph -> passes -> C ABI).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -26,6 +33,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -49,6 +57,8 @@ MEASURED_CLOCK_HZ = 2.1e9
 # algorithmic bytes per pixel: unique bytes a reference pass must read + write once
 BYTES_PER_PX = {"shade": 25.0, "bloom": 75.75, "histogram": 8.0, "tonemap": 12.0}
 ENV_SIZE, LUT_RES, N_LIGHTS = 512, 512, 256
+CFG5_FRAME = (7680, 4320)       # BASELINE.json configs[4]
+CFG5_GRID = {8: (4, 2)}         # (cols, rows): "tiled 2x4" = 2 rows of 4 tiles; other N: the most square grid
 
 
 def parse():
@@ -58,11 +68,13 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--width", type=int, default=3840, help="single-GPU frame / per-GPU tile budget (weak scaling)")
     p.add_argument("--height", type=int, default=2160)
-    p.add_argument("--frame", default=None, help="WxH: strong scaling of this frame over the ranks (cfg5: 7680x4320)")
+    p.add_argument("--frame", default=None, help="WxH: strong scaling of this frame over the ranks becomes the headline")
+    p.add_argument("--cfg5", action="store_true", help="= --frame 7680x4320 (BASELINE configs[4]; at N = 8: --layout 2x4)")
+    p.add_argument("--no-cfg5", action="store_true", help="N > 1, weak-scaling headline: skip the cfg5 (8K strong-scaling) sub-record")
     p.add_argument("--layout", default=None, help="RxC tile grid, rows x cols (cfg5: 2x4); default: most square")
     p.add_argument("--mode", choices=["halo", "apron"], default="halo", help="bloom across tile borders (N > 1)")
     p.add_argument("--transport", choices=["capi", "torch"], default="capi",
-                   help="collectives through the C ABI's own RCCL communicator or through torch.distributed (also RCCL)")
+                   help="collectives through the C ABI's own RCCL communicators or through torch.distributed (also RCCL)")
     p.add_argument("--overlap", action="store_true",
                    help="halo mode: shade the tile's border ring first (side stream) and exchange its strips while the core is shaded. "
                         "Off by default: on one GPU the split costs 73 us (cfg5 tile) / 120 us (4K-equivalent tile) because the ring's "
@@ -70,11 +82,11 @@ def parse():
     p.add_argument("--settle", type=int, default=300,
                    help="untimed frames rendered before the W warm-up steps so that the device's clock has ramped (DVFS: a fresh process "
                         "runs its first ~100 ms at a lower clock; with the default K the timed region is only ~25 ms).  Reported in config")
-    p.add_argument("--no-tail-overlap", action="store_true",
-                   help="N > 1: keep histogram all-reduce, average and tone-map of a frame on the frame's stream (default: on the context's side "
-                        "stream, beside the next frame's shade, HDR target and histogram double-buffered)")
+    p.add_argument("--no-tail-overlap", action="store_true", help="N > 1: do not time the overlapped-tail variant")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--no-host-graph", action="store_true", help="skip the C++ pass-graph leg (host_graph block)")
+    p.add_argument("--deadline", type=float, default=240.0, help="seconds a collective phase may take before the rank gives up (N > 1)")
     return p.parse_args()
 
 
@@ -98,16 +110,58 @@ def spawn_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
-def build_ibl(ctx):
-    """One-shot IBL precompute with the HIP kernels (not timed): LUT 512^2, sky 512^2 -> env 5 mips, SH9."""
+class Watchdog:
+    """A rank blocked in a collective whose peers never arrive (RCCL kernel spinning, ncclCommInitRank waiting) cannot be
+    unblocked from inside: each collective phase runs under a deadline, and a rank that misses it exits the process —
+    after rank 0 has written whatever record is complete.  Every rank arms the same phases, so all of them leave."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.deadline, self.what, self.on_fire = None, "", None
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                d, what, fire = self.deadline, self.what, self.on_fire
+            if d is not None and time.monotonic() > d:
+                print(f"bench.py: '{what}' did not finish before its deadline — giving up on this rank", file=sys.stderr, flush=True)
+                code = 3
+                try:
+                    if fire:
+                        code = fire(what)
+                finally:
+                    os._exit(code)
+
+    def phase(self, seconds, what):
+        wd = self
+
+        class _P:
+            def __enter__(self_inner):
+                with wd.lock:
+                    wd.deadline, wd.what = time.monotonic() + seconds, what
+
+            def __exit__(self_inner, *exc):
+                with wd.lock:
+                    wd.deadline = None
+                return False
+        return _P()
+
+
+def build_ibl(ctx, want_sky=False):
+    """One-shot IBL precompute with the HIP kernels (not timed): LUT 512^2, sky 512^2 -> env 5 mips, SH9.
+    want_sky: also return the host copy of the sky cube (the C++ pass graph builds its own IBL from it)."""
     sky_mips = int(np.log2(ENV_SIZE)) + 1
-    sky = ctx.upload(synth.env_cube(ENV_SIZE, sky_mips))
+    sky_np = synth.env_cube(ENV_SIZE, sky_mips)
+    sky = ctx.upload(sky_np)
     ctx.cube_gen_mips(sky, ENV_SIZE, sky_mips)
     lut = ctx.brdf_lut(LUT_RES)
     env = ctx.prefilter_env(sky, ENV_SIZE, sky_mips, ENV_SIZE, ENV_MIPS)
     sh = ctx.sh9_project(sky, ENV_SIZE, sky_mips)
     ctx.sync()
-    return lut, env, sh.cpu().numpy()
+    return (lut, env, sh.cpu().numpy(), sky_np) if want_sky else (lut, env, sh.cpu().numpy())
 
 
 def src_stamp():
@@ -246,8 +300,328 @@ def weak_tile(world, cols, rows, base_w, base_h):
     return int(round(base_w * s / cols / 16)) * 16, int(round(base_h * s / rows / 16)) * 16
 
 
+class Job:
+    """What every workload of one launch shares: the context, the process group, the IBL and the communicators."""
+
+    def __init__(self, a, ctx, dist, rank, world, rehearsal, flag_dev, wd):
+        self.a, self.ctx, self.dist, self.rank, self.world, self.rehearsal, self.flag_dev, self.wd = a, ctx, dist, rank, world, rehearsal, flag_dev, wd
+        self.notes = []
+        self.capi_comm = False
+
+    def all_agree(self, ok):
+        """True iff every rank says ok (fallback decisions must be taken by all ranks together)."""
+        if not self.dist:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.flag_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def max_over_ranks(self, v):
+        if not self.dist:
+            return float(v)
+        t = torch.tensor([v], dtype=torch.float64, device=self.flag_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def make_allreduce(self, kind):
+        if self.world == 1:
+            return None
+        if kind == "capi":
+            return self.ctx.allreduce_hist
+        dist, ctx = self.dist, self.ctx
+        if self.rehearsal:
+            def f(h):
+                ctx.sync()
+                t = h.cpu()
+                dist.all_reduce(t)
+                h.copy_(t)
+            return f
+        return lambda h: dist.all_reduce(h)   # RCCL, int32 sum == uint32 sum bit for bit
+
+
+def build_frame(job, make_spec, g, lights, mode, transport, overlap):
+    """LOCAL half of a candidate configuration: this rank's DeferredFrame (tile layout, halo plan, staging, buffers) and
+    its G-buffer.  Raises on anything inconsistent — before any rank has entered a collective for this candidate."""
+    world, rank = job.world, job.rank
+    halo = mode == "halo" and world > 1
+    specs = [make_spec(r, halo) for r in range(world)]
+    spec = specs[rank]
+    ht = HaloTransport("host" if job.rehearsal else transport, job.dist) if halo else None
+    fr = DeferredFrame(job.ctx, spec, g, lights, job.lut, LUT_RES, job.env, ENV_SIZE, ENV_MIPS, allreduce=job.make_allreduce(transport),
+                       all_specs=specs, rank=rank, halo_transport=ht, overlap=overlap)
+    if halo:   # what pbr_halo_exchange would refuse, found here instead of inside the group call
+        pitch, rows = spec.ew // 2, spec.eh // 2
+        for peer, snd, rcv in fr.halo_plan_local:
+            for q in (snd, rcv):
+                if q and (q[0] + q[2] > pitch or q[1] + q[3] > rows):
+                    raise RuntimeError(f"halo rectangle {q} of peer {peer} leaves the {pitch}x{rows} level-1 plane")
+            if not (0 <= peer < world) or peer == rank:
+                raise RuntimeError(f"bad halo peer {peer}")
+    gb_np = synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h)
+    fr.upload_gbuffer(gb_np)
+    fr.set_prev_luminance(0.18)
+    return fr, gb_np
+
+
+def verify_frame(job, fr):
+    """COLLECTIVE half: one frame of the very sequence the timed frames run, then: the all-reduced histogram must count
+    every pixel of the whole frame exactly once, and in halo mode every level-1 texel of E must have arrived, with the
+    sender's checksum.  Every rank runs the same collectives whatever it finds; a finding is raised at the end."""
+    spec, dist, rank, world = fr.spec, job.dist, job.rank, job.world
+    halo = spec.halo
+    if halo:
+        fr.level1.fill_(777.0)
+    fr.clustered()
+    if fr.split is not None:
+        fr.shade_and_bloom_overlapped()
+    else:
+        fr.shade()
+        fr.bloom_histogram()
+    if fr.allreduce is not None:
+        fr.allreduce(fr.hist)
+    job.ctx.sync()
+    problem = None
+    counted = int(fr.hist.cpu().to(torch.int64).sum())
+    if counted != spec.full_w * spec.full_h:
+        problem = f"histogram counts {counted} pixels, frame has {spec.full_w * spec.full_h}"
+    if halo:
+        if bool((fr.level1 == 777.0).any()):
+            problem = problem or "halo exchange left level-1 texels of the extended tile unfilled"
+        pw = spec.ew // 2
+        l1 = fr.level1.view(spec.eh // 2, pw, 4).view(torch.int16).to(torch.int64)
+
+        def csum(r):
+            return int(l1[r[1]:r[1] + r[3], r[0]:r[0] + r[2]].sum())
+        mine = {}
+        for peer, snd, rcv in fr.halo_plan_local:
+            if snd:
+                mine[("s", rank, peer)] = csum(snd)
+            if rcv:
+                mine[("r", peer, rank)] = csum(rcv)
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        sent = {k[1:]: v for d in every for k, v in d.items() if k[0] == "s"}
+        for k, v in mine.items():
+            if k[0] == "r" and sent.get(k[1:]) != v:
+                problem = problem or f"halo strip {k[1]} -> {k[2]} arrived with another checksum"
+    if problem:
+        raise RuntimeError(problem)
+    fr.hist.zero_()
+    fr.set_prev_luminance(0.18)
+
+
+def run_workload(job, name, scaling, make_spec, full_w, full_h, cols, rows, steps, warmup, settle, want_stage_timing):
+    """Set up, verify and time one workload on all ranks.  Returns a dict (rank 0 reports it)."""
+    a, ctx, dist, rank, world, rehearsal = job.a, job.ctx, job.dist, job.rank, job.world, job.rehearsal
+    cam = scene.Camera.reference_default(full_w, full_h)
+    g = scene.make_global(cam, full_w, full_h, sh_pack=job.sh, delta_time=1.0 / 60.0)
+    lights = synth.lights_in_view_box(N_LIGHTS, cam)
+    notes = []
+
+    want_overlap = a.mode == "halo" and a.overlap
+    if world == 1:
+        candidates = [("single", "none", False)]
+    elif rehearsal:
+        candidates = [(a.mode, "torch", want_overlap)] + ([(a.mode, "torch", False)] if want_overlap else []) + \
+                     ([("apron", "torch", False)] if a.mode == "halo" else [])
+    else:
+        first = "capi" if job.capi_comm else "torch"
+        candidates = [(a.mode, first, want_overlap)]
+        if want_overlap:
+            candidates.append((a.mode, first, False))
+        if first == "capi":
+            candidates.append((a.mode, "torch", False))
+        if a.mode == "halo":
+            candidates.append(("apron", "torch", False))
+    frame = None
+    for mode, transport, overlap in candidates:
+        label = f"{mode}/{transport}{'/overlap' if overlap else ''}"
+        ok, err = True, None
+        try:
+            frame, gb_np = build_frame(job, make_spec, g, lights, mode, transport, overlap)
+        except Exception as e:   # noqa: BLE001
+            ok, err = False, f"{label} could not be set up on rank {rank}: {e}"
+        if not job.all_agree(ok):    # nobody has entered a collective of this candidate yet
+            notes.append(err or f"{label} could not be set up on another rank")
+            frame = None
+            continue
+        with job.wd.phase(a.deadline, f"{name}: verification frame of {label}"):
+            try:
+                verify_frame(job, frame)
+            except Exception as e:   # noqa: BLE001
+                ok, err = False, f"{label} failed verification on rank {rank}: {e}"
+            if job.all_agree(ok):
+                break
+        notes.append(err or f"{label} failed on another rank")
+        frame = None
+        torch.cuda.synchronize()
+    if frame is None:
+        raise SystemExit(f"bench.py: no configuration of '{name}' passed its verification frame: " + "; ".join(notes))
+    spec = frame.spec
+    lights_px = mean_lights_per_pixel(g, gb_np, spec, frame.clusters)
+    torch.cuda.synchronize()
+
+    def timed(n_settle, n_warm, n_steps, shade_events=None):
+        with job.wd.phase(a.deadline, f"{name}: timed frames"):
+            for _ in range(n_settle + n_warm):   # the same count on every rank: frames carry collectives
+                frame.render()
+            frame.finish()
+            job.barrier()
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                frame.render(shade_events if (shade_events is not None and i % 5 == 0) else None)
+            frame.finish()
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            return job.max_over_ranks(time.perf_counter() - t0)
+
+    # ---- the headline: frames in order (at N = 1 there is nothing else)
+    # HIP events bracket the dominant kernel's launch inside the timed region (the ctx launches on torch's current stream, so
+    # torch events sit on the right stream).  Two marker packets cost ~0.8 % of a frame, so only every fifth frame carries them.
+    shade_events = [] if (want_stage_timing and not a.no_kernel_timing) else None
+    dt = timed(settle, warmup, steps, shade_events)
+    ms_per_step = dt / steps * 1e3
+
+    # ---- the same frames with the tail beside the next frame's shade (multi-GPU, C-ABI collectives): hides the all-reduce's
+    # latency.  Checked on every rank against the plain order (three frames each: same adapted luminance, same LDR image).
+    ms_overlapped = None
+    if world > 1 and not rehearsal and transport == "capi" and frame.split is None and not a.no_tail_overlap:
+        with job.wd.phase(a.deadline, f"{name}: overlapped-tail check"):
+            def three_frames():
+                frame.set_prev_luminance(0.18)
+                frame.hist.zero_()
+                for _ in range(3):
+                    frame.render()
+                frame.finish()
+                torch.cuda.synchronize()
+                return float(frame.avg.cpu()[0]), int(frame.ldr.to(torch.int64).sum().item())
+            plain = three_frames()
+            ok = True
+            try:
+                frame.enable_tail_overlap(capi_allreduce=True)   # allocations only: no rank enters a collective the others do not
+            except Exception as e:   # noqa: BLE001
+                ok = False
+                notes.append(f"tail overlap not set up on rank {rank}: {e}")
+            good = job.all_agree(ok) and job.all_agree(three_frames() == plain)
+        if good:
+            ms_overlapped = timed(20, warmup, steps) / steps * 1e3
+        else:
+            notes.append("overlapped frame tail not timed (not available, or it did not reproduce the plain order's frames)")
+        frame._tail_overlap = False
+        frame.set_prev_luminance(0.18)
+        frame.hist.zero_()
+        torch.cuda.synchronize()
+
+    lp = [None] * world
+    if dist:
+        dist.all_gather_object(lp, round(lights_px, 3))
+    else:
+        lp = [round(lights_px, 3)]
+    total_px = spec.full_w * spec.full_h
+    res = {"name": name, "scaling": scaling, "frame_obj": frame, "g": g, "lights": lights, "gb_np": gb_np, "spec": spec, "cols": cols, "rows": rows,
+           "ms_per_step": ms_per_step, "value": total_px / (ms_per_step * 1e-3) / 1e6, "ms_overlapped": ms_overlapped,
+           "mode": mode, "transport": transport, "notes": notes, "lights_px": lp, "shade_events": shade_events, "total_px": total_px}
+    return res
+
+
+def workload_config(job, r, settle):
+    spec, world, rows, cols = r["spec"], job.world, r["rows"], r["cols"]
+    if world == 1:
+        workload = f"{spec.full_w}x{spec.full_h} G-buffer"
+    elif r["scaling"] == "weak":
+        workload = (f"weak scaling of the cfg4 scene: {spec.full_w}x{spec.full_h} frame (16:9, {world} x 8.3 Mpixel) as {rows} rows x {cols} cols of "
+                    f"{spec.w}x{spec.h} tiles, one per GPU")
+    else:
+        workload = f"strong scaling: {spec.full_w}x{spec.full_h} frame as {rows} rows x {cols} cols of {spec.w}x{spec.h} tiles, one per GPU"
+    workload += f"; {N_LIGHTS} clustered lights + IBL (env {ENV_SIZE}^2 x{ENV_MIPS} mips, LUT {LUT_RES}^2, SH9), auto-exposure + ACES + 9-tap bloom"
+    fr = r["frame_obj"]
+    cfg = {"workload": workload, "frame": [spec.full_w, spec.full_h], "layout_rows_x_cols": f"{rows}x{cols}",
+           "tile": [spec.x0, spec.y0, spec.w, spec.h], "shaded_rect": [spec.sx0, spec.sy0, spec.sw, spec.sh],
+           "bloom_rect": [spec.ex0, spec.ey0, spec.ew, spec.eh],
+           "bloom_borders": "none" if world == 1 else (r["mode"] + (" (ring first: exchange overlaps the core's shade)" if fr.split is not None else "")),
+           "collectives": "none" if world == 1 else ("gloo-rehearsal" if job.rehearsal else f"rccl-{r['transport']}"
+                                                     + (" (halo exchange and histogram all-reduce on separate communicators)" if r["transport"] == "capi" else "")),
+           "mean_lights_per_pixel_by_rank": r["lights_px"], "clock_settle_frames": settle,
+           "frame_tail": "in order (value, ms_per_step)"}
+    if r["ms_overlapped"] is not None:
+        cfg["ms_per_step_tail_overlapped"] = round(r["ms_overlapped"], 4)
+        cfg["value_tail_overlapped"] = round(r["total_px"] / (r["ms_overlapped"] * 1e-3) / 1e6, 2)
+        cfg["frame_tail"] += "; *_tail_overlapped = the same frames with all-reduce + average + tone-map on a side stream, beside the next frame's shade"
+    if r["notes"] or job.notes:
+        cfg["notes"] = job.notes + r["notes"]
+    return cfg
+
+
+def host_graph_leg(job, r, frames):
+    """The same workload driven by the C++ pass graph (libpbr_host.so: RenderScheduler -> FrameGraph -> the reference-shaped
+    passes -> HipCommandList -> C ABI): ms per frame with every reference dispatch issued one by one and with fused passes, each
+    with the reference's per-frame fence wait and in throughput mode (3 frames in flight).  Outside the timed region.  Multi-GPU:
+    pbrh_create_tile in the workload's mode, halo exchange + histogram all-reduce over the renderer's own RCCL communicators."""
+    from direct12pbrrenderer_amd.host import HostRenderer
+    from direct12pbrrenderer_amd.api import comm_unique_id
+    a, world, rank, dist = job.a, job.world, job.rank, job.dist
+    spec = r["spec"]
+    halo = r["mode"] == "halo"
+    ok, err, hr = True, None, None
+    try:
+        tile = (spec.full_w, spec.full_h, r["cols"], r["rows"], rank, halo) if world > 1 else None
+        hr = HostRenderer(job.ctx.device, spec.full_w, spec.full_h, ENV_SIZE, LUT_RES, tile=tile)
+        hr.set_skybox(job.sky_np, ENV_SIZE)
+        hr.set_lights(r["lights"])
+        if world > 1 and not halo:
+            raise RuntimeError("apron mode is not driven through the host graph here")
+        hr.set_gbuffer(r["gb_np"])
+        hr.set_initial_luminance(0.18)
+    except Exception as e:   # noqa: BLE001
+        ok, err = False, f"host graph not set up on rank {rank}: {e}"
+    if not job.all_agree(ok):
+        if hr:
+            hr.close()
+        return {"error": err or "host graph not set up on another rank"}
+    out = {"path": "libpbr_host.so: RenderScheduler::ExecutePipeline -> FrameGraph::Execute -> pass classes -> HipCommandList -> C ABI (include/pbr_hip.h)",
+           "frames_per_figure": frames}
+    try:
+        with job.wd.phase(a.deadline, "host graph leg"):
+            if world > 1:
+                ids = [comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                hr.comm_init(world, rank, ids[0])
+            hr.render()                       # one-shot IBL passes + first frame
+            for fused in (0, 1):
+                hr.set_fused(fused)
+                for in_flight in (1, 3):
+                    hr.set_frames_in_flight(in_flight)
+                    hr.render_n(max(frames // 2, 5))
+                    if dist:
+                        dist.barrier()
+                    ms = job.max_over_ranks(hr.render_n(frames))
+                    key = ("fused" if fused else "dispatch_by_dispatch") + ("_fence_per_frame" if in_flight == 1 else "_throughput")
+                    out[key + "_ms"] = round(ms, 4)
+                out["dispatches_per_frame_" + ("fused" if fused else "dispatch_by_dispatch")] = hr.dispatch_count()
+        best = out["fused_throughput_ms"]
+        out["Mpixel_s_fused_throughput"] = round(r["total_px"] / (best * 1e-3) / 1e6, 1)
+        out["vs_python_driven_frame"] = round(best / r["ms_per_step"], 4)
+        out["note"] = ("fence_per_frame = D3D12Device::EndFrame's wait after every frame (the reference's loop); throughput = 3 frames in flight; "
+                       "the host graph resolves the sky on stencil == 0 pixels every frame like the reference (SkyboxPass), the Python-driven frame does not")
+    except Exception as e:   # noqa: BLE001
+        out["error"] = f"rank {rank}: {e}"
+    finally:
+        hr.close()
+    return out
+
+
 def main():
     a = parse()
+    if a.cfg5 and not a.frame:
+        a.frame = f"{CFG5_FRAME[0]}x{CFG5_FRAME[1]}"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -279,271 +653,106 @@ def main():
     ctx = PbrContext(dev)
     flag_dev = "cpu" if rehearsal else f"cuda:{dev}"
 
-    def all_agree(ok):
-        """True iff every rank says ok (the fallback decisions below must be taken by all ranks together)."""
-        if not dist:
-            return bool(ok)
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(t.item())
+    # ---- the record so far, for a rank that has to give up in a later (optional) phase
+    state = {"out": None}
 
-    # ---- workload: which frame, which tile grid
-    layout = parse_layout(a.layout) if a.layout else None
-    cols, rows = grid_for_world(world, layout)
-    if a.frame:
-        fw, fh = (int(v) for v in a.frame.lower().split("x"))
-        scaling = "strong"
+    def emit(out):
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if rank == 0 and out is not None:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-        def make_spec(r, halo):
-            return tile_of_frame(r, world, fw, fh, layout=(cols, rows), halo=halo)
-    else:
-        tw, th = weak_tile(world, cols, rows, a.width, a.height)
-        scaling = "weak"
+    def on_deadline(what):
+        out = state["out"]
+        if out is None:
+            return 3
+        out.setdefault("config", {}).setdefault("notes", []).append(f"gave up on '{what}' after {a.deadline:.0f} s; the record holds what was measured before")
+        emit(out)
+        return 0
 
-        def make_spec(r, halo):
-            return tile_for_rank(r, world, tw, th, layout=(cols, rows), halo=halo)
+    wd = Watchdog()
+    wd.on_fire = on_deadline
+    job = Job(a, ctx, dist, rank, world, rehearsal, flag_dev, wd)
+    job.lut, job.env, job.sh, job.sky_np = build_ibl(ctx, want_sky=True)
 
-    lut, env, sh = build_ibl(ctx)
-    spec0 = make_spec(rank, False)
-    cam = scene.Camera.reference_default(spec0.full_w, spec0.full_h)
-    g = scene.make_global(cam, spec0.full_w, spec0.full_h, sh_pack=sh, delta_time=1.0 / 60.0)
-    lights = synth.lights_in_view_box(N_LIGHTS, cam)
-
-    # ---- collectives: the C ABI's own RCCL communicator first, torch.distributed (also RCCL) as the fallback
-    notes = []
-    capi_comm = False
+    # ---- collectives: the C ABI's own RCCL communicators first, torch.distributed (also RCCL) as the fallback
     if world > 1 and not rehearsal and a.transport == "capi":
         ok = True
-        try:
-            from direct12pbrrenderer_amd.api import comm_unique_id
-            ids = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init(world, rank, ids[0])
-        except Exception as e:   # noqa: BLE001 — any failure here means "use the other RCCL transport"
-            ok = False
-            notes.append(f"pbr_comm_init failed on rank {rank}: {e}")
-        capi_comm = all_agree(ok)
-        if not capi_comm:
-            notes.append("C-ABI RCCL communicator unavailable: collectives through torch.distributed")
+        with wd.phase(a.deadline, "pbr_comm_init"):
+            try:
+                from direct12pbrrenderer_amd.api import comm_unique_id
+                ids = [comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ctx.comm_init(world, rank, ids[0])
+            except Exception as e:   # noqa: BLE001 — any failure here means "use the other RCCL transport"
+                ok = False
+                job.notes.append(f"pbr_comm_init failed on rank {rank}: {e}")
+            job.capi_comm = job.all_agree(ok)
+        if not job.capi_comm:
+            job.notes.append("C-ABI RCCL communicators unavailable: collectives through torch.distributed")
 
-    def make_allreduce(kind):
-        if world == 1:
-            return None
-        if kind == "capi":
-            return ctx.allreduce_hist
-        if rehearsal:
-            def f(h):
-                ctx.sync()
-                t = h.cpu()
-                dist.all_reduce(t)
-                h.copy_(t)
-            return f
-        return lambda h: dist.all_reduce(h)   # RCCL, int32 sum == uint32 sum bit for bit
+    # ---- workloads: which frame, which tile grid
+    layout = parse_layout(a.layout) if a.layout else None
 
-    def setup(mode, transport, overlap):
-        """Build this rank's frame for (mode, transport), render one verification frame and check it:
-        the all-reduced histogram must count every pixel of the whole frame exactly once, and in halo mode every
-        level-1 texel of E must have arrived, with the sender's checksum.  Returns (frame, gb_np) or raises."""
-        halo = mode == "halo" and world > 1
-        specs = [make_spec(r, halo) for r in range(world)]
-        spec = specs[rank]
-        ht = None
-        if halo:
-            ht = HaloTransport("host" if rehearsal else transport, dist)
-        fr = DeferredFrame(ctx, spec, g, lights, lut, LUT_RES, env, ENV_SIZE, ENV_MIPS, allreduce=make_allreduce(transport),
-                           all_specs=specs, rank=rank, halo_transport=ht, overlap=overlap)
-        gb_np = synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h)
-        fr.upload_gbuffer(gb_np)
-        fr.set_prev_luminance(0.18)
-        if halo:
-            fr.level1.fill_(777.0)
-        fr.clustered()
-        if fr.split is not None:       # the very sequence the timed frames run
-            fr.shade_and_bloom_overlapped()
-        else:
-            fr.shade()
-            fr.bloom_histogram()
-        if fr.allreduce is not None:
-            fr.allreduce(fr.hist)
-        ctx.sync()
-        # every rank runs the SAME sequence of collectives below whatever it finds; a finding is raised at the end
-        problem = None
-        counted = int(fr.hist.cpu().to(torch.int64).sum())
-        if counted != spec.full_w * spec.full_h:
-            problem = f"histogram counts {counted} pixels, frame has {spec.full_w * spec.full_h}"
-        if halo:
-            if bool((fr.level1 == 777.0).any()):
-                problem = problem or "halo exchange left level-1 texels of the extended tile unfilled"
-            pw = spec.ew // 2
-            l1 = fr.level1.view(spec.eh // 2, pw, 4).view(torch.int16).to(torch.int64)
+    def strong(fw, fh, grid):
+        cols, rows = grid_for_world(world, grid)
+        return ("strong", lambda r, halo: tile_of_frame(r, world, fw, fh, layout=(cols, rows), halo=halo), fw, fh, cols, rows)
 
-            def csum(r):
-                return int(l1[r[1]:r[1] + r[3], r[0]:r[0] + r[2]].sum())
-            mine = {}
-            for peer, snd, rcv in fr.halo_plan_local:
-                if snd:
-                    mine[("s", rank, peer)] = csum(snd)
-                if rcv:
-                    mine[("r", peer, rank)] = csum(rcv)
-            every = [None] * world
-            dist.all_gather_object(every, mine)
-            sent = {k[1:]: v for d in every for k, v in d.items() if k[0] == "s"}
-            for k, v in mine.items():
-                if k[0] == "r" and sent.get(k[1:]) != v:
-                    problem = problem or f"halo strip {k[1]} -> {k[2]} arrived with another checksum"
-        if problem:
-            raise RuntimeError(problem)
-        fr.hist.zero_()
-        fr.set_prev_luminance(0.18)
-        return fr, gb_np
-
-    want_overlap = a.mode == "halo" and a.overlap
-    if world == 1:
-        candidates = [("single", "none", False)]
-    elif rehearsal:
-        candidates = [(a.mode, "torch", want_overlap)] + ([(a.mode, "torch", False)] if want_overlap else []) + \
-                     ([("apron", "torch", False)] if a.mode == "halo" else [])
+    if a.frame:
+        fw, fh = (int(v) for v in a.frame.lower().split("x"))
+        primary = strong(fw, fh, layout or (CFG5_GRID.get(world) if (fw, fh) == CFG5_FRAME else None))
     else:
-        first = "capi" if capi_comm else "torch"
-        candidates = [(a.mode, first, want_overlap)]
-        if want_overlap:
-            candidates.append((a.mode, first, False))
-        if first == "capi":
-            candidates.append((a.mode, "torch", False))
-        if a.mode == "halo":
-            candidates.append(("apron", "torch", False))
-    frame = None
-    for mode, transport, overlap in candidates:
-        ok, err = True, None
-        try:
-            frame, gb_np = setup(mode, transport, overlap)
-        except Exception as e:   # noqa: BLE001
-            ok, err = False, f"{mode}/{transport}{'/overlap' if overlap else ''} failed verification on rank {rank}: {e}"
-        if all_agree(ok):
-            break
-        notes.append(err or f"{mode}/{transport}{'/overlap' if overlap else ''} failed on another rank")
-        frame = None
-        torch.cuda.synchronize()
-    if frame is None:
-        raise SystemExit("bench.py: no multi-GPU configuration passed its verification frame: " + "; ".join(notes))
-    spec = frame.spec
-    lights_px = mean_lights_per_pixel(g, gb_np, spec, frame.clusters)
-    torch.cuda.synchronize()
+        cols, rows = grid_for_world(world, layout)
+        tw, th = weak_tile(world, cols, rows, a.width, a.height)
+        primary = ("weak", lambda r, halo: tile_for_rank(r, world, tw, th, layout=(cols, rows), halo=halo), cols * tw, rows * th, cols, rows)
 
-    # ---- frame tail beside the next frame's shade (multi-GPU, C-ABI collectives): hides the all-reduce's latency.  Checked on
-    # every rank against the plain order (three frames each: same adapted luminance, same LDR image) before it is used.
-    tail_overlap = False
-    if world > 1 and not rehearsal and transport == "capi" and frame.split is None and not a.no_tail_overlap:
-        def three_frames():
-            frame.set_prev_luminance(0.18)
-            frame.hist.zero_()
-            for _ in range(3):
-                frame.render()
-            frame.finish()
-            torch.cuda.synchronize()
-            return float(frame.avg.cpu()[0]), int(frame.ldr.to(torch.int64).sum().item())
-        plain = three_frames()
-        ok = True
-        try:
-            frame.enable_tail_overlap()          # allocations only: no rank enters a collective the others do not
-        except Exception as e:   # noqa: BLE001
-            ok = False
-            notes.append(f"tail overlap not set up on rank {rank}: {e}")
-        if all_agree(ok):
-            tail_overlap = all_agree(three_frames() == plain)
-        if not tail_overlap:
-            frame._tail_overlap = False
-            notes.append("frame tail kept in order (the overlapped tail was not available or did not reproduce the plain order's frames)")
-        frame.set_prev_luminance(0.18)
-        frame.hist.zero_()
-        torch.cuda.synchronize()
-
-    for _ in range(a.settle + a.warmup):   # the same count on every rank: frames carry collectives
-        frame.render()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events bracket the dominant kernel's launch inside the timed region (the ctx launches on torch's
-    # current stream, so torch events sit on the right stream).  Two marker packets cost ~0.8 % of a frame, so only
-    # every fifth frame carries them.
-    shade_events = None if a.no_kernel_timing else []
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        frame.render(shade_events if (shade_events is not None and i % 5 == 0) else None)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=flag_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        lp = [None] * world
-        dist.all_gather_object(lp, round(lights_px, 3))
-    else:
-        lp = [round(lights_px, 3)]
-    ms_per_step = dt / a.steps * 1e3
-    total_px = spec.full_w * spec.full_h
-    value = total_px / (ms_per_step * 1e-3) / 1e6
-
-    shaded_px = spec.sw * spec.sh
-    if world == 1:
-        workload = f"{spec.full_w}x{spec.full_h} G-buffer"
-    elif scaling == "weak":
-        workload = (f"weak scaling of the cfg4 scene: {spec.full_w}x{spec.full_h} frame (16:9, {world} x 8.3 Mpixel) as {rows} rows x {cols} cols of "
-                    f"{spec.w}x{spec.h} tiles, one per GPU")
-    else:
-        workload = f"strong scaling: {spec.full_w}x{spec.full_h} frame as {rows} rows x {cols} cols of {spec.w}x{spec.h} tiles, one per GPU"
-    workload += (f"; {N_LIGHTS} clustered lights + IBL (env {ENV_SIZE}^2 x{ENV_MIPS} mips, LUT {LUT_RES}^2, SH9), auto-exposure + ACES + 9-tap bloom")
+    res = run_workload(job, "headline", primary[0], primary[1], primary[2], primary[3], primary[4], primary[5], a.steps, a.warmup, a.settle,
+                       want_stage_timing=True)
+    frame, spec, g, lights = res["frame_obj"], res["spec"], res["g"], res["lights"]
     out = {
         "metric": "shaded Mpixel/s at 4K G-buffer (full deferred frame: clustered shade + bloom + auto-exposure + ACES)",
-        "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling if world > 1 else "weak", "vs_baseline": None,
+        "value": round(res["value"], 2), "unit": "Mpixel/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(res["ms_per_step"], 4), "higher_is_better": True, "scaling": res["scaling"] if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "frame": [spec.full_w, spec.full_h], "layout_rows_x_cols": f"{rows}x{cols}",
-                   "tile": [spec.x0, spec.y0, spec.w, spec.h], "shaded_rect": [spec.sx0, spec.sy0, spec.sw, spec.sh],
-                   "bloom_rect": [spec.ex0, spec.ey0, spec.ew, spec.eh],
-                   "bloom_borders": "none" if world == 1 else (mode + (" (ring first: exchange overlaps the core's shade)" if frame.split is not None else "")), "collectives": "none" if world == 1 else ("gloo-rehearsal" if rehearsal else f"rccl-{transport}"),
-                   "mean_lights_per_pixel_by_rank": lp, "clock_settle_frames": a.settle,
-                   "frame_tail": "all-reduce + average + tone-map on a side stream, beside the next frame's shade" if tail_overlap else "in order"},
+        "config": workload_config(job, res, a.settle),
     }
     if rehearsal:
         out["rehearsal"] = "all ranks share cuda:0 (gloo + host copies): functional run, not a measurement"
-    if notes:
-        out["config"]["notes"] = notes
+    state["out"] = out     # complete as a contract line from here on; what follows adds blocks
 
+    shaded_px = spec.sw * spec.sh
     if not a.no_kernel_timing:   # every rank runs the same stage sequence (halo stages are collective); rank 0 reports
-        iters = max(5, min(a.steps, 20))
-        ext_px = spec.ew * spec.eh
-        int_px = spec.w * spec.h
-        # bloom and the luminance histogram run fused in the frame (pbr_bloom_histogram); the two
-        # un-fused stage calls are timed as well for reference
-        stages = {
-            "cluster": (frame.clustered, None, 0.0),
-            "shade": (frame.shade, None, BYTES_PER_PX["shade"] * shaded_px),
-            "bloom+histogram": (frame.bloom_histogram, None, BYTES_PER_PX["bloom"] * (int_px if spec.halo else ext_px) + BYTES_PER_PX["histogram"] * int_px),
-            "histogram": (frame.histogram, None, BYTES_PER_PX["histogram"] * int_px),
-            "average": (frame.average, frame.histogram, 0.0),
-            "tonemap": (frame.tonemap, None, BYTES_PER_PX["tonemap"] * int_px),
-        }
-        if spec.halo:
-            stages["halo prefilter"] = (frame.halo_prefilter, None, 0.0)
-            stages["halo exchange"] = (frame.halo_exchange, None, 0.0)
-            stages["halo pyramid+merge"] = (frame.halo_pyramid, None, 0.0)
-        else:
-            stages["bloom"] = (frame.bloom, None, BYTES_PER_PX["bloom"] * ext_px)
-        frame.hist.zero_()
-        kern = {}
-        for name, (fn, pre, nbytes) in stages.items():
-            ms = time_stage(fn, iters, pre)
-            kern[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1) if nbytes else None}
+        with wd.phase(a.deadline, "per-stage timing"):
+            iters = max(5, min(a.steps, 20))
+            ext_px = spec.ew * spec.eh
+            int_px = spec.w * spec.h
+            # bloom and the luminance histogram run fused in the frame (pbr_bloom_histogram); the two
+            # un-fused stage calls are timed as well for reference
+            stages = {
+                "cluster": (frame.clustered, None, 0.0),
+                "shade": (frame.shade, None, BYTES_PER_PX["shade"] * shaded_px),
+                "bloom+histogram": (frame.bloom_histogram, None, BYTES_PER_PX["bloom"] * (int_px if spec.halo else ext_px) + BYTES_PER_PX["histogram"] * int_px),
+                "histogram": (frame.histogram, None, BYTES_PER_PX["histogram"] * int_px),
+                "average": (frame.average, frame.histogram, 0.0),
+                "tonemap": (frame.tonemap, None, BYTES_PER_PX["tonemap"] * int_px),
+            }
+            if spec.halo:
+                stages["halo prefilter"] = (frame.halo_prefilter, None, 0.0)
+                stages["halo exchange"] = (frame.halo_exchange, None, 0.0)
+                stages["halo pyramid+merge"] = (frame.halo_pyramid, None, 0.0)
+            else:
+                stages["bloom"] = (frame.bloom, None, BYTES_PER_PX["bloom"] * ext_px)
             frame.hist.zero_()
-        hbm_meas = measure_hbm_read(ctx)
+            kern = {}
+            for name, (fn, pre, nbytes) in stages.items():
+                ms = time_stage(fn, iters, pre)
+                kern[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1) if nbytes else None}
+                frame.hist.zero_()
+            hbm_meas = measure_hbm_read(ctx)
     if rank == 0 and not a.no_kernel_timing:
         # dominant kernel: the shade.  Its launch duration is the mean over the frames of the timed region; the
         # per-stage figures below come from separate isolated launches after it
+        shade_events = res["shade_events"]
         shade_ms_in_frame = sum(e0.elapsed_time(e1) for e0, e1 in shade_events) / max(len(shade_events), 1)
         kern["shade(in frame)"] = {"ms": round(shade_ms_in_frame, 4), "GB/s": round(BYTES_PER_PX["shade"] * shaded_px / (shade_ms_in_frame * 1e-3) / 1e9, 1)}
         achieved = kern["shade(in frame)"]["GB/s"]
@@ -556,6 +765,7 @@ def main():
                            "stage_frac_of_measured": {k: round(v["GB/s"] / hbm_meas, 4) for k, v in kern.items() if v["GB/s"]},
                            "note": "algorithmic bytes (SURVEY 8d) / HIP-event duration; hbm_measured_GBps = pbr_membench_read streaming 2 GiB on this device; "
                                    "the shade with 256 clustered lights is FP32-VALU-bound (SURVEY D6): its HBM fraction is structurally low; "
+                                   "stage_GBps of the fused bloom is EFFECTIVE (the 16 reference passes' bytes / the fused launches' time), not traffic; "
                                    "traffic (when present) is the committed rocprofv3 PMC figure for this workload and this version of shade.hip, "
                                    "IBL gathers served by L2/MALL included"}
         sq = kernel_entry(load_profile("pmc_sq_latest.json", shaded_px), "k_deferred_shade", ("SQ_INSTS_VALU",))
@@ -594,21 +804,73 @@ def main():
                 valu["TFLOPs_upper_bound"] = round(tf, 1)
                 valu["frac_of_fp32_peak_upper_bound"] = round(tf / FP32_VALU_PEAK_TFLOPS, 3)
             out["roofline"]["valu"] = valu
+
+    # ---- the drop-in path: the same workload driven by the C++ pass graph
+    if not a.no_host_graph and not rehearsal:
+        hg = host_graph_leg(job, res, max(a.steps, 20))
+        if rank == 0:
+            out["host_graph"] = hg
+
+    # ---- BASELINE configs[4] in the same launch: the 8K frame cut over the ranks (strong scaling) + its single-GPU time
+    if world > 1 and not a.frame and not a.no_cfg5:
+        del frame
+        res["frame_obj"] = None
+        torch.cuda.empty_cache()
+        s5 = strong(CFG5_FRAME[0], CFG5_FRAME[1], CFG5_GRID.get(world))
+        try:
+            r5 = run_workload(job, "cfg5", s5[0], s5[1], s5[2], s5[3], s5[4], s5[5], a.steps, a.warmup, min(a.settle, 100), want_stage_timing=False)
+            c5 = workload_config(job, r5, min(a.settle, 100))
+            c5.update({"ms_per_step": round(r5["ms_per_step"], 4), "value": round(r5["value"], 2), "unit": "Mpixel/s", "scaling": "strong", "steps": a.steps})
+            hg5 = None
+            if not a.no_host_graph and not rehearsal:
+                hg5 = host_graph_leg(job, r5, max(a.steps, 20))
+            r5["frame_obj"] = None
+            torch.cuda.empty_cache()
+            # the denominator: the same 8K frame on ONE GPU (rank 0, the others wait), so that the x-factor comes from one record
+            single_ms = None
+            with wd.phase(max(a.deadline, 600.0), "cfg5: single-GPU 8K frame on rank 0"):
+                if rank == 0:
+                    fw, fh = CFG5_FRAME
+                    from direct12pbrrenderer_amd.pipeline import TileSpec
+                    fr1 = DeferredFrame(ctx, TileSpec(0, 0, fw, fh, fw, fh, 0), r5["g"], r5["lights"], job.lut, LUT_RES, job.env, ENV_SIZE, ENV_MIPS)
+                    fr1.upload_gbuffer(synth.gbuffer_tile(0, 0, fw, fh, fw, fh))
+                    fr1.set_prev_luminance(0.18)
+                    for _ in range(30 + a.warmup):
+                        fr1.render()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(a.steps):
+                        fr1.render()
+                    torch.cuda.synchronize()
+                    single_ms = (time.perf_counter() - t0) / a.steps * 1e3
+                    del fr1
+                if dist:
+                    dist.barrier()
+            if rank == 0:
+                c5["single_gpu_ms_per_step"] = round(single_ms, 4)
+                c5["single_gpu_value"] = round(r5["total_px"] / (single_ms * 1e-3) / 1e6, 2)
+                c5["speedup_vs_single_gpu"] = round(single_ms / r5["ms_per_step"], 3)
+                if r5["ms_overlapped"] is not None:
+                    c5["speedup_vs_single_gpu_tail_overlapped"] = round(single_ms / r5["ms_overlapped"], 3)
+                if hg5 is not None:
+                    c5["host_graph"] = hg5
+                out["config"]["cfg5"] = c5
+        except SystemExit as e:
+            out["config"]["cfg5"] = {"error": str(e)}
+
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(g, lights, lut.cpu().view(torch.int16).numpy().view(np.float16),
-                                               env.cpu().view(torch.int16).numpy().view(np.float16), a.width, a.height)
+            out["cpu_baseline"] = cpu_baseline(g, lights, job.lut.cpu().view(torch.int16).numpy().view(np.float16),
+                                               job.env.cpu().view(torch.int16).numpy().view(np.float16), a.width, a.height)
         except Exception as e:   # the baseline is reporting only; never fail the GPU measurement on it
             out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    with wd.phase(a.deadline, "teardown"):
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        ctx.close()
     # the record is the last thing this process writes (teardown messages of the libraries, if any, come before it)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    if rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    emit(out)
     os.close(json_fd)
 
 

@@ -26,6 +26,7 @@ SIGNATURES = {
     "pbr_ctx_destroy": (None, [_vp]),
     "pbr_ctx_set_stream": (_int, [_vp, _vp]),
     "pbr_ctx_use_own_stream": (_int, [_vp]),
+    "pbr_ctx_get_stream": (_vp, [_vp]),
     "pbr_ctx_side_begin": (_int, [_vp]),
     "pbr_ctx_side_end": (_int, [_vp]),
     "pbr_ctx_side_join": (_int, [_vp]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "pbr_halo_exchange": (_int, [_vp, _vp, _u32, _u32, C.POINTER(HaloPeer), _u32, _vp, _sz]),
     "pbr_halo_pack": (_int, [_vp, _vp, _u32, _u32, C.POINTER(HaloPeer), _u32, _vp, _sz, _int]),
     "pbr_runtime_error": (C.c_char_p, []),
+    "pbr_runtime_mismatch_dirs": (_int, [C.c_char_p, C.c_char_p]),
     "pbr_membench_read": (_int, [_vp, _vp, _sz, _vp, _u32]),
 }
 

@@ -3,6 +3,7 @@
 #include "pbr_device.hpp"
 #include <dlfcn.h>
 #include <link.h>
+#include <unistd.h>
 #include <cstring>
 #include <vector>
 
@@ -38,10 +39,22 @@ static int scan_cb(struct dl_phdr_info* info, size_t, void* data) {
     return 0;
 }
 static char g_runtime_err[512];
+static bool dir_has_hip_runtime(const std::string& dir) {
+    // torch wheels bundle libamdhip64.so next to libtorch_hip.so; a torch built against the system ROCm does not
+    for (const char* n : {"/libamdhip64.so", "/libamdhip64.so.7", "/libamdhip64.so.6"})
+        if (access((dir + n).c_str(), F_OK) == 0) return true;
+    return false;
+}
+// the rule on its own (no process state), so that it can be checked without arranging a second runtime
+extern "C" int pbr_runtime_mismatch_dirs(const char* hip_dir, const char* torch_dir) {
+    if (!hip_dir || !torch_dir || !*hip_dir || !*torch_dir) return 0;   // no torch, or no HIP runtime mapped yet
+    if (std::strcmp(hip_dir, torch_dir) == 0) return 0;                  // torch's own copy is the one in use
+    return dir_has_hip_runtime(torch_dir) ? 1 : 0;                       // torch without a bundled runtime uses the system one too
+}
 static bool runtime_mismatch() {
     RuntimeScan s;
     dl_iterate_phdr(scan_cb, &s);
-    if (s.torch_dir.empty() || s.hip_dir.empty() || s.hip_dir == s.torch_dir) return false;
+    if (!pbr_runtime_mismatch_dirs(s.hip_dir.c_str(), s.torch_dir.c_str())) return false;
     snprintf(g_runtime_err, sizeof(g_runtime_err),
              "two ROCm installations in one process: the HIP runtime in use is %s/libamdhip64 but PyTorch (%s) ships its own; "
              "load torch BEFORE libpbr_hip.so / libpbr_host.so (direct12pbrrenderer_amd._lib.load() does)", s.hip_dir.c_str(), s.torch_dir.c_str());
@@ -78,9 +91,10 @@ void pbr_ctx_destroy(pbr_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->comm && ctx->rccl_lib) {
+    if (ctx->rccl_lib) {
         nccl_destroy_fn d = (nccl_destroy_fn)dlsym(ctx->rccl_lib, "ncclCommDestroy");
-        if (d) d(ctx->comm);
+        if (d && ctx->comm_hist) d(ctx->comm_hist);
+        if (d && ctx->comm) d(ctx->comm);
     }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->ev_side_fork) (void)hipEventDestroy(ctx->ev_side_fork);
@@ -99,15 +113,21 @@ pbr_status pbr_ctx_set_stream(pbr_ctx* ctx, void* hip_stream) {
 
 pbr_status pbr_ctx_use_own_stream(pbr_ctx* ctx) {
     if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, !ctx->on_side, "pbr_ctx_use_own_stream: on the side stream (pbr_ctx_side_end first)");
     ctx->stream = ctx->own_stream;
     return PBR_OK;
 }
+
+void* pbr_ctx_get_stream(const pbr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 const char* pbr_last_error(const pbr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 pbr_status pbr_sync(pbr_ctx* ctx) {
     if (!ctx) return PBR_ERR_INVALID;
     PBR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // work forked to the side stream (pbr_ctx_side_begin .. _end) and not joined yet belongs to "everything enqueued so far"
+    if (ctx->side_stream && (ctx->side_pending || ctx->on_side) && ctx->stream != ctx->side_stream)
+        PBR_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
     return PBR_OK;
 }
 
@@ -117,6 +137,7 @@ struct nccl_uid { char internal[128]; };
 typedef int (*nccl_get_uid_fn)(nccl_uid*);
 typedef int (*nccl_init_rank_fn)(void**, int, nccl_uid, int);
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_split_fn)(void*, int, int, void**, void*);   // ncclCommSplit(comm, color, key, &newcomm, config)
 enum { NCCL_UINT32 = 3, NCCL_SUM = 0 };
 
 typedef int (*nccl_p2p_fn)(void*, size_t, int, int, void*, hipStream_t);   // ncclSend / ncclRecv (buffer, count, type, peer, comm, stream)
@@ -168,17 +189,24 @@ pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_i
     PBR_HIP(ctx, hipSetDevice(ctx->device));
     int r = f(&ctx->comm, world, id, rank);
     if (r != 0) { ctx->comm = nullptr; return pbr::fail(ctx, PBR_ERR_COMM, "ncclCommInitRank failed"); }
+    // A second communicator over the same ranks for the histogram all-reduce: the halo exchange (frame stream) and the
+    // all-reduce (side stream when the frame's tail is overlapped) may then be in flight at the same time without
+    // relying on every rank enqueueing them in the same host order — RCCL orders operations per communicator.
+    nccl_split_fn split = (nccl_split_fn)dlsym(ctx->rccl_lib, "ncclCommSplit");
+    if (!split) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_comm_init: ncclCommSplit missing (RCCL too old)");
+    r = split(ctx->comm, 0, rank, &ctx->comm_hist, nullptr);
+    if (r != 0 || !ctx->comm_hist) { ctx->comm_hist = nullptr; return pbr::fail(ctx, PBR_ERR_COMM, "ncclCommSplit failed"); }
     return PBR_OK;
 }
 
 pbr_status pbr_allreduce_hist(pbr_ctx* ctx, uint32_t* hist256) {
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, hist256 != nullptr, "pbr_allreduce_hist: null histogram");
-    if (ctx->world <= 1 && !ctx->comm) return PBR_OK;   // single GPU: the local histogram is the global one
-    if (!ctx->comm) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_allreduce_hist: world > 1 but no communicator");
+    if (ctx->world <= 1 && !ctx->comm_hist) return PBR_OK;   // single GPU: the local histogram is the global one
+    if (!ctx->comm_hist) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_allreduce_hist: world > 1 but no communicator");
     nccl_allreduce_fn f = (nccl_allreduce_fn)dlsym(ctx->rccl_lib, "ncclAllReduce");
     if (!f) return pbr::fail(ctx, PBR_ERR_COMM, "ncclAllReduce missing");
-    int r = f(hist256, hist256, PBR_HISTOGRAM_BINS, NCCL_UINT32, NCCL_SUM, ctx->comm, ctx->stream);
+    int r = f(hist256, hist256, PBR_HISTOGRAM_BINS, NCCL_UINT32, NCCL_SUM, ctx->comm_hist, ctx->stream);
     if (r != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclAllReduce failed");
     return PBR_OK;
 }

@@ -16,7 +16,8 @@ struct pbr_ctx {
     std::vector<float> host_tmp;      // host staging that must outlive an enqueued copy (prefilter sample tables)
     // RCCL (loaded lazily with dlopen so a 1-GPU run never needs librccl)
     void* rccl_lib = nullptr;
-    void* comm = nullptr;
+    void* comm = nullptr;             // frame communicator: halo exchange (ncclSend / ncclRecv)
+    void* comm_hist = nullptr;        // ncclCommSplit of it: the histogram all-reduce (may run on the side stream)
     int world = 1;
     int rank = 0;
     // high-priority side stream of pbr_ctx_side_begin / _end / _join

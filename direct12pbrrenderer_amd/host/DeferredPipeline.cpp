@@ -25,7 +25,7 @@ std::vector<IRenderPass*> DeferredRenderPipeline::Setup() {
     mAutoExposurePass = std::make_unique<AutoExposurePass>();
     mToneMappingPass = std::make_unique<ToneMappingPass>(mSize);
     mPresentPass = std::make_unique<PresentPass>();
-    mBloomPass = std::make_unique<BloomPass>();
+    mBloomPass = std::make_unique<BloomPass>(mHaloChain);
     mClusteredPass = std::make_unique<ClusteredPass>();
     mPresentPass->SetFinalTexture(DeferredPipelineResource::ToneMappedTexture);
     return {mPrefilterEnvMapPass.get(), mPrecomputeBRDFPass.get(), mClusteredPass.get(), mGBufferPass.get(),
@@ -90,6 +90,7 @@ void GBufferPass::Execute(FGContext* context) {
     GBufferSource& src = context->Scene->GBuffer();
     if (!src.Dirty) return;   // the planes a rasterizer would have left in device memory are still there
     src.Dirty = false;
+    if (context->CommandList->FramesInFlight() > 1) context->CommandList->WaitIdle();   // earlier frames still read the planes
     auto* a = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::GBufferA));
     if (src.Width != a->Width() || src.Height != a->Height()) throw HipException("GBufferPass: G-buffer source size != render size");
     const size_t n = (size_t)src.Width * src.Height;
@@ -173,7 +174,8 @@ void ClusteredPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:208-
     mClusteredCulling.SetRWStructuredBuffer("Clusters", sw_cluster);
     mClusteredCulling.SetRWStructuredBuffer("PointLights", sw_point_light);
     if (context->Scene->GetLightCount() > (uint32)MaxSceneLights) throw HipException("ClusteredPass: more than MaxSceneLights lights");
-    std::vector<pbr_light> lights(MaxSceneLights);
+    std::vector<pbr_light>& lights = mLights;
+    lights.assign(MaxSceneLights, pbr_light{});
     int i = 0;
     // frustum culling point lights (DeferredPipeline.cpp:224-241): membership and buffer order come from the octree walk
     const Matrix4x4 view_projection = context->Camera->GetProjectionMatrix() * context->Camera->GetLocalSpaceMatrix();
@@ -185,7 +187,15 @@ void ClusteredPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:208-
     });
     mClusteredCompute.SetConstantBuffer(ClusteredShaderConstant{i});
     mClusteredCulling.SetConstantBuffer(ClusteredShaderConstant{i});
-    sw_point_light->Commit(lights.data(), lights.size() * sizeof(pbr_light));
+    // the reference re-uploads the buffer every frame through its upload ring; here the device copy is rewritten only when
+    // the culled list changed (a static camera and scene: never again) — and then only once no earlier frame that reads
+    // it can still be in flight (throughput mode keeps several)
+    if (i != mCommittedCount || mCommitted.size() != lights.size() || std::memcmp(mCommitted.data(), lights.data(), (size_t)i * sizeof(pbr_light)) != 0) {
+        if (context->CommandList->FramesInFlight() > 1) context->CommandList->WaitIdle();
+        sw_point_light->Commit(lights.data(), lights.size() * sizeof(pbr_light));
+        mCommitted = lights;
+        mCommittedCount = i;
+    }
     if (context->CommandList->FusedPasses()) {
         context->CommandList->Clustered(sw_cluster, sw_point_light, i);
         return;
@@ -210,6 +220,7 @@ void AutoExposurePass::Execute(FGContext* context) {   // DeferredPipeline.cpp:2
     auto* avg_luminance = As<DeviceStructuredBuffer>(GetTransientResource(context, DeferredPipelineResource::AverageLuminance));
     if (!mAvarageLuminanceInitialized) {
         mAvarageLuminanceInitialized = true;
+        if (context->CommandList->FramesInFlight() > 1) context->CommandList->WaitIdle();
         avg_luminance->Commit(&mInitialLuminance, sizeof(float));
     }
     {
@@ -249,11 +260,12 @@ void ToneMappingPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:32
 }
 
 // ----------------------------------------------------------------------------------- bloom
-BloomPass::BloomPass() {   // DeferredPipeline.cpp:338-374
+BloomPass::BloomPass(RenderSize halo_chain) : mHalo(halo_chain.Width != 0) {   // DeferredPipeline.cpp:338-374
     const FGTransientTextureDescription& d = FGResourceDescriptionTable::Instance()->GetTransientTexture(DeferredPipelineResource::DeferredShadingRT);
-    if ((d.Width >> (MipmapLevel - 1)) == 0 || (d.Height >> (MipmapLevel - 1)) == 0) throw HipException("BloomPass: render size too small for the mip chain");
-    WriteTransientTexture(DeferredPipelineResource::BloomMipchain, d.Width, d.Height, MipmapLevel, d.Format, ETexture2DFlag_AllowUnorderedAccess);
-    WriteTransientTexture(DeferredPipelineResource::BloomTempTexture, d.Width, d.Height, MipmapLevel, d.Format, ETexture2DFlag_AllowUnorderedAccess);
+    const uint32 cw = mHalo ? halo_chain.Width : d.Width, ch = mHalo ? halo_chain.Height : d.Height;
+    if ((cw >> (MipmapLevel - 1)) == 0 || (ch >> (MipmapLevel - 1)) == 0) throw HipException("BloomPass: render size too small for the mip chain");
+    WriteTransientTexture(DeferredPipelineResource::BloomMipchain, cw, ch, MipmapLevel, d.Format, ETexture2DFlag_AllowUnorderedAccess);
+    WriteTransientTexture(DeferredPipelineResource::BloomTempTexture, cw, ch, MipmapLevel, d.Format, ETexture2DFlag_AllowUnorderedAccess);
     WriteResource(DeferredPipelineResource::DeferredShadingRT);
     mPrefilter.SetShader("bloom_prefilter.hlsl", true);
     mUpsampleBlurH.SetShader("blur_horizontal.hlsl", true);
@@ -272,6 +284,13 @@ void BloomPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:400-570,
     auto* temp_tex = As<DeviceTexture2D>(GetTransientResource(context, DeferredPipelineResource::BloomTempTexture));
     HipCommandList* cmd = context->CommandList;
     auto texel = [](uint32 w, uint32 h) { return Vector2{1.0f / (float)w, 1.0f / (float)h}; };
+    if (mHalo) {
+        // multi-GPU halo mode (SURVEY 8e option 2; not in the reference): the pyramid runs on the tile's extended rectangle,
+        // whose level 1 outside the interior arrives from the neighbouring devices — prefilter the interior, exchange,
+        // levels 1..4 + merge.  Bit-identical to the sixteen dispatches below on the whole frame in the interior.
+        cmd->BloomHalo(original_tex, mip_chain, temp_tex, 1.0f, 0.5f);
+        return;
+    }
     if (cmd->FusedPasses()) {   // the sixteen dispatches below as one call: same HDR result
         cmd->Bloom(original_tex, mip_chain, temp_tex, 1.0f, 0.5f);
         return;

@@ -95,12 +95,15 @@ class BloomPass : public ComputePass {   // :208-298
 public:
     static constexpr uint32 BloomStep = 3;
     static constexpr uint32 MipmapLevel = BloomStep + 2;
-    BloomPass();
+    // halo_chain: {0, 0} = the mip chains have DeferredShadingRT's size (the reference); multi-GPU halo mode:
+    // the size of the tile's extended rectangle E, on which the pyramid runs (the HDR target covers S = interior + 4 px)
+    explicit BloomPass(RenderSize halo_chain = RenderSize{0, 0});
     const char* Name() const override { return "Bloom"; }
     void Execute(FGContext* context) override;
 protected:
     ShadingState mDownsampleH[BloomStep], mDownsampleV[BloomStep], mUpsampleH[BloomStep], mUpsampleV[BloomStep];
     ShadingState mUpsampleBlurH, mUpsampleBlurV, mUpsampleMerge, mPrefilter;
+    bool mHalo = false;
 };
 
 class ClusteredPass : public ComputePass {   // :300-369
@@ -112,6 +115,8 @@ public:
     void Execute(FGContext* context) override;
 protected:
     ShadingState mClusteredCompute, mClusteredCulling;
+    std::vector<pbr_light> mLights, mCommitted;   // this frame's light buffer / what the device buffer holds
+    int mCommittedCount = -1;
 };
 
 class AutoExposurePass : public ComputePass {   // :371-429
@@ -146,6 +151,11 @@ class DeferredRenderPipeline : public IRenderPipeline {   // :463-481, DeferredP
 public:
     DeferredRenderPipeline(RenderSize size, uint32 env_size = PreFilterEnvMapPass::PreFilterEnvMapSize, uint32 lut_res = PrecomputeBRDFPass::TextureResolution)
         : mSize(size), mEnvSize(env_size), mLutRes(lut_res) {}
+    // one device's tile of a larger frame: every target covers the layout's shaded rectangle S; in halo mode the
+    // bloom chains cover the extended rectangle E
+    DeferredRenderPipeline(const TileLayout& layout, uint32 env_size = PreFilterEnvMapPass::PreFilterEnvMapSize, uint32 lut_res = PrecomputeBRDFPass::TextureResolution)
+        : mSize(RenderSize{layout.Shaded.w, layout.Shaded.h}), mEnvSize(env_size), mLutRes(lut_res),
+          mHaloChain(layout.Halo ? RenderSize{layout.Bloom.w, layout.Bloom.h} : RenderSize{0, 0}) {}
     std::vector<IRenderPass*> Setup() override;
 
     std::unique_ptr<GBufferPass> mGBufferPass;
@@ -160,6 +170,7 @@ public:
 private:
     RenderSize mSize;
     uint32 mEnvSize, mLutRes;
+    RenderSize mHaloChain{0, 0};
 };
 
 }  // namespace MRendererHip

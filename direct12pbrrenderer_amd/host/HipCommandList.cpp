@@ -120,12 +120,70 @@ HipCommandList::HipCommandList(int hip_device) {
     pbr_status st = pbr_ctx_create(hip_device, &mCtx);
     if (st != PBR_OK) throw HipException("pbr_ctx_create failed (status " + std::to_string(st) + ")");
 }
-HipCommandList::~HipCommandList() { pbr_ctx_destroy(mCtx); }
+HipCommandList::~HipCommandList() {
+    (void)pbr_sync(mCtx);
+    for (hipEvent_t e : mFrameFence) (void)hipEventDestroy(e);
+    pbr_ctx_destroy(mCtx);
+}
 
 void HipCommandList::Check(pbr_status st, const char* what) {
     if (st != PBR_OK) throw HipException(std::string(what) + ": " + pbr_last_error(mCtx));
 }
-void HipCommandList::EndFrame() { Check(pbr_sync(mCtx), "pbr_sync"); }
+void HipCommandList::WaitIdle() {
+    FlushPendingBloom();
+    Check(pbr_sync(mCtx), "pbr_sync");
+}
+void HipCommandList::SetFramesInFlight(uint32 k) {
+    WaitIdle();
+    for (hipEvent_t e : mFrameFence) (void)hipEventDestroy(e);
+    mFrameFence.clear();
+    mFrameIndex = 0;
+    if (k <= 1) return;   // the reference's per-frame fence wait
+    if (k > 8) throw HipException("SetFramesInFlight: at most 8");
+    mFrameFence.resize(k, nullptr);
+    for (hipEvent_t& e : mFrameFence) ThrowIfFailed(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+}
+void HipCommandList::EndFrame() {
+    FlushPendingBloom();
+    if (mFrameFence.empty()) {   // D3D12Device::EndFrame: signal + wait, every frame
+        Check(pbr_sync(mCtx), "pbr_sync");
+        return;
+    }
+    const size_t k = mFrameFence.size();
+    ThrowIfFailed(hipEventRecord(mFrameFence[mFrameIndex % k], (hipStream_t)pbr_ctx_get_stream(mCtx)), "hipEventRecord");
+    mFrameIndex++;
+    if (mFrameIndex >= k) ThrowIfFailed(hipEventSynchronize(mFrameFence[mFrameIndex % k]), "hipEventSynchronize");   // frame i - k + 1
+}
+
+void HipCommandList::SetLayout(const TileLayout& l) {
+    mLayout = l;
+    mTile = pbr_tile{l.Shaded.x, l.Shaded.y, l.Shaded.w, l.Shaded.h, l.FullW, l.FullH};
+    mInterior = l.Tiled() ? l.InteriorInShaded() : Rect{};
+    mHaloPlan = l.HaloPlan();
+    mHaloStaging.reset();
+    if (!mHaloPlan.empty()) {
+        if (mHaloPlan.size() > 16) throw HipException("SetLayout: more than 16 halo peers");
+        const size_t bytes = pbr_halo_staging_bytes(mHaloPlan.data(), (uint32_t)mHaloPlan.size());
+        mHaloStaging = std::make_unique<DeviceStructuredBuffer>((uint32)bytes, 8);
+    }
+}
+
+bool HipCommandList::HaloStripOffset(int rank, bool recv, size_t* offset, size_t* bytes) const {
+    size_t off = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (const pbr_halo_peer& p : mHaloPlan) {
+            const uint32_t* q = pass == 0 ? p.send : p.recv;
+            const size_t n = (size_t)q[2] * q[3] * 8;
+            if (p.rank == rank && (pass == 1) == recv) {
+                if (!n) return false;
+                *offset = off;
+                *bytes = n;
+                return true;
+            }
+            off += n;
+        }
+    return false;
+}
 
 // roctx (libroctx64.so.4: roctxRangePushA / roctxRangePop), resolved once; a copy that is already mapped — PyTorch
 // ships one, rocprofv3 preloads one — is preferred over opening another
@@ -181,6 +239,7 @@ void HipCommandList::Dispatch(ShadingState* s, uint32 gx, uint32 gy, uint32 gz) 
     if (!s || !s->GetShader() || !s->IsCompute()) throw HipException("Dispatch: shading state has no compute shader");
     const std::string_view f = s->File();
     mDispatchCount++;
+    if (f != "hdr_luminance_histogram.hlsl") FlushPendingBloom();
     if (f == "precompute_brdf.hlsl") {
         const auto& c = s->Constants<PrecomputeBRDFConstant>();
         auto* out = dynamic_cast<DeviceTexture2D*>(s->RWTexture("PrecomputeBRDF").Texture);
@@ -242,8 +301,15 @@ void HipCommandList::Dispatch(ShadingState* s, uint32 gx, uint32 gy, uint32 gz) 
         const Rect r = mInterior.w ? mInterior : Rect{0, 0, in.w, in.h};
         if (r.x + r.w > in.w || r.y + r.h > in.h || c.TextureWidth != r.w || c.TextureHeight != r.h)
             throw HipException("hdr_luminance_histogram: TextureWidth/Height must be the interior rectangle's size");
-        Check(pbr_lum_histogram(mCtx, in.ptr + 4 * ((size_t)r.y * in.w + r.x), r.w, r.h, in.w, c.MinLogLuminance, c.InvLogLuminanceRange, hist),
-              "pbr_lum_histogram");
+        const TextureBinding& lum = s->Texture("LuminanceTexture");
+        if (mPendingBloom.What != PendingBloom::None && lum.Texture == mPendingBloom.Hdr && lum.MipSlice <= 0) {
+            // the bloom held back by Bloom / BloomHalo wrote this very texture: count the histogram in its last kernel
+            FlushPendingBloom(hist, c.MinLogLuminance, c.InvLogLuminanceRange);
+        } else {
+            FlushPendingBloom();
+            Check(pbr_lum_histogram(mCtx, in.ptr + 4 * ((size_t)r.y * in.w + r.x), r.w, r.h, in.w, c.MinLogLuminance, c.InvLogLuminanceRange, hist),
+                  "pbr_lum_histogram");
+        }
         if (mCaptureHistogram) {
             Check(pbr_sync(mCtx), "pbr_sync");
             mCapturedHistogram.resize(256);
@@ -273,6 +339,7 @@ void HipCommandList::DrawScreen(ShadingState* s) {
     if (!s || !s->GetShader() || s->IsCompute()) throw HipException("DrawScreen: shading state has no pixel shader");
     const std::string_view f = s->File();
     mDispatchCount++;
+    FlushPendingBloom();
     if (!mRenderTarget) throw HipException("DrawScreen: no render target bound (FrameGraph::PreparePass)");
     if (f == "deferred_shading.hlsl") {
         auto tex = [&](const char* n) { return dynamic_cast<DeviceTexture2D*>(s->Texture(n).Texture); };
@@ -310,6 +377,7 @@ void HipCommandList::DrawScreen(ShadingState* s) {
 void HipCommandList::Clustered(DeviceStructuredBuffer* clusters, DeviceStructuredBuffer* point_lights, int32 num_lights) {
     if (!clusters || !point_lights) throw HipException("Clustered: null buffer");
     mDispatchCount++;
+    FlushPendingBloom();
     mNumLights = num_lights;
     Check(pbr_clustered(mCtx, &mGlobal, (const pbr_light*)point_lights->DevicePtr(), num_lights, (pbr_cluster*)clusters->DevicePtr()), "pbr_clustered");
 }
@@ -319,14 +387,75 @@ void HipCommandList::Bloom(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, Dev
     if (mip_chain->Width() != hdr->Width() || mip_chain->Height() != hdr->Height() || temp->Width() != hdr->Width() || temp->Height() != hdr->Height())
         throw HipException("Bloom: the mip chains must have the HDR target's size");
     mDispatchCount++;
-    Check(pbr_bloom(mCtx, (pbr_half*)hdr->DevicePtr(), hdr->Width(), hdr->Height(), hdr->Width(), (pbr_half*)mip_chain->DevicePtr(),
-                    (pbr_half*)temp->DevicePtr(), threshold, knee), "pbr_bloom");
+    FlushPendingBloom();
+    mPendingBloom = PendingBloom{PendingBloom::Whole, hdr, mip_chain, temp, threshold, knee};
+    if (!mFusedPasses) FlushPendingBloom();
+}
+
+void HipCommandList::FlushPendingBloom(uint32_t* hist, float min_log, float inv_range) {
+    const PendingBloom p = mPendingBloom;
+    mPendingBloom = PendingBloom{};
+    if (p.What == PendingBloom::Whole) {
+        pbr_half *hdr = (pbr_half*)p.Hdr->DevicePtr(), *a = (pbr_half*)p.MipChain->DevicePtr(), *b = (pbr_half*)p.Temp->DevicePtr();
+        const uint32 w = p.Hdr->Width(), h = p.Hdr->Height();
+        if (hist) {
+            const Rect r = mInterior.w ? mInterior : Rect{0, 0, w, h};
+            const uint32_t rect[4] = {r.x, r.y, r.w, r.h};
+            Check(pbr_bloom_histogram(mCtx, hdr, w, h, w, a, b, p.Threshold, p.Knee, rect, min_log, inv_range, hist), "pbr_bloom_histogram");
+        } else {
+            Check(pbr_bloom(mCtx, hdr, w, h, w, a, b, p.Threshold, p.Knee), "pbr_bloom");
+        }
+    } else if (p.What == PendingBloom::Tiled) {
+        IssueBloomTiled(p.Hdr, p.MipChain, p.Temp, hist, min_log, inv_range);
+    }
+}
+
+void HipCommandList::IssueBloomTiled(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, DeviceTexture2D* temp, uint32_t* hist, float min_log, float inv_range) {
+    const PixelRect s = mLayout.ShadedInBloom(), i = mLayout.InteriorInBloom();
+    const uint32_t hdr_rect[4] = {s.x, s.y, s.w, s.h}, merge_rect[4] = {i.x, i.y, i.w, i.h};
+    Check(pbr_bloom_tiled(mCtx, (pbr_half*)hdr->DevicePtr(), hdr->Width(), hdr_rect, mLayout.Bloom.w, mLayout.Bloom.h, (pbr_half*)mip_chain->DevicePtr(),
+                          (pbr_half*)temp->DevicePtr(), merge_rect, min_log, inv_range, hist), "pbr_bloom_tiled");
+}
+
+void HipCommandList::HaloExchange(DeviceTexture2D* mip_chain) {
+    if (mHaloPlan.empty()) return;
+    pbr_half* level1 = (pbr_half*)mip_chain->MipPtr(1);
+    const uint32 pitch = mLayout.Bloom.w / 2, rows = mLayout.Bloom.h / 2;
+    const uint32_t n = (uint32_t)mHaloPlan.size();
+    void* st = mHaloStaging->DevicePtr();
+    const size_t bytes = mHaloStaging->Bytes();
+    if (mHaloTransport == HaloTransport::Rccl) {
+        Check(pbr_halo_exchange(mCtx, level1, pitch, rows, mHaloPlan.data(), n, st, bytes), "pbr_halo_exchange");
+    } else {   // the strips are moved between staging areas by the host program (pbrh_halo_copy_from)
+        Check(pbr_halo_pack(mCtx, level1, pitch, rows, mHaloPlan.data(), n, st, bytes, 0), "pbr_halo_pack");
+        Check(pbr_halo_pack(mCtx, level1, pitch, rows, mHaloPlan.data(), n, st, bytes, 1), "pbr_halo_pack(unpack)");
+    }
+}
+
+void HipCommandList::BloomHalo(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, DeviceTexture2D* temp, float threshold, float knee) {
+    if (!hdr || !mip_chain || !temp) throw HipException("BloomHalo: null texture");
+    if (!mLayout.Halo) throw HipException("BloomHalo: the command list has no halo layout (SetLayout)");
+    const TileLayout& l = mLayout;
+    if (hdr->Width() != l.Shaded.w || hdr->Height() != l.Shaded.h) throw HipException("BloomHalo: the HDR target must cover the shaded rectangle");
+    if (mip_chain->Width() != l.Bloom.w || mip_chain->Height() != l.Bloom.h || temp->Width() != l.Bloom.w || temp->Height() != l.Bloom.h)
+        throw HipException("BloomHalo: the mip chains must cover the extended rectangle");
+    mDispatchCount++;
+    FlushPendingBloom();
+    // level-1 texels of the interior, written into the level-1 plane of E
+    const PixelRect s = l.ShadedInBloom(), i = l.InteriorInShaded();
+    const uint32_t rect[4] = {i.x / 2, i.y / 2, i.w / 2, i.h / 2};
+    Check(pbr_bloom_prefilter_rect(mCtx, (pbr_half*)hdr->DevicePtr(), hdr->Width(), hdr->Height(), hdr->Width(), (pbr_half*)mip_chain->MipPtr(1),
+                                   l.Bloom.w / 2, s.x / 2, s.y / 2, rect, threshold, knee), "pbr_bloom_prefilter_rect");
+    HaloExchange(mip_chain);
+    mPendingBloom = PendingBloom{PendingBloom::Tiled, hdr, mip_chain, temp, threshold, knee};
+    if (!mFusedPasses) FlushPendingBloom();
 }
 
 void HipCommandList::DrawMesh(ShadingState* s) {   // D3D12CommandList.cpp DrawMesh; SkyboxPass::Execute :59-75
     if (!s || s->IsCompute()) throw HipException("DrawMesh: graphics shading state expected");
     const std::string_view f = s->File();
     mDispatchCount++;
+    FlushPendingBloom();
     if (f != "skybox.hlsl") throw HipException("DrawMesh: " + std::string(f) + " is a raster shader without a kernel in this build");
     if (!mRenderTarget || !mDepthStencil) throw HipException("DrawMesh: render target / depth-stencil not bound (FrameGraph::PreparePass)");
     auto* sky = dynamic_cast<DeviceTexture2DArray*>(s->Texture("SkyBox").Texture);
@@ -343,6 +472,7 @@ void HipCommandList::EncodeGBuffer(ShadingState* s, const float* m0, const float
     if (!a || !b || !c || a->Width() != b->Width() || a->Width() != c->Width() || a->Height() != b->Height() || a->Height() != c->Height())
         throw HipException("EncodeGBuffer: G-buffer planes of one size expected");
     mDispatchCount++;
+    FlushPendingBloom();
     Check(pbr_gbuffer_encode(mCtx, m0, m1, m2, a->Width(), a->Height(), a->Width(), (uint32_t*)a->DevicePtr(),
                              (uint32_t*)b->DevicePtr(), (uint32_t*)c->DevicePtr()), "pbr_gbuffer_encode");
 }

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "IPipeline.h"
+#include "TileLayout.h"
 
 namespace MRendererHip {
 
@@ -21,7 +22,13 @@ public:
     HipCommandList& operator=(const HipCommandList&) = delete;
 
     void BeginFrame() { mDispatchCount = 0; mEventLog.clear(); }
-    void EndFrame();   // D3D12Device::EndFrame blocks on the fence every frame (D3D12Device.cpp:993-1003)
+    // D3D12Device::EndFrame blocks on the fence every frame (D3D12Device.cpp:993-1003): FramesInFlight() == 1, the
+    // default.  With k > 1 (throughput mode, not in the reference) EndFrame returns once frame i - k + 1 is done, so
+    // the host records frame i + 1 while the GPU still runs frame i; WaitIdle() drains.
+    void EndFrame();
+    void SetFramesInFlight(uint32 k);
+    uint32 FramesInFlight() const { return (uint32)mFrameFence.size() ? (uint32)mFrameFence.size() : 1; }
+    void WaitIdle();
 
     // global constants (b2), RenderScheduler.cpp:22-41
     void SetGlobalConstant(const ConstantBufferGlobal& g) { mGlobal = g; }
@@ -33,9 +40,23 @@ public:
     void SetDepthStencil(DeviceTexture2D* ds) { mDepthStencil = ds; }
     // multi-GPU: the region of the full frame this device renders; default = whole target
     void SetTile(const pbr_tile& tile) { mTile = tile; }
+    // multi-GPU, everything at once from a tile layout: the render target is the layout's SHADED rectangle S (global-pixel
+    // addressing, interior-only histogram / tone-map); in halo mode also the level-1 exchange plan and its staging area
+    void SetLayout(const TileLayout& layout);
+    const TileLayout& Layout() const { return mLayout; }
+    // how HaloExchange moves the strips: over the context's RCCL communicator (pbr_halo_exchange; needs pbr_comm_init), or
+    // not at all (Loopback: pack + unpack only — several tiles rendered one after the other on one device, the strips
+    // copied between their staging areas by the host program: pbrh_halo_copy_from)
+    enum class HaloTransport { Rccl, Loopback };
+    void SetHaloTransport(HaloTransport t) { mHaloTransport = t; }
+    const std::vector<pbr_halo_peer>& HaloPlan() const { return mHaloPlan; }
+    DeviceStructuredBuffer* HaloStaging() const { return mHaloStaging.get(); }
+    // byte offset of the strip sent to / received from `rank` inside the staging area (all send strips in plan order,
+    // then all receive strips: the layout pbr_halo_exchange and pbr_halo_pack use); false if there is no such strip
+    bool HaloStripOffset(int rank, bool recv, size_t* offset, size_t* bytes) const;
     // multi-GPU: the part of the render target this device OWNS (the rest is the apron it shades only to feed bloom):
     // the luminance histogram counts, and the tone-map writes, interior pixels only.  w == 0: the whole target.
-    struct Rect { uint32 x = 0, y = 0, w = 0, h = 0; };
+    using Rect = PixelRect;
     void SetInterior(const Rect& r) { mInterior = r; }
     const Rect& Interior() const { return mInterior; }
     // multi-GPU without a communicator (several tiles rendered one after the other on one device: tests, a host that
@@ -66,8 +87,16 @@ public:
     bool FusedPasses() const { return mFusedPasses; }
     // ClusteredPass::Execute's two dispatches (pbr_clustered)
     void Clustered(DeviceStructuredBuffer* clusters, DeviceStructuredBuffer* point_lights, int32 num_lights);
-    // BloomPass::Execute's sixteen dispatches (pbr_bloom); mip_chain / temp are scratch afterwards
+    // BloomPass::Execute's sixteen dispatches (pbr_bloom); mip_chain / temp are scratch afterwards.  With fused passes the
+    // call is held back until the next command: when that is the luminance histogram of the same texture, both become ONE
+    // pbr_bloom_histogram (the histogram is counted by the bloom's last kernel: one full read of the HDR target saved) —
+    // a command list is free to merge adjacent commands as long as every consumer sees the same results.
     void Bloom(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, DeviceTexture2D* temp, float threshold, float knee);
+    // Halo mode (SURVEY 8e option 2) — what BloomPass::Execute issues on a tile whose bloom pyramid runs on the extended
+    // rectangle E: level-1 texels of the interior (pbr_bloom_prefilter_rect) -> the rest of E's level 1 from the neighbours
+    // (HaloExchange) -> levels 1..4 on E and the merge into the interior (pbr_bloom_tiled; held back like Bloom when fused).
+    // hdr covers S; mip_chain / temp are E-sized.
+    void BloomHalo(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, DeviceTexture2D* temp, float threshold, float knee);
 
     // Named ranges around pass bodies, where the reference has PIXScopedEvent (DeferredPipeline.cpp:8 `PIXScope`): roctx
     // ranges here, visible to rocprofv3 --marker-trace.  libroctx64 is looked up at run time; absent = no-op.
@@ -83,6 +112,15 @@ public:
 
 private:
     void Check(pbr_status st, const char* what);
+    void HaloExchange(DeviceTexture2D* mip_chain);
+    // the bloom call held back by Bloom / BloomHalo: issued with the histogram (hist != nullptr) or on its own
+    struct PendingBloom {
+        enum Kind { None, Whole, Tiled } What = None;
+        DeviceTexture2D *Hdr = nullptr, *MipChain = nullptr, *Temp = nullptr;
+        float Threshold = 0, Knee = 0;
+    };
+    void FlushPendingBloom(uint32_t* hist = nullptr, float min_log = 0.0f, float inv_range = 0.0f);
+    void IssueBloomTiled(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, DeviceTexture2D* temp, uint32_t* hist, float min_log, float inv_range);
 
     pbr_ctx* mCtx = nullptr;
     ConstantBufferGlobal mGlobal{};
@@ -95,6 +133,13 @@ private:
     bool mFusedPasses = false;
     pbr_tile mTile{};
     Rect mInterior{};
+    TileLayout mLayout{};
+    HaloTransport mHaloTransport = HaloTransport::Rccl;
+    std::vector<pbr_halo_peer> mHaloPlan;
+    std::unique_ptr<DeviceStructuredBuffer> mHaloStaging;
+    PendingBloom mPendingBloom;
+    std::vector<hipEvent_t> mFrameFence;   // ring of per-frame completion events (throughput mode)
+    uint64_t mFrameIndex = 0;
     std::vector<uint32> mExternalHistogram, mCapturedHistogram;
     bool mCaptureHistogram = false;
     std::vector<std::string> mEventLog;

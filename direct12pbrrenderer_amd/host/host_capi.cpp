@@ -55,6 +55,55 @@ pbrh_renderer* pbrh_create(int device, uint32_t width, uint32_t height, uint32_t
     }
 }
 
+// One device's tile of a full_w x full_h frame cut cols x rows (rank = row * cols + col): the targets cover the shaded
+// rectangle, the bloom chains the extended one (TileLayout.h).  halo = 0: apron mode.
+pbrh_renderer* pbrh_create_tile(int device, uint32_t full_w, uint32_t full_h, uint32_t cols, uint32_t rows, uint32_t rank, int halo,
+                                uint32_t env_size, uint32_t lut_res, char* err, size_t err_len) {
+    auto* r = new pbrh_renderer();
+    try {
+        const TileLayout layout = TileLayout::OfFrame(full_w, full_h, cols, rows, rank, halo != 0);
+        FGResourceDescriptionTable::Instance()->Reset();
+        r->width = layout.Shaded.w;
+        r->height = layout.Shaded.h;
+        r->pipeline = std::make_unique<DeferredRenderPipeline>(layout, env_size, lut_res);
+        r->scheduler = std::make_unique<RenderScheduler>(r->pipeline.get(), device, r->width, r->height);
+        r->scene = std::make_unique<Scene>();
+        r->scheduler->CommandList()->SetLayout(layout);
+        if (layout.Tiled()) r->pipeline->mAutoExposurePass->SetFullFramePixelCount(full_w * full_h);
+        // the camera sees the FULL frame (App.cpp:99-101 with the frame's aspect ratio)
+        r->camera = std::make_unique<Camera>(0.333f * 3.14159265359f, full_w, full_h, 0.1f, 1000.0f);
+        r->camera->Move(Vector3{0, 3, 10});
+        r->camera->Rotate(0, 3.14159265359f, 0);
+        return r;
+    } catch (const std::exception& e) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", e.what());
+        delete r;
+        return nullptr;
+    }
+}
+
+// CPU only: the layout arithmetic of pbrh_create_tile.  rects = interior, shaded, bloom rectangle (x, y, w, h each, global
+// pixels); peers = the halo plan (rank, send x y w h, recv x y w h: 9 ints per peer, level-1 texels local to the bloom
+// rectangle's level-1 plane).  Returns the number of peers (may exceed max_peers), -1 on a bad grid.
+int pbrh_tile_layout(uint32_t full_w, uint32_t full_h, uint32_t cols, uint32_t rows, uint32_t rank, int halo, uint32_t rects[12], int32_t* peers, int max_peers) {
+    try {
+        const TileLayout l = TileLayout::OfFrame(full_w, full_h, cols, rows, rank, halo != 0);
+        const PixelRect* src[3] = {&l.Interior, &l.Shaded, &l.Bloom};
+        for (int k = 0; k < 3 && rects; k++) {
+            rects[4 * k] = src[k]->x; rects[4 * k + 1] = src[k]->y; rects[4 * k + 2] = src[k]->w; rects[4 * k + 3] = src[k]->h;
+        }
+        const std::vector<pbr_halo_peer> plan = l.HaloPlan();
+        for (size_t i = 0; i < plan.size() && (int)i < max_peers && peers; i++) {
+            int32_t* q = peers + 9 * i;
+            q[0] = plan[i].rank;
+            for (int k = 0; k < 4; k++) { q[1 + k] = (int32_t)plan[i].send[k]; q[5 + k] = (int32_t)plan[i].recv[k]; }
+        }
+        return (int)plan.size();
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
 void pbrh_destroy(pbrh_renderer* r) { delete r; }
 const char* pbrh_last_error(const pbrh_renderer* r) { return r ? r->err.c_str() : "null renderer"; }
 
@@ -168,6 +217,33 @@ int pbrh_comm_init(pbrh_renderer* r, int world, int rank, const void* uid) {
     });
 }
 
+int pbrh_set_halo_loopback(pbrh_renderer* r, int on) {
+    return guarded(r, [&] {
+        r->scheduler->CommandList()->SetHaloTransport(on ? HipCommandList::HaloTransport::Loopback : HipCommandList::HaloTransport::Rccl);
+    });
+}
+
+// dst's receive strip from src's rank <- src's send strip to dst's rank (device-to-device; both renderers idle)
+int pbrh_halo_copy_from(pbrh_renderer* dst, pbrh_renderer* src) {
+    return guarded(dst, [&] {
+        if (!src) throw HipException("pbrh_halo_copy_from: null source");
+        HipCommandList *d = dst->scheduler->CommandList(), *s = src->scheduler->CommandList();
+        d->WaitIdle();
+        s->WaitIdle();
+        size_t doff = 0, dbytes = 0, soff = 0, sbytes = 0;
+        const bool want = d->HaloStripOffset((int)s->Layout().Rank, true, &doff, &dbytes);
+        const bool have = s->HaloStripOffset((int)d->Layout().Rank, false, &soff, &sbytes);
+        if (want != have || dbytes != sbytes) throw HipException("pbrh_halo_copy_from: the two layouts do not agree on the strip");
+        if (!want) return;   // not neighbours
+        ThrowIfFailed(hipMemcpy((char*)d->HaloStaging()->DevicePtr() + doff, (const char*)s->HaloStaging()->DevicePtr() + soff, dbytes, hipMemcpyDeviceToDevice),
+                      "copy halo strip");
+    });
+}
+
+int pbrh_set_frames_in_flight(pbrh_renderer* r, int k) {
+    return guarded(r, [&] { r->scheduler->CommandList()->SetFramesInFlight(k < 1 ? 1u : (uint32)k); });
+}
+
 int pbrh_set_external_histogram(pbrh_renderer* r, const uint32_t* counts256) {
     return guarded(r, [&] { r->scheduler->CommandList()->SetExternalHistogram(counts256); });
 }
@@ -202,6 +278,7 @@ int pbrh_render_n(pbrh_renderer* r, int n, float dt, double* ms_per_frame) {
             r->time += dt;
             r->scheduler->ExecutePipeline(r->scene.get(), r->camera.get(), dt, r->time);
         }
+        r->scheduler->CommandList()->WaitIdle();   // throughput mode: the last frames are still in flight
         const auto t1 = std::chrono::steady_clock::now();
         if (ms_per_frame) *ms_per_frame = std::chrono::duration<double, std::milli>(t1 - t0).count() / (n > 0 ? n : 1);
     });
@@ -234,6 +311,7 @@ int pbrh_dispatch_count(const pbrh_renderer* r) { return r ? (int)r->scheduler->
 long pbrh_read(pbrh_renderer* r, const char* name, void* dst, size_t dst_bytes) {
     long n = -1;
     int st = guarded(r, [&] {
+        r->scheduler->CommandList()->WaitIdle();
         IDeviceResource* res = r->scheduler->GetFrameGraph()->FindResource(FGResourceIDs::Instance()->NameToID(name));
         size_t bytes = std::min(dst_bytes, res->Bytes());
         ThrowIfFailed(hipMemcpy(dst, res->DevicePtr(), bytes, hipMemcpyDeviceToHost), "read back");

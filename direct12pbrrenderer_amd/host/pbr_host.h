@@ -12,6 +12,27 @@ typedef struct pbrh_renderer pbrh_renderer;
 
 pbrh_renderer* pbrh_create(int hip_device, uint32_t width, uint32_t height, uint32_t env_size, uint32_t lut_res,
                            char* err, size_t err_len);
+/* ---- multi-GPU, one renderer per device: this device's tile of a full_w x full_h frame cut cols x rows
+ * (rank = row * cols + col; BASELINE cfg5: 7680 x 4320, cols 4, rows 2).  Every target covers the tile's SHADED rectangle;
+ * uv / camera ray / ClusterIndex use global pixels, the histogram counts and the tone-map writes the interior only, the
+ * average divides by the full frame's pixel count.  halo = 0 (apron mode): the device shades interior + 256 px and blooms
+ * that.  halo = 1: it shades interior + 4 px; BloomPass::Execute computes the interior's half-res level, receives the rest
+ * of the extended rectangle's half-res level from the neighbouring devices (pbr_halo_exchange over the communicator of
+ * pbrh_comm_init) and runs the pyramid on the extended rectangle (pbr_bloom_tiled). */
+pbrh_renderer* pbrh_create_tile(int hip_device, uint32_t full_w, uint32_t full_h, uint32_t cols, uint32_t rows, uint32_t rank, int halo,
+                                uint32_t env_size, uint32_t lut_res, char* err, size_t err_len);
+/* CPU only: the layout arithmetic behind pbrh_create_tile.  rects = interior, shaded, bloom rectangle (x, y, w, h each, in
+ * global pixels); peers = the halo plan, 9 ints per peer: rank, send x y w h, recv x y w h (half-res texels local to the bloom
+ * rectangle's half-res plane).  Returns the number of peers, -1 on a bad grid. */
+int pbrh_tile_layout(uint32_t full_w, uint32_t full_h, uint32_t cols, uint32_t rows, uint32_t rank, int halo, uint32_t rects[12], int32_t* peers, int max_peers);
+/* halo mode without a communicator (several tiles rendered one after the other on ONE device): on = the exchange step only
+ * packs the outgoing strips into the renderer's staging area and unpacks whatever the incoming part of it holds;
+ * pbrh_halo_copy_from(dst, src) copies the strip src sends to dst into dst's staging area (device to device). */
+int pbrh_set_halo_loopback(pbrh_renderer* r, int on);
+int pbrh_halo_copy_from(pbrh_renderer* dst, pbrh_renderer* src);
+/* 1 (default) = the reference's frame loop: every frame ends with the fence wait (D3D12Device.cpp:993-1003).  k > 1 =
+ * throughput mode: a frame's end waits for frame i - k + 1 only, so the host records ahead of the GPU. */
+int pbrh_set_frames_in_flight(pbrh_renderer* r, int k);
 void pbrh_destroy(pbrh_renderer* r);
 const char* pbrh_last_error(const pbrh_renderer* r);
 /* fp32 RGBA cube mip 0 (host, 6*size*size*4 floats): uploaded, box mips + SH9 computed on the GPU */

@@ -482,12 +482,18 @@ class DeferredFrame:
         self.average()
         self.tonemap()
 
-    def enable_tail_overlap(self):
+    def enable_tail_overlap(self, capi_allreduce=False):
         """Multi-GPU frames whose histogram all-reduce runs on the context's own stream (the C ABI's RCCL communicator): double-
         buffer the HDR target and the histogram so that a frame's tail can overlap the next frame's shade.  Throughput mode:
-        the LDR image of frame i is complete when frame i + 1's tail has been joined (or after a device synchronisation)."""
+        the LDR image of frame i is complete when frame i + 1's tail has been joined (or after ctx.sync(), which also waits
+        for the side stream).  The all-reduce MUST be one that is enqueued on the context's current stream — PbrContext.
+        allreduce_hist, or a stand-in the caller vouches for with capi_allreduce=True (tests: a 1-rank communicator); a
+        torch.distributed all-reduce runs on torch's own stream and would race with the double-buffered histogram."""
         if self.allreduce is None or self.split is not None:
             raise ValueError("tail overlap needs an all-reduce (world > 1) and the plain frame order")
+        own = getattr(self.allreduce, "__self__", None) is self.ctx and getattr(self.allreduce, "__name__", "") == "allreduce_hist"
+        if not (own or capi_allreduce):
+            raise ValueError("tail overlap needs the C ABI's all-reduce (PbrContext.allreduce_hist): it must be enqueued on the context's side stream")
         self._hdr_alt = torch.zeros_like(self.hdr)
         self._hist_alt = torch.zeros_like(self.hist)
         self._tail_overlap = True

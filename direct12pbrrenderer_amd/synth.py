@@ -37,7 +37,22 @@ def _unit(h):
     return h.astype(np.float64) * (1.0 / 4294967296.0)
 
 
-def gbuffer_tile(x0, y0, w, h, full_w, full_h, near=0.1, far=1000.0, rough_min=48, coverage_mask=False, cell=1):
+def gbuffer_tile(x0, y0, w, h, full_w, full_h, near=0.1, far=1000.0, rough_min=48, coverage_mask=False, cell=1, workers=None):
+    """gbuffer_band on row bands in a thread pool (numpy releases the GIL inside its loops): the same arrays, several
+    times faster for 4K / 8K frames.  workers: None = min(8, cores); 1 = in the calling thread."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    n = min(8, os.cpu_count() or 1) if workers is None else int(workers)
+    if n <= 1 or h < 256:
+        return gbuffer_band(x0, y0, w, h, full_w, full_h, near, far, rough_min, coverage_mask, cell)
+    rows = -(-h // (4 * n))
+    bands = [(y, min(rows, h - y)) for y in range(0, h, rows)]
+    with ThreadPoolExecutor(n) as ex:
+        parts = list(ex.map(lambda b: gbuffer_band(x0, y0 + b[0], w, b[1], full_w, full_h, near, far, rough_min, coverage_mask, cell), bands))
+    return {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
+
+
+def gbuffer_band(x0, y0, w, h, full_w, full_h, near=0.1, far=1000.0, rough_min=48, coverage_mask=False, cell=1):
     """Returns dict of A,B,C (uint32 [h,w]), depth (float32 [h,w]), stencil (uint8 [h,w]).
 
     albedo rgb u8 uniform; emission 255 with p = 1/128; octahedral normal (u8,u8) uniform (every pair

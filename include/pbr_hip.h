@@ -147,6 +147,9 @@ void        pbr_ctx_destroy(pbr_ctx* ctx);
 pbr_status  pbr_ctx_set_stream(pbr_ctx* ctx, void* hip_stream);
 /* go back to the context's private stream */
 pbr_status  pbr_ctx_use_own_stream(pbr_ctx* ctx);
+/* the hipStream_t the next call will enqueue on (for a host that orders its own events / copies with the context's
+ * work: the C++ pass graph records its per-frame fence there); NULL = HIP's default stream */
+void*       pbr_ctx_get_stream(const pbr_ctx* ctx);
 /* A second, high-priority stream of the context.  _begin: it waits for everything enqueued so far, and the calls made
  * until _end enqueue on it; _end: back to the context's stream — what follows runs concurrently with the side stream's
  * work; _join: the context's stream waits for the side stream.  (Multi-GPU: the tile's border ring and its halo exchange
@@ -155,12 +158,17 @@ pbr_status  pbr_ctx_side_begin(pbr_ctx* ctx);
 pbr_status  pbr_ctx_side_end(pbr_ctx* ctx);
 pbr_status  pbr_ctx_side_join(pbr_ctx* ctx);
 const char* pbr_last_error(const pbr_ctx* ctx);
+/* blocks until everything enqueued through the context is done: its stream AND side-stream work not joined yet */
 pbr_status  pbr_sync(pbr_ctx* ctx);
 const char* pbr_version(void);
 /* NULL, or why this process cannot use the library: a second ROCm installation is mapped next to the HIP runtime in
  * use (PyTorch ships its own libamdhip64; it must be loaded first).  pbr_ctx_create refuses with
  * PBR_ERR_UNSUPPORTED in that case and prints this text. */
 const char* pbr_runtime_error(void);
+/* the rule behind pbr_runtime_error as a pure function: 1 iff the HIP runtime in use (mapped from hip_dir) is not the
+ * one PyTorch (libtorch_hip.so in torch_dir) ships — i.e. torch_dir holds its own libamdhip64.so and hip_dir is another
+ * directory.  A PyTorch built against the system ROCm (no bundled runtime) is NOT a mismatch. */
+int pbr_runtime_mismatch_dirs(const char* hip_dir, const char* torch_dir);
 
 /* ---- one-shot IBL precompute --------------------------------------------------------------- */
 /* precompute_brdf.hlsl:20-62 dispatched by PrecomputeBRDFPass::Execute (DeferredPipeline.cpp:117-136).
@@ -327,8 +335,11 @@ pbr_status pbr_tonemap(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h
 /* RCCL communicator over the ranks of one node.  unique_id: 128 bytes from
  * pbr_comm_unique_id() on rank 0, broadcast by the caller (e.g. torch.distributed store). */
 pbr_status pbr_comm_unique_id(void* out_128_bytes);
+/* Collective over all ranks.  Creates TWO communicators over the same ranks: the frame communicator (halo exchange)
+ * from the unique id, and an ncclCommSplit of it for the histogram all-reduce — the two collectives may be in flight
+ * on different streams at the same time (overlapped frame tail), and RCCL orders operations per communicator only. */
 pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_id_128_bytes);
-/* ncclAllReduce(sum, uint32, 256) on the ctx stream; no-op without a communicator / world 1 */
+/* ncclAllReduce(sum, uint32, 256) on the ctx stream, on the histogram communicator; no-op without a communicator / world 1 */
 pbr_status pbr_allreduce_hist(pbr_ctx* ctx, uint32_t* hist256);
 
 /* Halo exchange of half4 rectangles of one plane (level 1 of the bloom pyramid) with neighbouring tiles: for every

@@ -74,6 +74,27 @@ want[20:29, 50:67] = before[2:11, 3:20]
 want[0:40, 30:38] = before[0:40, 70:78]
 assert np.array_equal(after, want) and float(other[0]) == 1.0
 ctx.side_join()                               # nothing pending: a no-op
+# both collectives in flight at once on different streams — the histogram all-reduce (its own communicator, an
+# ncclCommSplit of the frame communicator) on the side stream, the halo exchange on the main one — and then pbr_sync
+# WITHOUT a join: it waits for the context's stream and for the side-stream work not joined yet
+before = after.copy()
+hist = torch.arange(256, dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+ctx.side_begin()
+ctx.allreduce_hist(hist)
+ctx.side_end()
+ctx.halo_exchange(plane.view(torch.float16), W, H, peers, n, st.view(torch.float16))
+ctx.sync()
+after = plane.cpu().numpy()
+want = before.copy()
+want[20:29, 50:67] = before[2:11, 3:20]
+want[0:40, 30:38] = before[0:40, 70:78]
+assert np.array_equal(after, want) and torch.equal(hist.cpu(), torch.arange(256, dtype=torch.int32))
+ctx.side_join()
+ctx.side_begin()
+assert ctx.lib.pbr_ctx_use_own_stream(ctx.h) == -1 and b"side stream" in ctx.lib.pbr_last_error(ctx.h)   # refused while on the side stream
+ctx.side_end()
+ctx.side_join()
 try:
     ctx.side_end()
     raise SystemExit("side_end without side_begin must be refused")
@@ -115,9 +136,9 @@ def run(overlap):
     for i in range(7):
         fr.upload_gbuffer(gbs[i %% 2])               # alternating inputs: a stale buffer would show
         fr.render()
-        if overlap:
+        if overlap and i %% 2:
             fr.finish()
-        ctx.sync()
+        ctx.sync()                                   # also waits for the side stream's un-joined tail (even frames rely on it)
         out.append((fr.ldr.cpu().numpy().copy(), float(fr.avg.cpu()[0])))
     # and back to back without a host synchronisation in between: the last frame must still be the same
     for i in range(7, 12):
@@ -126,6 +147,12 @@ def run(overlap):
     fr.finish(); ctx.sync()
     out.append((fr.ldr.cpu().numpy().copy(), float(fr.avg.cpu()[0])))
     return out
+try:
+    fr = DeferredFrame(ctx, TileSpec(0, 0, W, H, W, H, 0), g, lights, lut, 512, env, 512, 5, allreduce=lambda h: None)
+    fr.enable_tail_overlap()
+    raise SystemExit("an all-reduce that is not the C ABI's must be refused")
+except ValueError as e:
+    assert "C ABI" in str(e)
 a, b = run(False), run(True)
 for i, ((la, va), (lb, vb)) in enumerate(zip(a, b)):
     assert va == vb, (i, va, vb)

@@ -63,3 +63,50 @@ def test_host_library_exports_every_declared_symbol():
     assert len(declared) >= 25
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in pbr_host.h but not exported"
+
+
+def test_runtime_mismatch_rule_ignores_a_torch_without_a_bundled_runtime(tmp_path):
+    """pbr_runtime_mismatch_dirs: a mismatch only when PyTorch's directory really holds its own libamdhip64 and the
+    runtime in use comes from elsewhere; a PyTorch built against the system ROCm (nothing bundled) is one runtime."""
+    from direct12pbrrenderer_amd import _lib
+    lib = _lib.load()
+    bundled, bare = tmp_path / "torch_bundled", tmp_path / "torch_bare"
+    bundled.mkdir()
+    bare.mkdir()
+    (bundled / "libamdhip64.so").write_bytes(b"")
+    rocm = b"/opt/rocm/lib"
+    assert lib.pbr_runtime_mismatch_dirs(rocm, str(bundled).encode()) == 1      # two runtimes: refuse
+    assert lib.pbr_runtime_mismatch_dirs(rocm, str(bare).encode()) == 0         # torch uses the system runtime too
+    assert lib.pbr_runtime_mismatch_dirs(str(bundled).encode(), str(bundled).encode()) == 0
+    assert lib.pbr_runtime_mismatch_dirs(rocm, b"") == 0 and lib.pbr_runtime_mismatch_dirs(b"", str(bundled).encode()) == 0
+
+
+def test_host_tile_layout_matches_the_python_tiling_and_halo_plan():
+    """TileLayout (C++ pass graph) against pipeline.py's TileSpec / halo_plan, which the gloo tests pin against the single
+    frame: same interior / shaded / bloom rectangles and the same level-1 strips, for cfg5's 2 rows x 4 cols and other grids."""
+    import ctypes
+    import numpy as np
+    import torch  # noqa: F401
+    from direct12pbrrenderer_amd.pipeline import halo_plan, tile_of_frame
+    lib = ctypes.CDLL(os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_host.so"))
+    lib.pbrh_tile_layout.argtypes = [ctypes.c_uint32] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    for fw, fh, cols, rows in ((7680, 4320, 4, 2), (7680, 4320, 2, 1), (7680, 4320, 2, 2), (3072, 576, 3, 1), (1024, 2048, 1, 4), (3840, 2160, 1, 1)):
+        world = cols * rows
+        for halo in (False, True):
+            specs = [tile_of_frame(r, world, fw, fh, layout=(cols, rows), halo=halo) for r in range(world)]
+            for rank, s in enumerate(specs):
+                rects = np.zeros(12, np.uint32)
+                peers = np.zeros((16, 9), np.int32)
+                n = lib.pbrh_tile_layout(fw, fh, cols, rows, rank, int(halo), rects.ctypes.data, peers.ctypes.data, 16)
+                assert n >= 0
+                assert rects.tolist() == [s.x0, s.y0, s.w, s.h, s.sx0, s.sy0, s.sw, s.sh, s.ex0, s.ey0, s.ew, s.eh], (fw, fh, cols, rows, rank, halo)
+                hx, hy = s.ex0 // 2, s.ey0 // 2
+                want = []
+                if halo and world > 1:
+                    for peer, snd, rcv in halo_plan(rank, world, specs):
+                        loc = lambda q: [0, 0, 0, 0] if q is None else [q[0] - hx, q[1] - hy, q[2] - q[0], q[3] - q[1]]
+                        want.append([peer] + loc(snd) + loc(rcv))
+                assert n == len(want) and peers[:n].tolist() == want, (fw, fh, cols, rows, rank, halo)
+    assert lib.pbrh_tile_layout(7680, 4320, 4, 2, 8, 1, None, None, 0) == -1       # rank outside the grid
+    assert lib.pbrh_tile_layout(7680, 4320, 7, 2, 0, 1, None, None, 0) == -1       # 7680 / 7 is not integral
+    assert lib.pbrh_tile_layout(1000, 1000, 2, 1, 0, 1, None, None, 0) == -1       # 500-px tiles are not multiples of 16
