@@ -80,9 +80,11 @@ void FrameGraph::Setup() { mPipelinePasses = mRenderPipeline->Setup(); }
 
 void FrameGraph::Compile() {
     mParser.Parse(mPipelinePasses, mRenderPipeline->mPresentPass.get());
+    mDescriptions = FGResourceDescriptionTable::Instance()->All();
+    mDescriptions.resize(FGResourceIDs::Instance()->NumResources());
     mFGResourceAllocator.Reset();
     for (auto& lc : mParser.GetResourceLifecycle())
-        if (lc.Valid) mFGResourceAllocator.AllocateTransientResource(lc.ResourceId);
+        if (lc.Valid) mFGResourceAllocator.AllocateTransientResource(lc.ResourceId, Describe(lc.ResourceId));
 }
 
 void FrameGraph::Execute(HipCommandList* cmd, Scene* scene, Camera* camera) {
@@ -95,7 +97,7 @@ void FrameGraph::Execute(HipCommandList* cmd, Scene* scene, Camera* camera) {
 }
 
 IDeviceResource* FrameGraph::FindResource(FGResourceId id) {
-    const auto& d = FGResourceDescriptionTable::Instance()->Get(id);
+    const auto& d = Describe(id);
     if (auto* p = std::get_if<FGPersistentResourceDescription>(&d)) return p->Resource;
     return mFGResourceAllocator.GetResource(id);
 }
@@ -116,7 +118,7 @@ void FrameGraph::PreparePass(HipCommandList* cmd, uint32 pass_index) {
     if (!pass) return;
     DeviceTexture2D *rt = nullptr, *ds = nullptr;
     for (FGResourceId id : pass->GetOutputResources()) {
-        const auto& d = FGResourceDescriptionTable::Instance()->Get(id);
+        const auto& d = Describe(id);
         if (auto* t = std::get_if<FGTransientTextureDescription>(&d)) {
             if (t->Format != ETextureFormat_DepthStencil && !rt) rt = dynamic_cast<DeviceTexture2D*>(mFGResourceAllocator.GetResource(id));
             if (t->Format == ETextureFormat_DepthStencil && !ds) ds = dynamic_cast<DeviceTexture2D*>(mFGResourceAllocator.GetResource(id));

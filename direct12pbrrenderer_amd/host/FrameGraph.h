@@ -36,8 +36,10 @@ public:
     const std::vector<IRenderPass*>& ExecutionOrder() const { return mParser.GetExecutionOrder(); }
 private:
     void PreparePass(HipCommandList* cmd, uint32 pass_index);
+    const FGResourceDescriptionTable::Description& Describe(FGResourceId id) const { return mDescriptions.at(id); }
     FGExecutionParser mParser;
     FGResourceAllocator mFGResourceAllocator;
+    std::vector<FGResourceDescriptionTable::Description> mDescriptions;   // this pipeline's declarations (copied at Compile)
     std::vector<IRenderPass*> mPipelinePasses;
     IRenderPipeline* mRenderPipeline;
     uint32 mExecutionPass;

@@ -217,6 +217,9 @@ public:
     const FGPersistentResourceDescription& GetPersistentResource(FGResourceId id) const { return std::get<FGPersistentResourceDescription>(mDescriptions.at(id)); }
     // a new renderer instance re-declares everything (the reference has one pipeline per process)
     void Reset() { mDescriptions.clear(); }
+    // the declarations of the pipeline that was just set up: a FrameGraph keeps its own copy (FrameGraph::Compile), so that
+    // several renderers can live in one process although this table — like the reference's — is a process-wide singleton
+    const std::vector<Description>& All() const { return mDescriptions; }
 private:
     template <class T>
     void Declare(FGResourceId id, const T& desc) {
@@ -234,8 +237,7 @@ private:
 class FGResourceAllocator {
 public:
     void Reset() { mTransient.assign(FGResourceIDs::Instance()->NumResources(), nullptr); }
-    void AllocateTransientResource(FGResourceId id) {
-        const auto& d = FGResourceDescriptionTable::Instance()->Get(id);
+    void AllocateTransientResource(FGResourceId id, const FGResourceDescriptionTable::Description& d) {
         if (auto* t = std::get_if<FGTransientTextureDescription>(&d)) {
             mTransient[id] = std::make_shared<DeviceTexture2D>(t->Width, t->Height, t->MipLevels, t->Format);
         } else if (auto* b = std::get_if<FGTransientBufferDescription>(&d)) {

@@ -251,6 +251,30 @@ def deferred_shade(g, tile: Tile, gb, lut, env, env_size, env_mips, clusters, li
     return (hdr, f32, sens) if want_sens else (hdr, f32)
 
 
+def deferred_shade_f64(g, tile: Tile, gb, lut, env, env_size, env_mips, clusters, lights):
+    """The shade in double precision (pbr_oracle_f64.cpp): (lo, hi, flags) — float64 [h,w,3] interval of the exact colour
+    (lo == hi away from sampler-step / cube-face edges) and uint8 [h,w] flags (0 = comparable pixel)."""
+    h, w = gb["A"].shape
+    planes = {k: np.ascontiguousarray(v) for k, v in gb.items()}
+    s = GBuffer(planes["A"].ctypes.data, planes["B"].ctypes.data, planes["C"].ctypes.data,
+                planes["depth"].ctypes.data, planes["stencil"].ctypes.data, w)
+    lo, hi = np.zeros((h, w, 3), dtype=np.float64), np.zeros((h, w, 3), dtype=np.float64)
+    flags = np.zeros((h, w), dtype=np.uint8)
+    lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+    lut = np.ascontiguousarray(lut)
+    L = lib()
+    L.orc_deferred_shade_f64.argtypes = [C.POINTER(Global), C.POINTER(Tile), C.POINTER(GBuffer), _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32]
+    _ok(L.orc_deferred_shade_f64(C.byref(g), C.byref(tile), C.byref(s), _p(lut), lut.shape[0], _p(env), env_size, env_mips,
+                                 _p(clusters), _p(lights) if len(lights) else None, _p(lo), _p(hi), _p(flags), w), "deferred_shade_f64")
+    return lo, hi, flags
+
+
+def truth_distance(colour, lo, hi):
+    """Per-pixel, per-channel distance of an fp32 colour [h,w,>=3] to the double-precision interval [lo, hi]."""
+    c = colour[..., :3].astype(np.float64)
+    return np.maximum(np.maximum(lo - c, c - hi), 0.0)
+
+
 def skybox(g, tile: Tile, sky, sky_size, sky_mips, stencil, hdr):
     """In place on hdr [h,w,4] half: sky colour where stencil == 0."""
     h, w = stencil.shape

@@ -92,6 +92,17 @@ int orc_deferred_shade_sens(const pbr_global* g, const pbr_tile* tile, const pbr
                        const uint16_t* env, uint32_t env_size, uint32_t env_mips,
                        const pbr_cluster* clusters, const pbr_light* lights,
                        uint16_t* hdr, uint32_t hdr_pitch, float* hdr_f32_or_null, float* sens_rgb_or_null, float* flip_rgb_or_null); /* a8-a12 */
+/* The same pass in DOUBLE precision (pbr_oracle_f64.cpp): the exact value of the reference's formulas on the same inputs, as
+   an interval [lo, hi] per channel (3 doubles per pixel each, pitch out_pitch pixels) — lo == hi except where the argument of
+   a sampler snap / cube-face choice lies within a few fp32 ulps of its step edge, where both sides are admissible.
+   flags (1 byte per pixel): 1 = stencil 0 (not shaded), 2 = octahedral fold decided by rounding, 4 = cluster cell decided by
+   rounding (another evaluation may walk another light list): tests skip flagged pixels.  The third party between the GPU
+   kernel and the fp32 restatement above: distance of an fp32 colour c to the truth = max(lo - c, c - hi, 0). */
+int orc_deferred_shade_f64(const pbr_global* g, const pbr_tile* tile, const pbr_gbuffer* gb,
+                       const uint16_t* lut, uint32_t lut_res,
+                       const uint16_t* env, uint32_t env_size, uint32_t env_mips,
+                       const pbr_cluster* clusters, const pbr_light* lights,
+                       double* lo_rgb, double* hi_rgb, uint8_t* flags, uint32_t out_pitch);
 int orc_skybox(const pbr_global* g, const pbr_tile* tile, const float* sky, uint32_t sky_size, uint32_t sky_mips,
                const uint8_t* stencil, uint32_t pitch, uint16_t* hdr, uint32_t hdr_pitch);                  /* 8f-1 */
 int orc_gbuffer_encode(const float* m0, const float* m1, const float* m2, uint32_t w, uint32_t h, uint32_t pitch,
