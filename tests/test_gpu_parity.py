@@ -229,20 +229,48 @@ def _shade_on_gpu(ctx, g, tile, gb, lut, env, env_size, env_mips, clusters_np, l
     return to_np_half(hdr)
 
 
-def _check_shade(got, want, want_f32, stencil, what, hard_ulp=64, sens=None):
-    """The fp16 target against the oracle's.  sens = the oracle's report of its own fp32 conditioning per pixel
-    (orc_deferred_shade_sens: [0] GGX highlight sensitivity to the rounding of N.H, [1] one step of the fixed-point
-    sampler); pixels where that allowance is a sizeable part of the bound are ILL-CONDITIONED in the reference formula
-    itself and are held to the allowance only, all others to the plain bound and to the ULP limits."""
+def _truth(orc, g, tile, gb, lut, env, env_size, env_mips, cl, lights):
+    """The shade in DOUBLE precision (oracle/pbr_oracle_f64.cpp): per-channel interval [lo, hi] of the exact value of the
+    reference's formulas on these inputs (lo == hi away from sampler-step / cube-face edges) + flags (0 = comparable)."""
+    return orc.deferred_shade_f64(g, tile, gb, lut, env, env_size, env_mips, cl, lights)
+
+
+F64_ORACLE_FACTOR = 4.0     # a pixel may be this many times further from the exact value than the fp32 restatement is ...
+F32_REL_LINF = 1e-4         # ... on top of the relative L-inf bound north_star states
+
+
+def _truth_bound(orc, want_f32, truth, on):
+    """Per-pixel, per-channel allowance of the parity bound: 1e-4 * scale + 4 * |oracle_f32 - f64|.  The second term is
+    measured, not modelled: where the reference formula is ill-conditioned in fp32 (GGX highlights: t = NdotH^2 (a^4 - 1) + 1
+    cancels) the fp32 restatement itself is that far from the exact value, and the GPU may be as well — but not more than
+    a small factor further.  Returns (bound, scale, comparable-pixel mask over the `on` pixels)."""
+    lo, hi, flags = truth
+    ok = (flags == 0)[on]
+    scale = float(np.abs(hi[on][ok]).max())
+    d_orc = orc.truth_distance(want_f32, lo, hi)[on]
+    return F32_REL_LINF * scale + F64_ORACLE_FACTOR * d_orc, scale, ok, d_orc
+
+
+def _check_shade(orc, got, want, want_f32, truth, stencil, what, hard_ulp=64):
+    """The fp16 target.  (1) Against the double-precision truth: every comparable pixel within
+    1e-4 * scale + 4 * |oracle_f32 - f64| of the exact value, plus the fp16 rounding of the stored value (half an ulp of
+    the value itself).  (2) Against the fp32 restatement's fp16 image, in ULPs, on the well-conditioned pixels (those where
+    the restatement is within a quarter of the bound of the exact value)."""
     on = stencil > 0
-    scale = np.abs(want_f32[on][:, :3]).max()
-    err = np.abs(got.astype(np.float32) - want.astype(np.float32))[on][:, :3]
-    # one fp16 ulp of the largest value (scale * 2^-10) is the storage granularity, the 1e-4 relative L-inf bound of
-    # SURVEY 8c sits on top of it (the fp32 probe tests check that bound without the fp16 term)
-    plain = 1e-4 * scale + scale * 2.0 ** -10
-    cond = (8.0 * 2.0 ** -24 * sens[0][on] + sens[1][on]) if sens is not None else np.zeros_like(err)
-    assert (err <= plain + cond).all(), f"{what}: L-inf {err.max()} vs scale {scale} (worst {np.max(err / (plain + cond)):.2f} x the bound)"
-    well = cond.max(axis=1) <= 0.25 * plain
+    lo, hi, flags = truth
+    bound, scale, ok, d_orc = _truth_bound(orc, want_f32, truth, on)
+    assert ok.mean() >= 0.95, f"{what}: only {ok.mean():.3f} of the pixels are comparable with the truth"
+    g32 = got.astype(np.float32)
+    dist = orc.truth_distance(g32, lo, hi)[on]
+    store = np.abs(g32[on][:, :3]).astype(np.float64) * 2.0 ** -11 + 2.0 ** -25      # round-to-nearest of the half store (+ half a subnormal step)
+    worst = (dist / (bound + store))[ok]
+    assert (worst <= 1.0).all(), f"{what}: a pixel is {worst.max():.2f} x its bound from the exact value (scale {scale})"
+    # pixels on a cluster / octahedral-fold edge have no truth to compare with: against the fp32 restatement, all but a handful
+    # (an evaluation that lands on the other side of the edge walks another light list)
+    err = np.abs(g32 - want.astype(np.float32))[on][:, :3]
+    off = (err > F32_REL_LINF * scale + scale * 2.0 ** -10 + F64_ORACLE_FACTOR * d_orc).any(axis=1) & ~ok
+    assert off.sum() <= max(2, int(1e-4 * on.sum())), f"{what}: {int(off.sum())} edge pixels differ from the fp32 restatement"
+    well = ok & (d_orc.max(axis=1) <= 0.25 * F32_REL_LINF * scale)
     assert well.mean() >= 0.97, f"{what}: only {well.mean():.3f} of the pixels are well-conditioned"
     # hard_ulp bounds the RELATIVE error of every channel; on a million-texel band a near-black channel (absolute error
     # still inside the L-inf bound above) can exceed it, so the full-size tests pass None
@@ -256,11 +284,12 @@ def test_deferred_shade_64_vs_oracle_and_golden(ctx, orc, golden, ibl, n_lights)
     cam, g, lights, gb, tile = common.shade_scene(64, 64, n_lights, sh)
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
-    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
     assert np.array_equal(want, golden[f"shade64_l{n_lights}"])
+    truth = _truth(orc, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
     sentinel = np.full((64, 64, 4), 7.0, dtype=np.float16)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, prefill=sentinel)
-    _check_shade(got, want, want_f32, gb["stencil"], f"shade {n_lights} lights", sens=sens)
+    _check_shade(orc, got, want, want_f32, truth, gb["stencil"], f"shade {n_lights} lights")
     assert np.all(got[gb["stencil"] == 0] == 7.0)      # stencil == 0 pixels are left untouched
 
 
@@ -271,19 +300,17 @@ def test_deferred_shade_ragged_tile_of_a_larger_frame(ctx, orc, ibl):
     cam, g, lights, gb, tile = common.shade_scene(200, 37, 256, sh, full=(640, 360), x0=328, y0=91)
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
-    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    truth = _truth(orc, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
-    _check_shade(got, want, want_f32, gb["stencil"], "ragged tile", sens=sens)
+    _check_shade(orc, got, want, want_f32, truth, gb["stencil"], "ragged tile")
     # the same region shaded as part of the whole frame agrees with the tile
     cam2, g2, lights2, gbf, tilef = common.shade_scene(640, 360, 256, sh)
     full = _shade_on_gpu(ctx, g2, tilef, gbf, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights2)
     assert np.array_equal(full[91:91 + 37, 328:328 + 200], got)
 
 
-# ---- the north_star bound itself: <= 1e-4 relative L-inf on the fp32 colour BEFORE the fp16 store
-F32_REL_LINF = 1e-4
-
-
+# ---- the north_star bound itself: <= 1e-4 relative L-inf on the fp32 colour BEFORE the fp16 store, against the EXACT value
 def _shade_f32_on_gpu(ctx, g, tile, gb, dlut, lut_res, env_padded, env_size, env_mips, clusters_np, lights):
     h, w = gb["A"].shape
     gbd = {k: ctx.upload(v) for k, v in gb.items()}
@@ -293,53 +320,55 @@ def _shade_f32_on_gpu(ctx, g, tile, gb, dlut, lut_res, env_padded, env_size, env
     return out.cpu().numpy()
 
 
-NDOTH_ULPS = 8.0 * 2.0 ** -24      # fp32 evaluations of N.H differ by a few unit roundoffs (normalize vs rsq, summation order)
-FLIP_FRACTION = 5e-3               # share of pixels that may sit on a 1/256-texel step edge of the fixed-point sampler
-
-
-def _check_shade_f32(got, want_f32, sens, stencil, what):
-    """|got - want| <= 1e-4 * max|want| (the relative L-inf bound SURVEY 8c / north_star state, over the covered
-    pixels' rgb) PLUS what the oracle reports about its own conditioning (orc_deferred_shade_sens):
-      sens[0] * NDOTH_ULPS : distribution_ggx cancels down to t ~ roughness^8 at a highlight, which amplifies one
-                             rounding error of N.H by up to 4 / roughness^8 in D — there the reference formula itself is
-                             not determined to 1e-4 in fp32, whoever evaluates it;
-      sens[1]              : the fixed-point sampler is a step function of the texel coordinate (steps of 1/256 texel);
-                             a reflection vector within a rounding error of a step edge lands on either side.  Allowed on
-                             at most FLIP_FRACTION of the pixels.
-    Returns (plain relative L-inf, fraction of pixels above the plain bound)."""
+def _check_shade_f32(orc, got, want_f32, truth, stencil, what):
+    """Per pixel and channel: |gpu_f32 - f64| <= 1e-4 * scale + 4 * |oracle_f32 - f64|, where f64 is the double-precision
+    evaluation of the reference's formulas on the same inputs (an interval where a sampler snap / face choice is decided by
+    rounding) and scale = max |f64| over the covered pixels.  No term of the bound is modelled: the fp32 restatement's own
+    distance to the exact value is measured, and the GPU gets a small multiple of it.  Edge pixels (cluster cell / octahedral
+    fold decided by rounding: no single truth) are compared with the fp32 restatement instead, all but a handful.
+    Returns the two error distributions (gpu, oracle; relative to scale) for the report in DESIGN.md section 2."""
     on = stencil > 0
-    a, b = got[on][:, :3].astype(np.float64), want_f32[on][:, :3].astype(np.float64)
-    assert np.isfinite(a).all() and np.isfinite(b).all(), what
-    scale = np.abs(b).max()
-    err = np.abs(a - b)
-    base = F32_REL_LINF * scale + NDOTH_ULPS * sens[0][on].astype(np.float64)
-    assert (err <= base + sens[1][on]).all(), \
-        f"{what}: |err| reaches {(err / (base + sens[1][on])).max():.2f} x its bound; plain relative L-inf {err.max() / scale:.3g}"
-    flips = (err > base).any(axis=1).mean()
-    assert flips <= FLIP_FRACTION, f"{what}: {flips:.4f} of the pixels need the sampler-step allowance"
-    # well-conditioned pixels (N.H allowance below a tenth of the bound) that are not on a step edge meet the plain bound
-    well = (NDOTH_ULPS * sens[0][on].astype(np.float64)).max(axis=1) <= 0.1 * F32_REL_LINF * scale
-    assert well.mean() > 0.98, f"{what}: only {well.mean():.3f} of the pixels are well-conditioned"
-    assert (err[well] > F32_REL_LINF * scale).any(axis=1).mean() <= FLIP_FRACTION
+    lo, hi, flags = truth
+    assert np.isfinite(got[on][:, :3]).all() and np.isfinite(want_f32[on][:, :3]).all(), what
+    bound, scale, ok, d_orc = _truth_bound(orc, want_f32, truth, on)
+    assert ok.mean() >= 0.95, f"{what}: only {ok.mean():.3f} of the pixels are comparable with the truth"
+    d_gpu = orc.truth_distance(got, lo, hi)[on]
+    worst = (d_gpu / bound)[ok]
+    assert (worst <= 1.0).all(), \
+        f"{what}: a pixel is {worst.max():.2f} x its bound from the exact value (gpu {d_gpu[ok].max() / scale:.3g}, oracle {d_orc[ok].max() / scale:.3g} of scale)"
+    err = np.abs(got[on][:, :3].astype(np.float64) - want_f32[on][:, :3])
+    off = (err > bound).any(axis=1) & ~ok
+    assert off.sum() <= max(2, int(1e-4 * on.sum())), f"{what}: {int(off.sum())} edge pixels differ from the fp32 restatement"
+    # not SYSTEMATICALLY further from the truth than the restatement: the upper quantiles of the two distributions agree
+    rg, ro = d_gpu[ok].max(axis=1) / scale, d_orc[ok].max(axis=1) / scale
+    for q in (0.99, 0.999, 0.9999):
+        assert np.quantile(rg, q) <= 2.0 * np.quantile(ro, q) + 2e-6, f"{what}: gpu q{q} {np.quantile(rg, q):.3g} vs oracle {np.quantile(ro, q):.3g}"
     assert np.all(got[on][:, 3] == 1.0)
-    return err.max() / scale, float((err > F32_REL_LINF * scale).any(axis=1).mean())
+    return rg, ro
+
+
+def _dist_line(what, rg, ro):
+    q = lambda a: f"max {a.max():.2e}, q99.99 {np.quantile(a, .9999):.1e}, q99 {np.quantile(a, .99):.1e}, > 1e-4: {int((a > 1e-4).sum())}"
+    return f"fp32 shade vs f64 truth, {what} ({rg.size} px): GPU {q(rg)} | fp32 restatement {q(ro)}"
 
 
 @pytest.mark.parametrize("n_lights", [0, 1, 256, 1024])
 def test_deferred_shade_f32_within_1e4_relative_linf(ctx, orc, ibl, n_lights):
-    """64x64 (0 / 1 / 256 / 1024 lights: the last one runs k_deferred_shade<*, 1025>) and a ragged tile of a larger frame."""
+    """64x64 (0 / 1 / 256 / 1024 lights: the last one runs k_deferred_shade<*, 1025>) and a ragged tile of a larger frame,
+    with the throughput frames' roughness range and with the full one (GGX peaks at roughness -> 0)."""
     sky, env, lut, sh = ibl
     dlut, denv = dev_half(ctx, lut), ctx.env_pad(dev_half(ctx, env), common.ENV_SIZE, common.ENV_MIPS)
-    for (w, h, full, x0, y0) in ((64, 64, None, 0, 0), (200, 37, (640, 360), 328, 91)):
-        cam, g, lights, gb, tile = common.shade_scene(w, h, n_lights, sh, full=full, x0=x0, y0=y0, rough_min=48)
+    for (w, h, full, x0, y0, rm) in ((64, 64, None, 0, 0, 48), (200, 37, (640, 360), 328, 91, 48), (64, 64, None, 0, 0, 0), (200, 37, (640, 360), 328, 91, 0)):
+        cam, g, lights, gb, tile = common.shade_scene(w, h, n_lights, sh, full=full, x0=x0, y0=y0, rough_min=rm)
         cl = orc.cluster_build(g)
         orc.cluster_cull(g, lights, cl)
         if n_lights == 1024:
             assert cl["NumLights"].max() == 32 and len(lights) > 256
-        _, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
+        _, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+        truth = _truth(orc, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
         got = _shade_f32_on_gpu(ctx, g, tile, gb, dlut, lut.shape[0], denv, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
-        rel, frac = _check_shade_f32(got, want_f32, sens, gb["stencil"], f"f32 shade {w}x{h}, {n_lights} lights")
-        print(f"fp32 shade vs oracle, {w}x{h}, {n_lights} lights: plain relative L-inf {rel:.3g}; {frac * 100:.3f} % of the pixels above 1e-4 (all inside the N.H conditioning allowance)")
+        rg, ro = _check_shade_f32(orc, got, want_f32, truth, gb["stencil"], f"f32 shade {w}x{h}, {n_lights} lights")
+        print(_dist_line(f"{w}x{h}, {n_lights} lights", rg, ro))
 
 
 @pytest.mark.parametrize("w,h", [(256, 144), (1920, 96)])
@@ -352,9 +381,10 @@ def test_deferred_shade_1024_lights_fp16_target(ctx, orc, ibl, w, h):
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     assert (cl["LightIndex"][cl["NumLights"] > 0].max() > 256)        # lists really index beyond the 257-stride table
-    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    truth = _truth(orc, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
-    _check_shade(got, want, want_f32, gb["stencil"], f"1024 lights {w}x{h}", hard_ulp=None, sens=sens)
+    _check_shade(orc, got, want, want_f32, truth, gb["stencil"], f"1024 lights {w}x{h}", hard_ulp=None)
 
 
 def test_deferred_shade_rejects_what_its_32bit_offsets_cannot_address(ctx, orc, ibl):
@@ -385,7 +415,7 @@ def bench_ibl(ctx):
     return lut, env, sh, to_np_half(lut), to_np_half(env)
 
 
-@pytest.mark.parametrize("w,h,rows", [(1920, 1080, 32), (3840, 2160, 32)])
+@pytest.mark.parametrize("w,h,rows", [(1920, 1080, 32), (3840, 2160, 32), (7680, 4320, 16)])
 def test_deferred_shade_band_with_the_bench_ibl(ctx, orc, bench_ibl, w, h, rows):
     """A band of the cfg2 / cfg4 frame (256 lights) shaded against the REAL IBL of the bench — LUT 512^2 and the
     512^2 x 5 env chain, not the 16^2 / 32^2 test set — in fp32 (<= 1e-4 rel L-inf) and on the fp16 target.  The oracle
@@ -395,16 +425,16 @@ def test_deferred_shade_band_with_the_bench_ibl(ctx, orc, bench_ibl, w, h, rows)
     cam, g, lights, gb, tile = common.shade_scene(w, rows, 256, sh, full=(w, h), x0=0, y0=y0, rough_min=48, coverage_mask=False)
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
-    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, 512, 5, cl, lights, want_f32=True, want_sens=True)
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, 512, 5, cl, lights, want_f32=True)
+    truth = _truth(orc, g, tile, gb, lut, env, 512, 5, cl, lights)
     envp = ctx.env_pad(env_d, 512, 5)
     got32 = _shade_f32_on_gpu(ctx, g, tile, gb, lut_d, 512, envp, 512, 5, cl, lights)
-    rel, frac = _check_shade_f32(got32, want_f32, sens, gb["stencil"], f"{w}x{h} band, bench IBL")
-    print(f"fp32 shade vs oracle, {w}x{rows} band of {w}x{h}, 256 lights, bench IBL: plain relative L-inf {rel:.3g}; "
-          f"{frac * 100:.4f} % of the pixels above 1e-4 (all inside the N.H conditioning allowance)")
+    rg, ro = _check_shade_f32(orc, got32, want_f32, truth, gb["stencil"], f"{w}x{h} band, bench IBL")
+    print(_dist_line(f"{w}x{rows} band of {w}x{h}, 256 lights, bench IBL", rg, ro))
     gbd = {k: ctx.upload(v) for k, v in gb.items()}
     hdr = ctx.zeros((rows, w, 4), torch.float16)
     ctx.deferred_shade(g, tile, gbd, w, lut_d, 512, envp, 512, 5, ctx.upload(cl), ctx.upload(lights), len(lights), hdr, w)
-    _check_shade(to_np_half(hdr), want, want_f32, gb["stencil"], f"{w}x{h} band fp16, bench IBL", hard_ulp=None, sens=sens)
+    _check_shade(orc, to_np_half(hdr), want, want_f32, truth, gb["stencil"], f"{w}x{h} band fp16, bench IBL", hard_ulp=None)
 
 
 # ------------------------------------------------------------------------------------------ a14-a15
@@ -605,8 +635,10 @@ def test_frame_1080p_region_properties_and_oracle_sample(ctx, orc, ibl):
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     band = {k: np.ascontiguousarray(v[y0:y0 + rows]) for k, v in gb.items()}
-    want, want_f32, sens = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
-    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "1080p band", sens=sens)
+    band_tile = Tile(0, y0, W, rows, W, H)
+    want, want_f32 = orc.deferred_shade(g, band_tile, band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    truth = _truth(orc, g, band_tile, band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+    _check_shade(orc, shaded[y0:y0 + rows], want, want_f32, truth, band["stencil"], "1080p band")
     fr.bloom()
     fr.histogram()
     hist = fr.hist.cpu().numpy().view(np.uint32).copy()
@@ -834,9 +866,10 @@ def test_deferred_shade_attenuation_floor_and_odd_lists(ctx, orc, ibl):
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     assert (cl["NumLights"] % 2 == 1).any()
-    want, want_f32, sens = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
+    want, want_f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    truth = _truth(orc, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
     got = _shade_on_gpu(ctx, g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
-    _check_shade(got, want, want_f32, gb["stencil"], "attenuation floor / odd lists", sens=sens)
+    _check_shade(orc, got, want, want_f32, truth, gb["stencil"], "attenuation floor / odd lists")
 
 
 @pytest.mark.gpu
@@ -890,8 +923,10 @@ def test_frame_4k_256_lights_full_size_properties_tiles_and_oracle_band(ctx, orc
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     band = {k: np.ascontiguousarray(v[y0:y0 + rows]) for k, v in gb.items()}
-    want, want_f32, sens = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True, want_sens=True)
-    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "4K band", hard_ulp=None, sens=sens)
+    band_tile = Tile(0, y0, W, rows, W, H)
+    want, want_f32 = orc.deferred_shade(g, band_tile, band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    truth = _truth(orc, g, band_tile, band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+    _check_shade(orc, shaded[y0:y0 + rows], want, want_f32, truth, band["stencil"], "4K band", hard_ulp=None)
     full.bloom_histogram()
     hist_full = full.hist.cpu().numpy().view(np.uint32).copy()
     assert hist_full.sum() == W * H
@@ -1008,9 +1043,10 @@ def test_frame_8k_cfg5_full_size_band_properties_and_tiles(ctx, orc, ibl):
     cl = orc.cluster_build(g)
     orc.cluster_cull(g, lights, cl)
     band = {k: np.ascontiguousarray(v[y0:y0 + rows]) for k, v in gb.items()}
-    want, want_f32, sens = orc.deferred_shade(g, Tile(0, y0, W, rows, W, H), band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights,
-                                              want_f32=True, want_sens=True)
-    _check_shade(shaded[y0:y0 + rows], want, want_f32, band["stencil"], "8K band", hard_ulp=None, sens=sens)
+    band_tile = Tile(0, y0, W, rows, W, H)
+    want, want_f32 = orc.deferred_shade(g, band_tile, band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    truth = _truth(orc, g, band_tile, band, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+    _check_shade(orc, shaded[y0:y0 + rows], want, want_f32, truth, band["stencil"], "8K band", hard_ulp=None)
     # the full frame's level 1 (prefilter of the shaded frame), before bloom overwrites the chains
     l1_full = ctx.zeros((H // 2, W // 2, 4), torch.float16)
     ctx.bloom_prefilter(full.hdr, W, H, W, l1_full)

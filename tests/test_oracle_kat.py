@@ -319,3 +319,48 @@ def test_sampler_fixed_point_addressing(orc):
     assert orc.sample_cube_f32(cube, 8, mips, d, 1.3)[0] == np.float32(1.0 + 77.0 / 256.0)
     assert orc.sample_cube_f32(cube, 8, mips, d, 1.0009)[0] == 1.0
     assert orc.sample_cube_f32(cube, 8, mips, d, 7.0)[0] == 3.0                                  # clamped to the last mip
+
+
+def test_f64_truth_brackets_the_fp32_restatement(orc, ibl):
+    """oracle/pbr_oracle_f64.cpp (the double-precision third party of the shade's parity bound) against the fp32 restatement on
+    the 64x64 / 256-light scene: the interval is degenerate except on a small share of sampler-step pixels, the fp32 colour lies
+    within 1e-4 of the exact one everywhere on this scene (its distance is what the GPU tests multiply by 4), flags mark exactly
+    the stencil-0 pixels plus a handful of edge pixels, and — KAT — with no lights, no emission and a constant-radiance
+    environment the exact colour is albedo (1 - m) / pi * L (1 / pi again in the SH pack, Q17) + L * (F0 A + B)."""
+    import common
+    sky, env, lut, sh = ibl
+    cam, g, lights, gb, tile = common.shade_scene(64, 64, 256, sh, rough_min=0)
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    _, f32 = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights, want_f32=True)
+    lo, hi, flags = orc.deferred_shade_f64(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+    assert np.array_equal((flags & 1) != 0, gb["stencil"] == 0)
+    ok = flags == 0
+    assert ((flags > 1).sum()) <= 8 and (lo <= hi).all()
+    scale = np.abs(hi[ok]).max()
+    width = (hi - lo)[ok].max(axis=-1)
+    assert (width > 0).mean() < 0.05 and width.max() < 2e-3 * scale
+    d = orc.truth_distance(f32, lo, hi)[ok]
+    assert d.max() <= 1e-4 * scale and np.median(d) < 1e-7 * scale
+    # KAT: constant environment L, no lights: out = albedo (1 - m) / pi * irr + L (F0 lut.x + lut.y), irr = sha.w = L
+    L = 0.75
+    g2 = type(g).from_buffer_copy(bytes(g))
+    pack = np.zeros(28, np.float32)
+    pack[[3, 11, 19]] = L                      # sha_r.w, sha_g.w, sha_b.w
+    C.memmove(C.addressof(g2.SkyBoxSH), pack.ctypes.data, 112)
+    env_c = np.full_like(env, np.float16(L))
+    nol = lights[:0]
+    cl0 = orc.cluster_build(g2)
+    orc.cluster_cull(g2, nol, cl0)
+    gb2 = {k: v.copy() for k, v in gb.items()}
+    gb2["A"] &= np.uint32(0x00FFFFFF)          # emission 0
+    lo, hi, flags = orc.deferred_shade_f64(g2, tile, gb2, lut, env_c, common.ENV_SIZE, common.ENV_MIPS, cl0, nol)
+    y, x = np.argwhere(flags == 0)[7]
+    a, c = int(gb2["A"][y, x]), int(gb2["C"][y, x])
+    alb = np.array([np.float32(v / np.float32(255.0)) for v in (a & 255, (a >> 8) & 255, (a >> 16) & 255)], np.float64)
+    m = float(np.float32((c >> 8) & 255) / np.float32(255.0))
+    F0 = 0.04 + m * (alb - 0.04)
+    spec = (hi[y, x] + lo[y, x]) / 2 - alb * (1 - m) * 0.31830988618 * L
+    ab = np.linalg.lstsq(np.stack([F0 * L, np.full(3, L)], axis=1), spec, rcond=None)[0]   # the LUT pair this pixel sampled
+    assert np.allclose(np.stack([F0 * L, np.full(3, L)], axis=1) @ ab, spec, rtol=0, atol=1e-12)
+    assert 0.0 <= ab[0] <= 1.01 and 0.0 <= ab[1] <= 1.01
