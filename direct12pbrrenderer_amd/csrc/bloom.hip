@@ -842,7 +842,7 @@ static int blur_h_rows(uint32_t ow, uint32_t oh) {
 // fast-path preconditions: the level below is exactly half, and the size keeps every snapped sample coordinate
 // on its dyadic value (coordinate error ~4 * 2^-24 * size must stay below half a 1/256 step)
 static bool exact_half(uint32_t n) { return (n & 1u) == 0u && n <= 8192u; }
-static bool force_staged() { static const bool v = getenv("PBR_BLOOM_STAGED") != nullptr; return v; }   // A/B switch for tests and profiling
+static bool force_staged() { static const bool v = pbr::knob_set("PBR_BLOOM_STAGED"); return v; }   // A/B switch (knobs build only)
 
 template <int MODE, bool DUAL, int TAIL>
 static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint32_t ih, const pbr_half* in2,
@@ -859,11 +859,11 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
     tr.bx = buf_origin ? (int)buf_origin[0] : 0; tr.by = buf_origin ? (int)buf_origin[1] : 0;
     // histogram instance: ~1024 blocks that each walk the same number of tiles (an uneven split leaves the chip
     // half empty for the last round; one block per tile costs 256 contended global atomics per tile)
-    static const int hist_blocks = getenv("PBR_BLOOM_HIST_BLOCKS") ? atoi(getenv("PBR_BLOOM_HIST_BLOCKS")) : 1024;
+    static const int hist_blocks = pbr::knob_int("PBR_BLOOM_HIST_BLOCKS", 1024);
     auto even_blocks = [](int n_tiles) { const int per = (n_tiles + hist_blocks - 1) / hist_blocks; return (n_tiles + per - 1) / per; };
     if constexpr (MODE == M_UP) {
         // 2x-up levels big enough to fill the chip with 128 x 32 tiles: the two-columns-per-lane kernel (PBR_BLOOM_WIDE=0|1 forces)
-        static const int wide_forced = getenv("PBR_BLOOM_WIDE") ? atoi(getenv("PBR_BLOOM_WIDE")) : -1;
+        static const int wide_forced = pbr::knob_int("PBR_BLOOM_WIDE", -1);
         const int wtx0 = tr.mx0 / 128, wty0 = tr.my0 / 32;
         const int wtiles_x = (tr.mx1 + 127) / 128 - wtx0, wn = wtiles_x * ((tr.my1 + 31) / 32 - wty0);
         if (wide_forced >= 0 ? wide_forced == 1 : wn >= 400) {
@@ -874,7 +874,7 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
         }
     }
     // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 below (PBR_BLOOM_TILE=16: on 4 waves)
-    static const int forced = getenv("PBR_BLOOM_TILE") ? atoi(getenv("PBR_BLOOM_TILE")) : 0;
+    static const int forced = pbr::knob_int("PBR_BLOOM_TILE", 0);
     const bool big = forced ? forced == 32 : (uint64_t)((tr.mx1 + 63) / 64 - tr.mx0 / 64) * ((tr.my1 + 31) / 32 - tr.my0 / 32) >= 900;
     // tiles that intersect the merge rect (TAIL 0 has no rect: every tile of the level)
     const int th = big ? 32 : 16;

@@ -199,7 +199,7 @@ pbr_status pbr_lum_histogram(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, hdr && hist256, "pbr_lum_histogram: null pointer");
     PBR_REQUIRE(ctx, w && h && w <= 65535 && h <= 65535 && pitch >= w, "pbr_lum_histogram: bad size");
-    static const int max_blocks = getenv("PBR_HIST_BLOCKS") ? atoi(getenv("PBR_HIST_BLOCKS")) : HIST_BLOCKS;   // sweep switch
+    static const int max_blocks = pbr::knob_int("PBR_HIST_BLOCKS", HIST_BLOCKS);   // sweep switch (knobs build only)
     size_t n = (size_t)w * h;
     int blocks = (int)((n + 4095) / 4096);   // >= two trips of a block's four 256-pair segments
     if (blocks > max_blocks) blocks = max_blocks;

@@ -534,7 +534,7 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     PBR_REQUIRE(ctx, size >= 1 && mips >= 1 && mips <= 16 && (size >> (mips - 1)) >= 1, "pbr_prefilter_env: bad output size/mips");
     PBR_REQUIRE(ctx, sky && sky->data && sky->size >= 1 && sky->mips >= 1 && (sky->size >> (sky->mips - 1)) >= 1, "pbr_prefilter_env: bad sky cube");
     PBR_REQUIRE(ctx, size <= 8192, "pbr_prefilter_env: bad output size/mips");
-    static const bool sequential = getenv("PBR_PREFILTER_SEQ") != nullptr;   // A/B switch: the thread-per-texel kernel, all mips in one launch
+    static const bool sequential = pbr::knob_set("PBR_PREFILTER_SEQ");   // A/B switch: the thread-per-texel kernel, all mips in one launch
     if (sequential || sky->mips > 16) {
         size_t blocks = 0;
         for (uint32_t m = 0; m < mips; m++) blocks += ((size_t)6 * (size >> m) * (size >> m) + 255) / 256;
@@ -549,7 +549,7 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     const size_t padded_texels = cube_border_mip_offset(sky->size, sky->mips);
     PBR_REQUIRE(ctx, padded_texels <= 0xFFFFFFFFull, "pbr_prefilter_env: sky cube too large");
     ctx->host_tmp.assign((size_t)mips * PBR_SAMPLE_COUNT * 4, 0.0f);
-    static const bool wave_per_texel = getenv("PBR_PREFILTER_WAVE") != nullptr;   // A/B switch: the other mapping
+    static const bool wave_per_texel = pbr::knob_set("PBR_PREFILTER_WAVE");   // A/B switch: the other mapping
     const uint32_t per_block = wave_per_texel ? (uint32_t)PF_TEXELS_PER_BLOCK : 256u;
     uint32_t blocks = 0;
     for (uint32_t m = 1; m < mips; m++) {

@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include "../../include/pbr_hip.h"
 
 struct pbr_ctx {
@@ -46,6 +47,22 @@ inline pbr_status launched(pbr_ctx* ctx, const char* where) {
 }
 
 constexpr size_t SCRATCH_BYTES = 1u << 20;
+
+// Tuning / A-B switches of the launch code.  The PRODUCT library takes every one at its built-in value and never reads the
+// environment: a drop-in must not change its kernel choice on an environment variable.  A build with -DPBR_DEBUG_KNOBS
+// (`make knobs` -> libpbr_hip_knobs.so; used by the tests that force a kernel choice and by the sweep scripts through
+// PBR_HIP_LIB) reads PBR_<NAME> once per call site.
+inline const char* knob_text(const char* name) {
+#ifdef PBR_DEBUG_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+inline int knob_int(const char* name, int dflt) { const char* v = knob_text(name); return v ? atoi(v) : dflt; }
+inline float knob_float(const char* name, float dflt) { const char* v = knob_text(name); return v ? (float)atof(v) : dflt; }
+inline bool knob_set(const char* name) { return knob_text(name) != nullptr; }
 
 }  // namespace pbr
 

@@ -592,8 +592,8 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)env_padded_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
     p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch; p.hdr_f32 = hdr_f32;
     // schedule (see the kernel): long blocks first, short ones for the tail
-    static const float big_frac = getenv("PBR_SHADE_BIGFRAC") ? (float)atof(getenv("PBR_SHADE_BIGFRAC")) : 0.92f;   // re-swept after the per-pixel trims (tools/debug/sched_sweep.sh): 0.9-0.95 with 1-row tail blocks beats 0.85 / 2 by ~0.4 %
-    static const uint32_t rows_small_cfg = getenv("PBR_SHADE_ROWS_SMALL") ? (uint32_t)atoi(getenv("PBR_SHADE_ROWS_SMALL")) : 1u;
+    static const float big_frac = pbr::knob_float("PBR_SHADE_BIGFRAC", 0.92f);   // re-swept after the per-pixel trims (the knobs build): 0.9-0.95 with 1-row tail blocks beats 0.85 / 2 by ~0.4 %
+    static const uint32_t rows_small_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_SMALL", 1);
     const uint32_t rows_small = rows_small_cfg >= 1 && rows_small_cfg <= (uint32_t)SHADE_ROWS ? rows_small_cfg : 1u;
     const uint32_t whole[1][4] = {{0, 0, tile->w, tile->h}};
     if (!rects) { rects = whole; n_rects = 1; }

@@ -845,8 +845,10 @@ def test_bloom_wide_2x_up_kernel_bit_exact(force, sizes):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env.pop("PBR_BLOOM_WIDE", None)
-    if force:
+    if force:   # the switch exists in the knobs build only (the product library never reads the environment)
         env["PBR_BLOOM_WIDE"] = force
+        env["PBR_HIP_LIB"] = os.path.join(root, "direct12pbrrenderer_amd", "libpbr_hip_knobs.so")
+        assert os.path.exists(env["PBR_HIP_LIB"]), "build with make -C direct12pbrrenderer_amd/csrc (target knobs)"
     r = subprocess.run(["timeout", "-k", "10", "500", sys.executable, "-c", _WIDE_BLOOM % (root, os.path.join(root, "tests"), sizes)],
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "wide bloom ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

@@ -110,3 +110,13 @@ def test_host_tile_layout_matches_the_python_tiling_and_halo_plan():
     assert lib.pbrh_tile_layout(7680, 4320, 4, 2, 8, 1, None, None, 0) == -1       # rank outside the grid
     assert lib.pbrh_tile_layout(7680, 4320, 7, 2, 0, 1, None, None, 0) == -1       # 7680 / 7 is not integral
     assert lib.pbrh_tile_layout(1000, 1000, 2, 1, 0, 1, None, None, 0) == -1       # 500-px tiles are not multiples of 16
+
+
+def test_product_library_never_reads_the_environment():
+    """The tuning / A-B switches of the launch code (PBR_* variables) exist in the knobs build only
+    (libpbr_hip_knobs.so, -DPBR_DEBUG_KNOBS): the product library does not even import getenv."""
+    lib = os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_hip.so")
+    knobs = os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_hip_knobs.so")
+    und = lambda path: subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und(lib)
+    assert "getenv" in und(knobs)
