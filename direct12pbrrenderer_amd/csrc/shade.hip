@@ -61,6 +61,15 @@ __device__ __forceinline__ float view_space_depth(float d, float near_z, float f
     return num / den;
 }
 
+// the same expression with v_rcp for the division (<= 2 ulp from the IEEE result): for consumers that are continuous in z_vs
+__device__ __forceinline__ float view_space_depth_quick(float d, float near_z, float far_z) {
+#pragma clang fp contract(off)
+    const float range = far_z - near_z;
+    const float prod = d * range;
+    const float den = far_z - prod;
+    return (near_z * far_z) * rcp(den);
+}
+
 __device__ __forceinline__ float sign_custom(float x) { return x < 0.0f ? -1.0f : 1.0f; }   // global.hlsli:85-88 (Q22)
 
 // global.hlsli:101-115
@@ -144,6 +153,14 @@ __device__ __forceinline__ f2 mul2_sat(f2 a, f2 b) {
     return r;
 }
 
+// {0, 0} in a register pair with one instruction.  (s_nop: the wait state a packed-fp32 consumer of the result needs, which the
+// compiler cannot insert around asm — see mul2_sat.)
+__device__ __forceinline__ f2 zero2() {
+    f2 r;
+    asm("v_pk_mov_b32 %0, 0, 0\n\ts_nop 0" : "=v"(r));
+    return r;
+}
+
 struct alignas(8) H4x2 { H4 a, b; };   // two x-adjacent half4 texels (16 bytes, 8-byte aligned)
 struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-byte aligned)
 
@@ -174,7 +191,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     // v, cvv.y and the cluster row depend on the pixel ROW only: evaluated once per block row (k_deferred_shade, the same
     // expressions) and handed in as row = {v, cvv.y, cluster row} — an IEEE divide, a floor and their neighbours less per pixel
     V3 pos, view, n;
-    float z_vs, roughness;
+    float z_vs, roughness, depth_keep;
     {
         const uint32_t b = at(p.B, gi * 4u), c = at(p.C, gi * 4u);
         const float depth_ndc = at(p.depth, gi * 4u);
@@ -185,8 +202,10 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
                                  p.InvView[6] * cvv.x + p.InvView[7] * cvv.y + p.InvView[8] * cvv.z);
         roughness = (float)(c & 255u) * inv255;
         n = normalize3(decode_octahedron((float)(b & 255u) * inv255, (float)((b >> 8) & 255u) * inv255));
-        // ViewSpaceDepth :74-77, ReconstructWorldPosition :79-83
-        z_vs = view_space_depth(depth_ndc, p.Near, p.Far);
+        // ViewSpaceDepth :74-77, ReconstructWorldPosition :79-83.  Quick form (one v_rcp, <= 2 ulp): the position is continuous in
+        // it; the cluster slice, which is not, re-evaluates the exact IEEE sequence wherever it could matter (below)
+        z_vs = view_space_depth_quick(depth_ndc, p.Near, p.Far);
+        depth_keep = depth_ndc;
         const V3 cam = v3(p.CameraPos[0], p.CameraPos[1], p.CameraPos[2]);
         const float zs = z_vs * p.inv_near;   // not an IEEE divide: the position is continuous in it (the slice index below is not, and keeps its divides)
         pos = v3(cam.x + camera_vec.x * zs, cam.y + camera_vec.y * zs, cam.z + camera_vec.z * zs);
@@ -200,20 +219,25 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     float s1x = 0.0f, s1y = 0.0f, s1z = 0.0f, s2x = 0.0f, s2y = 0.0f, s2z = 0.0f, s3x = 0.0f, s3y = 0.0f, s3z = 0.0f;
     // STAGED_LISTS: every staged list holds at least one pair (empty ones: two null lights), so the walk is a do-while with no
     // branch around it — with one, the compiler zeroes the 18 accumulator registers on both sides of every branch (36 moves per pixel)
+#ifndef PBR_EXP_NOLOOP   // (PBR_EXP_*: compile-time switches of tools/isa_phase_count.py, which sizes the phases of this function)
     if (STAGED_LISTS || n_lights > 0) {
         int sx = (int)floorf(u * (float)PBR_CLUSTER_X);
         int sy = (int)row.z;
-        const float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
+        float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
         // Slice index = (int)(Z * logf(zc / Near) / log(Far / Near)), a discontinuous function of the depth: its value must be the
         // shader's / the oracle's to the bit, which takes two IEEE divides and a full-precision logf (~45 instructions).  A quick
         // estimate t = slice_k * v_log_f32(zc * inv_near) is within 5e-6 of that expression's real value (1-ulp log2 of
         // magnitude <= ~14, two rounded constants), and so is the exact sequence's own result: wherever t is further than 1e-4
-        // from an integer both truncate alike.  Only waves with a lane inside that band (2e-4 of the pixels) run the sequence.
+        // from an integer both truncate alike.  Only waves with a lane inside that band (2e-4 of the pixels) run the sequence —
+        // from the depth texel on: the quick view-space depth above (v_rcp) is within 2 ulp of the IEEE one, i.e. within 3e-7 of
+        // its slice coordinate, far inside the band.
         const float t_quick = p.slice_k * __builtin_amdgcn_logf(zc * p.inv_near);
         const float t_frac = t_quick - floorf(t_quick);
         int sz = (int)t_quick;
-        if (__any(!(t_frac > 1.0e-4f && t_frac < 1.0f - 1.0e-4f)))
+        if (__any(!(t_frac > 1.0e-4f && t_frac < 1.0f - 1.0e-4f))) {
+            zc = fminf(fmaxf(view_space_depth(depth_keep, p.Near, p.Far), p.Near), p.Far);
             sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
+        }
         sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
         sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
         // brdf() (brdf.hlsli:47-67) with D, G, the 4 NdotL NdotV denominator AND the attenuation under ONE reciprocal:
@@ -237,7 +261,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // plain v_fma 2.6 / v_mul 3.0, v_max / v_min 4.6, v_rsq / v_rcp 8.5.  Two lights per trip in the halves of packed
         // registers therefore buy ~1.2x per flop, not 2x; the SoA light planes put the same component of both lights into
         // an adjacent VGPR pair with no moves.  Per trip: 47 packed + 4 transcendental + the loop's compare and pointer step (+ 2 / 4 v_max on the slow paths).
-        f2 a1x = f2s(0.0f), a1y = f2s(0.0f), a1z = f2s(0.0f), a2x = f2s(0.0f), a2y = f2s(0.0f), a2z = f2s(0.0f), a3x = f2s(0.0f), a3y = f2s(0.0f), a3z = f2s(0.0f);
+        // the nine packed sums start at zero: ONE v_pk_mov_b32 per register pair (the compiler writes two v_mov_b32 per pair)
+        f2 a1x = zero2(), a1y = zero2(), a1z = zero2(), a2x = zero2(), a2y = zero2(), a2z = zero2(), a3x = zero2(), a3y = zero2(), a3z = zero2();
         const float att_c0 = llds[6 * LSTRIDE], att_c1 = llds[7 * LSTRIDE], att_c2 = llds[8 * LSTRIDE];   // light 0's polynomial (ATT: everyone's)
         auto light2 = [&](auto q_safe, auto t_safe, const lds_cf* la, const lds_cf* lb, auto att_uniform) {
             constexpr bool QSAFE = decltype(q_safe)::value, TSAFE = decltype(t_safe)::value, ATT = decltype(att_uniform)::value;
@@ -322,6 +347,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         s2x = a2x.x + a2x.y; s2y = a2y.x + a2y.y; s2z = a2z.x + a2z.y;
         s3x = a3x.x + a3x.y; s3y = a3y.x + a3y.y; s3z = a3z.x + a3z.y;
     }
+#endif
 
     // ---- phase 3: material terms (planes A and C re-read: L2 hits, keeps them out of the loop's registers)
     const uint32_t a = at(p.A, gi * 4u);
@@ -343,6 +369,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         out = out + albedo * emission;
 
         // ---- phase 4a: EnvironmentDiffuse :23-54
+#ifndef PBR_EXP_NOSH
         const float bx = n.x * n.y, by = n.y * n.z, bz = n.z * n.z, bw = n.z * n.x;
         const float cc = n.x * n.x - n.y * n.y;
         const pbr_sh_pack& s = p.sh;
@@ -355,11 +382,13 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         out.x += albedo.x * kd * ir;
         out.y += albedo.y * kd * ig;
         out.z += albedo.z * kd * ib;
+#endif
     }
 
     // ---- phase 4b: EnvironmentSpecular :56-70 — padded env chain: each bilinear row is one 16-byte pair
 #ifndef PBR_EXP_NOIBL
     {
+#ifndef PBR_EXP_NOENV
         const V3 R = normalize3(n * (2.0f * NdV) - view);
         float lod = roughness * (float)PBR_ENV_MIPS;   // Q4: roughness*5 on a 5-mip chain
         lod = snap8(fminf(fmaxf(lod, 0.0f), (float)(p.env_mips - 1)));   // 8-bit LOD fraction
@@ -381,7 +410,12 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             cu = (sc * inv + 1.0f) * 0.5f;
             cv = (tc * inv + 1.0f) * 0.5f;
         }
-        auto fetch = [&](uint32_t l, uint32_t mip_off) {
+        // One trilinear sample = eight texels x eight weights.  The shader's nested lerps (x, then y, then level) cost 2 products per
+        // lerp and channel (47 instructions for the three channels); as a weighted sum — weights (1-fx | fx)(1-fy | fy)(1-f | f),
+        // 10 multiplies once — each texel is ONE v_fma_mix_f32 per channel (34 instructions).  The two forms differ by rounding
+        // only (~3 ulp of fp32 on a convex combination of fp16 texels).
+        struct Foot { H4x2 r0, r1; float w00, w10, w01, w11; };
+        auto foot = [&](uint32_t l, uint32_t mip_off, float wl) {
             const int s = (int)(p.env_size >> l), sq = s + 1;
             // u in [0,1] -> texel coordinate in [-0.5, s-0.5]: no NaN / range guard needed here; x.8 fixed-point snap
             const float fxp = snap8(cu * (float)s) - 0.5f, fyp = snap8(cv * (float)s) - 0.5f;
@@ -392,21 +426,33 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             // (host-checked: the padded chain is smaller than 4 GiB)
             const uint32_t o = __umul24(__umul24(face, (uint32_t)sq) + (uint32_t)((int)fly + 1), (uint32_t)sq) + (uint32_t)((int)flx + 1);
             const char* q = reinterpret_cast<const char*>(p.env) + (mip_off + o * 4u) * 8u;
-            const H4x2 r0 = *reinterpret_cast<const H4x2*>(q);
-            const H4x2 r1 = *reinterpret_cast<const H4x2*>(q + 16);
-            const float wx0 = 1.0f - fx, wy0 = 1.0f - fy;
-            // a * wx0 + b * fx with BOTH products as v_fma_mix_f32 (the fp16 -> fp32 conversion rides in the instruction): written
-            // as fma(a, wx0, 0) the first product keeps its rounding and loses its separate v_cvt
-            auto xl = [&](h16 a, h16 b) { return __builtin_fmaf((float)b, fx, __builtin_fmaf((float)a, wx0, 0.0f)); };
-            const float tr = xl(r0.a.x, r0.b.x), br = xl(r1.a.x, r1.b.x);
-            const float tg = xl(r0.a.y, r0.b.y), bg = xl(r1.a.y, r1.b.y);
-            const float tb = xl(r0.a.z, r0.b.z), bb = xl(r1.a.z, r1.b.z);
-            return v3(tr * wy0 + br * fy, tg * wy0 + bg * fy, tb * wy0 + bb * fy);
+            Foot f;
+            f.r0 = *reinterpret_cast<const H4x2*>(q);
+            f.r1 = *reinterpret_cast<const H4x2*>(q + 16);
+            const float wy1 = fy * wl, wy0 = wl - wy1;         // (1 - fy) wl, fy wl
+            f.w10 = fx * wy0; f.w00 = wy0 - f.w10;             // (1 - fx)(1 - fy) wl, fx (1 - fy) wl
+            f.w11 = fx * wy1; f.w01 = wy1 - f.w11;
+            return f;
         };
-        const V3 ea = fetch(l0, mip_off[l0]);   // per-lane index: the table sits in LDS (an SGPR array would spill to scratch)
-        const V3 eb = fetch(l1, mip_off[l1]);
-        const float w0 = 1.0f - env_f;
-        const V3 envc = v3(ea.x * w0 + eb.x * env_f, ea.y * w0 + eb.y * env_f, ea.z * w0 + eb.z * env_f);
+        const Foot fa = foot(l0, mip_off[l0], 1.0f - env_f);   // per-lane index: the table sits in LDS (an SGPR array would spill to scratch)
+        const Foot fb = foot(l1, mip_off[l1], env_f);
+        auto chan = [&](h16 a00, h16 a10, h16 a01, h16 a11, h16 b00, h16 b10, h16 b01, h16 b11) {
+            float r = __builtin_fmaf((float)a00, fa.w00, 0.0f);   // fma(x, w, 0): the first product as v_fma_mix_f32 too (no separate v_cvt)
+            r = __builtin_fmaf((float)a10, fa.w10, r);
+            r = __builtin_fmaf((float)a01, fa.w01, r);
+            r = __builtin_fmaf((float)a11, fa.w11, r);
+            r = __builtin_fmaf((float)b00, fb.w00, r);
+            r = __builtin_fmaf((float)b10, fb.w10, r);
+            r = __builtin_fmaf((float)b01, fb.w01, r);
+            return __builtin_fmaf((float)b11, fb.w11, r);
+        };
+        const V3 envc = v3(chan(fa.r0.a.x, fa.r0.b.x, fa.r1.a.x, fa.r1.b.x, fb.r0.a.x, fb.r0.b.x, fb.r1.a.x, fb.r1.b.x),
+                           chan(fa.r0.a.y, fa.r0.b.y, fa.r1.a.y, fa.r1.b.y, fb.r0.a.y, fb.r0.b.y, fb.r1.a.y, fb.r1.b.y),
+                           chan(fa.r0.a.z, fa.r0.b.z, fa.r1.a.z, fa.r1.b.z, fb.r0.a.z, fb.r0.b.z, fb.r1.a.z, fb.r1.b.z));
+#else
+        const V3 envc = v3(0.5f, 0.5f, 0.5f);
+#endif
+#ifndef PBR_EXP_NOLUT
         // LUT bilinear with clamp addressing (Q5): one 8-byte pair per row; at the borders both taps are
         // the same texel, picked out of the pair that stays inside the row
         // Both coordinates lie in [0, 1] (UNORM8 roughness, clamped N.V): no NaN / range guard; x.8 fixed-point snap as in
@@ -434,6 +480,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         auto xl = [&](h16 a, h16 b) { return __builtin_fmaf((float)b, fx, __builtin_fmaf((float)a, wx0, 0.0f)); };   // two v_fma_mix_f32, see fetch
         const float la = xl(lt0.a.x, lt0.b.x) * wy0 + xl(lt1.a.x, lt1.b.x) * fy;
         const float lb = xl(lt0.a.y, lt0.b.y) * wy0 + xl(lt1.a.y, lt1.b.y) * fy;
+#else
+        const float la = 0.5f, lb = 0.25f;
+#endif
         out.x += envc.x * (F0.x * la + lb);
         out.y += envc.y * (F0.y * la + lb);
         out.z += envc.z * (F0.z * la + lb);

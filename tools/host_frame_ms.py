@@ -1,46 +1,31 @@
-"""Frame time of the C++ pass graph (libpbr_host.so: RenderScheduler -> FrameGraph -> passes -> C ABI) at 4K with 256
-lights, dispatch by dispatch and with fused passes; every frame ends with the reference's per-frame fence wait."""
-import ctypes as C
+"""Frame time of the C++ pass graph (libpbr_host.so: RenderScheduler -> FrameGraph -> passes -> HipCommandList -> C ABI) at
+4K with 256 lights: every reference dispatch issued one by one / fused passes, each with the reference's per-frame fence
+wait (D3D12Device::EndFrame) and in throughput mode (3 frames in flight).  The bench line carries the same figures in its
+`host_graph` block; this tool is what the rocprofv3 kernel trace of the drop-in path runs (tools/host_trace.sh).
+usage: python tools/host_frame_ms.py [frames]"""
 import os
 import sys
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from direct12pbrrenderer_amd import scene, synth  # noqa: E402
+from direct12pbrrenderer_amd.host import HostRenderer  # noqa: E402
 
-L = C.CDLL(os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_host.so"))
-L.pbrh_create.restype = C.c_void_p
-L.pbrh_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
-L.pbrh_destroy.argtypes = [C.c_void_p]
-L.pbrh_set_skybox.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
-L.pbrh_set_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-L.pbrh_set_gbuffer.argtypes = [C.c_void_p] * 6
-L.pbrh_set_initial_luminance.argtypes = [C.c_void_p, C.c_float]
-L.pbrh_set_fused.argtypes = [C.c_void_p, C.c_int]
-L.pbrh_render.argtypes = [C.c_void_p, C.c_float]
-L.pbrh_render_n.argtypes = [C.c_void_p, C.c_int, C.c_float, C.POINTER(C.c_double)]
-L.pbrh_dispatch_count.argtypes = [C.c_void_p]
-
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 W, H, ENV, LUT = 3840, 2160, 512, 512
-sky = synth.env_cube(ENV)
 cam = scene.Camera.reference_default(W, H)
-lights = synth.lights_in_view_box(256, cam)
-packed = np.ascontiguousarray(np.concatenate([lights["Position"], lights["Color"], np.full((256, 1), 2.0, np.float32), lights["Intensity"][:, None]], axis=1).astype(np.float32))
-gb = synth.gbuffer_tile(0, 0, W, H, W, H)
-err = C.create_string_buffer(256)
-r = L.pbrh_create(0, W, H, ENV, LUT, err, 256)
-assert r, err.value
-assert L.pbrh_set_skybox(r, sky[:4 * 6 * ENV * ENV].ctypes.data, ENV) == 0
-assert L.pbrh_set_lights(r, packed.ctypes.data, 256) == 0
-assert L.pbrh_set_gbuffer(r, *[np.ascontiguousarray(gb[k]).ctypes.data for k in ("A", "B", "C", "depth", "stencil")]) == 0
-L.pbrh_set_initial_luminance(r, 0.18)
+r = HostRenderer(0, W, H, ENV, LUT)
+r.set_skybox(synth.env_cube(ENV), ENV)
+r.set_lights(synth.lights_in_view_box(256, cam))
+r.set_gbuffer(synth.gbuffer_tile(0, 0, W, H, W, H))
+r.set_initial_luminance(0.18)
+r.render()
 for fused in (0, 1):
-    L.pbrh_set_fused(r, fused)
-    assert L.pbrh_render(r, 1.0 / 60.0) == 0
-    ms = C.c_double(0.0)
-    assert L.pbrh_render_n(r, 50, 1.0 / 60.0, C.byref(ms)) == 0
-    print(f"host pass graph, {'fused passes' if fused else 'dispatch by dispatch'}: {ms.value:.4f} ms/frame ({L.pbrh_dispatch_count(r)} dispatches/frame) "
-          f"= {W * H / ms.value / 1e3:.0f} Mpixel/s", flush=True)
-L.pbrh_destroy(r)
+    r.set_fused(fused)
+    for in_flight in (1, 3):
+        r.set_frames_in_flight(in_flight)
+        r.render_n(frames)
+        ms = r.render_n(frames)
+        print(f"host pass graph, {'fused passes' if fused else 'dispatch by dispatch'}, {'fence per frame' if in_flight == 1 else '3 frames in flight'}: "
+              f"{ms:.4f} ms/frame ({r.dispatch_count()} dispatches/frame) = {W * H / ms / 1e3:.0f} Mpixel/s", flush=True)
+r.close()
