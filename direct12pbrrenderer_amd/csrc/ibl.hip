@@ -394,95 +394,121 @@ static uint32_t build_prefilter_table(float roughness, uint32_t size, uint32_t s
 // (27 accumulators per thread -> wave shuffle reduce -> LDS -> one row of 27 per block).
 // Stage 2: one block sums the rows in a fixed order in fp64 and applies SH.cpp:135-151 + the
 // pack of SH.cpp:201-222.  Deterministic (no float atomics).
-constexpr int SH_BLOCKS = 512;
+constexpr int SH_MAX_BLOCKS = 512;    // rows of the partial-sum table in the context's scratch area (27 floats each)
 
+// wave-level sum in a FIXED order (xor butterfly: every lane ends with the same value)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_sh9_partial(const float* __restrict__ sky, uint32_t size, float* __restrict__ partial) {
-    const size_t n = (size_t)6 * size * size;
+// Stage 1.  grid (ceil(size / 256), ceil(size / rows), 6), block 256: a thread owns ONE column x of a face and walks `rows`
+// rows of it — no index division at all (u depends on x, v on the row: wave-uniform), every wave reads 1 KiB row segments,
+// several 16-byte loads in flight per lane.  27 accumulators per thread -> butterfly over the wave -> LDS over the four waves
+// -> one row of the partial table per block.
+// Stage 2 (k_sh9_finish, one block): column sums of the table in fp64 in a fixed order, SH.cpp:140-151 / :204-219, the pack.
+// (One launch with the LAST block finishing — ticket from a device-scope atomic behind a release fence — was built and
+// measured: 47 us against 43 for the old pair.  An agent-scope fence on this part writes back / invalidates the XCD's L2,
+// ~1 us a time, and every one of the ~400 blocks pays it; the kernel boundary does the same once.)
+__global__ __launch_bounds__(256) void k_sh9_partial(const float* __restrict__ sky, uint32_t size, uint32_t rows, float* __restrict__ partial) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x, face = blockIdx.z;
+    const uint32_t y0 = blockIdx.y * rows, y1 = min(y0 + rows, size);
+    const uint32_t bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     float acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) acc[i] = 0.0f;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
-        const uint32_t x = (uint32_t)(t % size), y = (uint32_t)((t / size) % size), f = (uint32_t)(t / ((size_t)size * size));
-        const float u = 2.0f * ((float)x + 0.5f) / (float)size - 1.0f;
-        const float v = 2.0f * ((float)y + 0.5f) / (float)size - 1.0f;
-        const V3 raw = cube_dir_raw(f, u, v);
-        const float r2 = dot3(raw, raw);
-        const float inv = 1.0f / sqrtf(r2);
-        const V3 d = raw * inv;
-        const float dw = (4.0f / ((float)size * (float)size)) * (inv * inv * inv);   // texel solid angle
-        const float4 c = reinterpret_cast<const float4*>(sky)[t];
-        float Y[9];   // SH.cpp:6-37
-        Y[0] = 0.282095f;
-        Y[1] = 0.488603f * d.y;
-        Y[2] = 0.488603f * d.z;
-        Y[3] = 0.488603f * d.x;
-        Y[4] = 1.092548f * d.x * d.y;
-        Y[5] = 1.092548f * d.y * d.z;
-        Y[6] = 0.315392f * (3.0f * d.z * d.z - 1.0f);
-        Y[7] = 1.092548f * d.x * d.z;
-        Y[8] = 0.546274f * (d.x * d.x - d.y * d.y);
-        const float r = c.x * dw, g = c.y * dw, b = c.z * dw;
+    if (x < size) {
+        const float inv_size = 1.0f / (float)size;
+        const float u = 2.0f * ((float)x + 0.5f) * inv_size - 1.0f;
+        const float dw0 = 4.0f * inv_size * inv_size;
+        const float4* col = reinterpret_cast<const float4*>(sky) + ((size_t)face * size) * size + x;
+#pragma unroll 4
+        for (uint32_t y = y0; y < y1; y++) {
+            const float4 c = col[(size_t)y * size];
+            const float v = 2.0f * ((float)y + 0.5f) * inv_size - 1.0f;
+            const V3 raw = cube_dir_raw(face, u, v);
+            const float inv = rsq(dot3(raw, raw));
+            const V3 d = raw * inv;
+            const float dw = dw0 * (inv * inv * inv);   // texel solid angle
+            float Y[9];   // SH.cpp:6-37
+            Y[0] = 0.282095f;
+            Y[1] = 0.488603f * d.y;
+            Y[2] = 0.488603f * d.z;
+            Y[3] = 0.488603f * d.x;
+            Y[4] = 1.092548f * d.x * d.y;
+            Y[5] = 1.092548f * d.y * d.z;
+            Y[6] = 0.315392f * (3.0f * d.z * d.z - 1.0f);
+            Y[7] = 1.092548f * d.x * d.z;
+            Y[8] = 0.546274f * (d.x * d.x - d.y * d.y);
+            const float r = c.x * dw, g = c.y * dw, b = c.z * dw;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            acc[k] += r * Y[k];
-            acc[9 + k] += g * Y[k];
-            acc[18 + k] += b * Y[k];
+            for (int k = 0; k < 9; k++) {
+                acc[k] += r * Y[k];
+                acc[9 + k] += g * Y[k];
+                acc[18 + k] += b * Y[k];
+            }
         }
     }
     __shared__ float red[4][27];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 27; i++) {
-        float s = wave_sum(acc[i]);
+        const float s = wave_sum(acc[i]);
         if (lane == 0) red[wave][i] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 27) {
-        partial[(size_t)blockIdx.x * 27 + threadIdx.x] =
-            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    }
+    if (threadIdx.x < 27)
+        partial[(size_t)bid * 27 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// 27 coefficients x 8 interleaved fp64 partial sums (rows j, j+8, ...), combined in a fixed tree: deterministic, and
-// eight times shorter than one serial chain of dependent loads per coefficient
-__global__ __launch_bounds__(256) void k_sh9_finish(const float* __restrict__ partial, int nblocks, float* __restrict__ out_pack) {
-    __shared__ float c[27];
-    __shared__ double part[8][27];
-    const int t = threadIdx.x;
-    if (t < 216) {
-        const int coef = t % 27, j = t / 27;
-        double s = 0.0;
-        for (int b = j; b < nblocks; b += 8) s += (double)partial[(size_t)b * 27 + coef];
-        part[j][coef] = s;
+// column sums of the nblocks x 27 table in fp64, fixed order: thread t takes rows t, t + 256, ... (27 independent loads per
+// row, all in flight), then a butterfly over the wave and a fixed tree over the four waves
+__global__ __launch_bounds__(256) void k_sh9_finish(const float* __restrict__ partial, uint32_t nblocks, float* __restrict__ out_pack) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double dred[4][27];
+    __shared__ float cfin[27];
+    double sum[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) sum[i] = 0.0;
+    for (uint32_t b = threadIdx.x; b < nblocks; b += 256) {
+        const float* row = partial + (size_t)b * 27;
+#pragma unroll
+        for (int i = 0; i < 27; i++) sum[i] += (double)row[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 27; i++) {
+        const double sfull = wave_sum_d(sum[i]);
+        if (lane == 0) dred[wave][i] = sfull;
     }
     __syncthreads();
+    const int t = threadIdx.x;
     if (t < 27) {
-        const double s = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) + ((part[4][t] + part[5][t]) + (part[6][t] + part[7][t]));
+        const double sfull = (dred[0][t] + dred[1][t]) + (dred[2][t] + dred[3][t]);
         const int n = t % 9;
         const int l = n == 0 ? 0 : (n < 4 ? 1 : 2);
         // SH.cpp:140-151: c = InvPI * K * A * L, then * basis constant (SH.cpp:204-209)
         const float K = sqrtf(4.0f * PI_F / (float)(2 * l + 1));
         const float A = l == 0 ? sqrtf(PI_F) / 2.0f : (l == 1 ? sqrtf(PI_F / 3.0f) : sqrtf(5.0f * PI_F) / 8.0f);
         const float basis[9] = {0.282095f, 0.488603f, 0.488603f, 0.488603f, 1.092548f, 1.092548f, 0.315392f, 1.092548f, 0.546274f};
-        float v = INV_PI_F * K * A * (float)s;
-        c[t] = v * basis[n];
+        const float v = INV_PI_F * K * A * (float)sfull;
+        cfin[t] = v * basis[n];
     }
     __syncthreads();
     if (t < 3) {   // channel t: sha_* = (c3,c1,c2,c0), shb_* = (c4,c5,3*c6,c7)   (SH.cpp:213-218, Q16)
-        const float* cc = c + 9 * t;
+        const float* cc = cfin + 9 * t;
         float* sha = out_pack + 8 * t;
         float* shb = sha + 4;
         sha[0] = cc[3]; sha[1] = cc[1]; sha[2] = cc[2]; sha[3] = cc[0];
         shb[0] = cc[4]; shb[1] = cc[5]; shb[2] = cc[6] * 3.0f; shb[3] = cc[7];
     }
     if (t == 3) {   // shc = (c8r, c8g, c8b, 0)  (SH.cpp:219)
-        out_pack[24] = c[8]; out_pack[25] = c[17]; out_pack[26] = c[26]; out_pack[27] = 0.0f;
+        out_pack[24] = cfin[8]; out_pack[25] = cfin[17]; out_pack[26] = cfin[26]; out_pack[27] = 0.0f;
     }
 }
 
@@ -593,15 +619,17 @@ pbr_status pbr_sh9_project(pbr_ctx* ctx, const pbr_cube_f32* sky, float* out_pac
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, sky && sky->data && out_pack, "pbr_sh9_project: null pointer");
     PBR_REQUIRE(ctx, sky->size >= 1 && sky->size <= 8192, "pbr_sh9_project: bad cube size");
-    size_t n = (size_t)6 * sky->size * sky->size;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > SH_BLOCKS) blocks = SH_BLOCKS;
-    PBR_REQUIRE(ctx, (size_t)blocks * 27 * sizeof(float) <= ctx->scratch_bytes, "pbr_sh9_project: scratch too small");
+    const uint32_t size = sky->size, cols = (size + 255) / 256;
+    // rows per block: as few as keep the partial table within SH_MAX_BLOCKS rows (512^2: 16 rows -> 2 x 32 x 6 = 384 blocks)
+    uint32_t rows = 1;
+    while ((uint64_t)cols * ((size + rows - 1) / rows) * 6 > (uint64_t)SH_MAX_BLOCKS) rows *= 2;
+    const uint32_t gy = (size + rows - 1) / rows;
+    PBR_REQUIRE(ctx, (size_t)SH_MAX_BLOCKS * 27 * sizeof(float) <= ctx->scratch_bytes, "pbr_sh9_project: scratch too small");
     float* partial = (float*)ctx->scratch;
-    hipLaunchKernelGGL(k_sh9_partial, dim3(blocks), dim3(256), 0, ctx->stream, sky->data, sky->size, partial);
+    hipLaunchKernelGGL(k_sh9_partial, dim3(cols, gy, 6), dim3(256), 0, ctx->stream, sky->data, size, rows, partial);
     pbr_status r = launched(ctx, "k_sh9_partial");
     if (r) return r;
-    hipLaunchKernelGGL(k_sh9_finish, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, out_pack);
+    hipLaunchKernelGGL(k_sh9_finish, dim3(1), dim3(256), 0, ctx->stream, partial, cols * gy * 6u, out_pack);
     return launched(ctx, "k_sh9_finish");
 }
 

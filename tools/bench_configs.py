@@ -3,7 +3,9 @@
 cfg1 LUT 256^2 / 512^2, cfg2 1080p shade with 1 point light (+ full frame), cfg3 512^2 prefilter (5 mips, 1 024 spp)
 + SH9, cfg5 one rank's share of the 8K frame (the busiest 1920x2160 tile of the 2 rows x 4 cols layout) in apron mode
 (tile + 256-px apron, everything measured) and in halo mode (tile + 4 px; the neighbours' level-1 strips cannot arrive on a
-one-GPU box, so the exchange itself is not in the figure — its plane is filled once before the clock).  One JSON line per config."""
+one-GPU box, so the exchange itself is not in the figure — its plane is filled once before the clock).  One JSON line per config.
+cfg1 - cfg3 also get their CPU leg: the oracle (kind "port") on all host threads, median of 5, on the
+whole config where that takes seconds and on a stated sample where it does not.  `--no-cpu` skips those legs."""
 import json
 import os
 import sys
@@ -21,6 +23,36 @@ from direct12pbrrenderer_amd.structs import ENV_MIPS  # noqa: E402
 
 ctx = PbrContext(0)
 out = []
+CPU = "--no-cpu" not in sys.argv
+
+
+def cpu_median(fn, reps=5):
+    """median wall time (s) of `fn` over `reps` runs after one warm-up — the oracle uses every host thread (OpenMP)"""
+    import time
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def kept_samples(roughness, n=1024):
+    """How many of the n Hammersley / GGX samples of env_map_gen.hlsl have N.L > 0 at this roughness (V = N): the others
+    contribute nothing and the table-driven kernel drops them."""
+    i = np.arange(n, dtype=np.uint32)
+    bits = i.copy()
+    bits = (bits << 16) | (bits >> 16)
+    bits = ((bits & 0x55555555) << 1) | ((bits & 0xAAAAAAAA) >> 1)
+    bits = ((bits & 0x33333333) << 2) | ((bits & 0xCCCCCCCC) >> 2)
+    bits = ((bits & 0x0F0F0F0F) << 4) | ((bits & 0xF0F0F0F0) >> 4)
+    bits = ((bits & 0x00FF00FF) << 8) | ((bits & 0xFF00FF00) >> 8)
+    xi_y = bits.astype(np.float32) * np.float32(2.3283064365386963e-10)
+    a = np.float32(roughness) * np.float32(roughness)
+    hz = np.sqrt((np.float32(1.0) - xi_y) / (np.float32(1.0) + (a * a - np.float32(1.0)) * xi_y))
+    return int((np.float32(2.0) * hz * hz - np.float32(1.0) > 0).sum())
+
 
 
 def emit(**kw):
@@ -32,8 +64,14 @@ def emit(**kw):
 for res in (256, 512):
     buf = ctx.empty((res, res, 2), torch.float16)
     ms = bench.time_stage(lambda: ctx.brdf_lut(res, out=buf), 10)
-    emit(config="cfg1", what=f"BRDF LUT {res}x{res}, 1024 spp", ms=round(ms, 4), Msamples_per_s=round(res * res * 1024 / ms / 1e3, 1),
-         Mtexels_per_s=round(res * res / ms / 1e3, 2))
+    rec = dict(config="cfg1", what=f"BRDF LUT {res}x{res}, 1024 spp", ms=round(ms, 4), Msamples_per_s=round(res * res * 1024 / ms / 1e3, 1),
+               Mtexels_per_s=round(res * res / ms / 1e3, 2))
+    if CPU:
+        from oracle import binding as orc
+        dt = cpu_median(lambda: orc.brdf_lut(res))
+        rec["cpu_baseline"] = {"value": round(res * res * 1024 / dt / 1e6, 1), "unit": "Msamples/s", "ms": round(dt * 1e3, 2), "cores": orc.num_threads(), "kind": "port",
+                               "sample": f"the whole {res}x{res} plane (oracle/pbr_oracle.cpp orc_brdf_lut, OpenMP), median of 5"}
+    emit(**rec)
 
 # ---- cfg3: prefilter + SH9 on the 512^2 cube
 sky_mips = 10
@@ -42,11 +80,40 @@ ctx.cube_gen_mips(sky, 512, sky_mips)
 envbuf = ctx.prefilter_env(sky, 512, sky_mips, 512, ENV_MIPS)
 ms = bench.time_stage(lambda: ctx.prefilter_env(sky, 512, sky_mips, 512, ENV_MIPS, out=envbuf), 5)
 texels = 6 * sum((512 >> m) ** 2 for m in range(5))
-emit(config="cfg3", what="GGX prefilter 512^2 cube, 5 mips, 1024 spp", ms=round(ms, 3), Gsamples_per_s=round(texels * 1024 / ms / 1e6, 2),
-     Mtexels_per_s=round(texels / ms / 1e3, 2))
+# what the kernel EVALUATES: mip 0 (roughness 0) is one fetch per texel; mips 1..4 loop over the samples with N.L > 0
+evaluated = 6 * 512 * 512 + sum(6 * (512 >> m) ** 2 * kept_samples(m / 4.0) for m in range(1, 5))
+rec = dict(config="cfg3", what="GGX prefilter 512^2 cube, 5 mips, 1024 spp", ms=round(ms, 3),
+           Gsamples_per_s_reference_equivalent=round(texels * 1024 / ms / 1e6, 2), Gsamples_per_s_evaluated=round(evaluated / ms / 1e6, 2),
+           evaluated_samples=evaluated, reference_samples=texels * 1024, Mtexels_per_s=round(texels / ms / 1e3, 2),
+           note="reference_equivalent = output texels x 1024 (what env_map_gen.hlsl loops over); evaluated = fetches the kernel performs (mip 0: 1 per texel; "
+                "mips 1-4: the samples with N.L > 0)")
+if CPU:
+    from oracle import binding as orc
+    sky_np = sky.cpu().numpy()
+    rng = np.random.default_rng(7)
+    n_s = 2048
+    picks = {m: rng.integers(0, 6 * (512 >> m) ** 2, n_s).astype(np.uint32) for m in range(5)}
+    import time
+    orc.prefilter_env_texels(sky_np, 512, sky_mips, 512, ENV_MIPS, 1, picks[1][:256])   # warm-up (OpenMP team, page faults)
+    # each mip's sample scaled to the mip's texel count (the shader's loop is 1024 iterations per texel on every mip)
+    est = 0.0
+    for m in range(5):
+        t0 = time.perf_counter()
+        orc.prefilter_env_texels(sky_np, 512, sky_mips, 512, ENV_MIPS, m, picks[m])
+        est += (time.perf_counter() - t0) / n_s * 6 * (512 >> m) ** 2
+    rec["cpu_baseline"] = {"value": round(texels * 1024 / est / 1e9, 3), "unit": "Gsamples/s (reference-equivalent)", "ms_estimated_whole_config": round(est * 1e3, 1),
+                           "cores": orc.num_threads(), "kind": "port",
+                           "sample": f"{n_s} random texels of each of the 5 mips (orc_prefilter_env_texels, OpenMP), each mip's time scaled to its texel count"}
+emit(**rec)
 shbuf = ctx.empty((28,), torch.float32)
 ms = bench.time_stage(lambda: ctx.sh9_project(sky, 512, sky_mips, out=shbuf), 10)
-emit(config="cfg3", what="SH9 projection of the 512^2 cube (quadrature, 25.2 MB in)", ms=round(ms, 4), GBps=round(6 * 512 * 512 * 16 / ms / 1e6, 1))
+rec = dict(config="cfg3", what="SH9 projection of the 512^2 cube (quadrature, 25.2 MB in)", ms=round(ms, 4), GBps=round(6 * 512 * 512 * 16 / ms / 1e6, 1),
+           frac_of_8TBps=round(6 * 512 * 512 * 16 / ms / 1e6 / 8000.0, 3))
+if CPU:
+    dt = cpu_median(lambda: orc.sh9_project(sky_np, 512))
+    rec["cpu_baseline"] = {"value": round(6 * 512 * 512 * 16 / dt / 1e9, 2), "unit": "GB/s", "ms": round(dt * 1e3, 2), "cores": orc.num_threads(), "kind": "port",
+                           "sample": "the whole 512^2 cube (orc_sh9_project quadrature, OpenMP), median of 5"}
+emit(**rec)
 ms = bench.time_stage(lambda: ctx.env_pad(envbuf, 512, ENV_MIPS), 10)
 emit(config="cfg3", what="env_pad (padded copy of the prefiltered chain)", ms=round(ms, 4))
 
@@ -78,10 +145,24 @@ def frame_times(name, spec, n_lights, what, cell=1, all_specs=None, rank=0, over
     fr.hist.zero_()
     full = bench.time_stage(fr.render, 20)
     shaded, inner = spec.sw * spec.sh, spec.w * spec.h
-    emit(config=name, what=what, shade_ms=round(shade, 4), bloom_histogram_ms=round(bloom, 4), frame_ms=round(full, 4),
-         shade_Mpixel_per_s=round(shaded / shade / 1e3, 1),
-         shade_GBps_algorithmic=round(25.0 * shaded / shade / 1e6, 1), frame_Mpixel_per_s_interior=round(inner / full / 1e3, 1),
-         shaded_pixels=shaded, bloom_pixels=spec.ew * spec.eh, interior_pixels=inner)
+    rec = dict(config=name, what=what, shade_ms=round(shade, 4), bloom_histogram_ms=round(bloom, 4), frame_ms=round(full, 4),
+               shade_Mpixel_per_s=round(shaded / shade / 1e3, 1),
+               shade_GBps_algorithmic=round(25.0 * shaded / shade / 1e6, 1), frame_Mpixel_per_s_interior=round(inner / full / 1e3, 1),
+               shaded_pixels=shaded, bloom_pixels=spec.ew * spec.eh, interior_pixels=inner)
+    if CPU and name == "cfg2":   # the 1080p / 1-light shade on the host cores (oracle, whole frame)
+        from oracle import binding as orc
+        from direct12pbrrenderer_amd.structs import Tile
+        gb = synth.gbuffer_tile(0, 0, spec.w, spec.h, spec.w, spec.h)
+        lut_np = lut.cpu().view(torch.int16).numpy().view(np.float16)
+        env_np = env.cpu().view(torch.int16).numpy().view(np.float16)
+        def shade_cpu():
+            cl = orc.cluster_build(g)
+            orc.cluster_cull(g, lights, cl)
+            orc.deferred_shade(g, Tile(0, 0, spec.w, spec.h, spec.w, spec.h), gb, lut_np, env_np, 512, ENV_MIPS, cl, lights)
+        dt = cpu_median(shade_cpu)
+        rec["cpu_baseline"] = {"value": round(spec.w * spec.h / dt / 1e6, 2), "unit": "Mpixel/s (shade only)", "ms": round(dt * 1e3, 1), "cores": orc.num_threads(), "kind": "port",
+                               "sample": "the whole 1920x1080 frame: cluster build + cull + deferred shade (oracle, OpenMP), inputs synthesised outside the clock, median of 5"}
+    emit(**rec)
 
 
 frame_times("cfg2", TileSpec(0, 0, 1920, 1080, 1920, 1080, 0), 1, "1920x1080 G-buffer, 1 point light + IBL")
