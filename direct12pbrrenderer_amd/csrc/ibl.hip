@@ -333,6 +333,131 @@ __global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict_
     store_h4(out + 4 * (cube_mip_offset(pl.size, mip) + (size_t)t), f4(cr / w, cg / w, cb / w, 1.0f));
 }
 
+// ---- the same table-driven, texel-per-lane loop on a HALF-precision FOOTPRINT copy of the source chain (what pbr_prefilter_env
+// launches for mips >= 1).  Counters of k_prefilter_tex (profiles/r03_*): VALU busy ~100 % (168 instructions per sample) AND
+// the texture addresser 74 % busy — eight 16-byte gathers per lane and sample move 128 B through a 64 B / clk path.  Here:
+//  * the source chain is copied once per call into the footprint layout the shade samples (k_cube_foot_h4: the four texels of
+//    every bilinear footprint, seams resolved, stored together) as half4: a trilinear sample is FOUR 16-byte loads = 64 B.
+//    Rounding the fp32 source to half costs <= 2^-11 relative per texel, spread over ~500-1000 samples of a texel whose
+//    result is rounded to half anyway (the reference's own source went through BC6H_UF16 on disk, BasicStorage.h:10-11);
+//    mip 0 — one fetch per texel, no averaging — stays on the fp32 chain (k_prefilter_mip0);
+//  * cube face / coordinates from v_cubeid / v_cubesc / v_cubetc / v_cubema + one v_rcp (continuous consumers only);
+//  * the sample's eight texels enter the sum as eight weighted v_fma_mix_f32 per channel, the sample weight N.L folded into
+//    the weights: no separate lerps, no fp16 -> fp32 converts.
+// The LOD of a sample comes from the table: wave-uniform, so level sizes and offsets stay in scalar registers.
+typedef uint32_t pf_u4 __attribute__((ext_vector_type(4)));   // two x-adjacent half4 texels as loaded: (a.xy, a.zw, b.xy, b.zw)
+struct PfFoot { pf_u4 r0, r1; float w00, w10, w01, w11; };
+// rgb += the footprint's four texels x their weights: twelve v_fma_mix_f32 (fp16 operand converted inside the instruction).
+// Written as asm because the compiler pairs the channels into v_pk_fma_f32 behind sixteen separate converts whichever way the
+// C is written (5 cycles per product instead of ~2.8).  The s_nop is the wait state a consumer needs behind a packed-fp32
+// producer (the weights may come out of v_pk_mul_f32), which the compiler cannot insert for asm (see shade.hip mul2_sat).
+__device__ __forceinline__ void pf_accumulate(float& r, float& g, float& b, const PfFoot& f) {
+    asm("s_nop 0\n\t"
+        "v_fma_mix_f32 %0, %3, %11, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %3, %11, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %4, %11, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %5, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %5, %12, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %6, %12, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %7, %13, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %7, %13, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %8, %13, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %0, %9, %14, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %9, %14, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %10, %14, %2 op_sel_hi:[1,0,0]"
+        : "+v"(r), "+v"(g), "+v"(b)
+        : "v"(f.r0.x), "v"(f.r0.y), "v"(f.r0.z), "v"(f.r0.w), "v"(f.r1.x), "v"(f.r1.y), "v"(f.r1.z), "v"(f.r1.w),
+          "v"(f.w00), "v"(f.w10), "v"(f.w01), "v"(f.w11));
+}
+__device__ __forceinline__ PfFoot pf_foot(const pbr_half* __restrict__ foot, uint32_t mip_off, uint32_t sq, float fs, uint32_t face, float cu, float cv, float wl) {
+    // mip_off, sq, fs, wl are wave-uniform (scalar registers): the sample's level comes from the table
+    const float fxp = snap8(cu * fs) - 0.5f, fyp = snap8(cv * fs) - 0.5f;
+    const float flx = floorf(fxp), fly = floorf(fyp);
+    const float fx = fxp - flx, fy = fyp - fly;
+    const uint32_t o = __umul24(__umul24(face, sq) + (uint32_t)((int)fly + 1), sq) + (uint32_t)((int)flx + 1);
+    const char* q = reinterpret_cast<const char*>(foot) + (mip_off + o * 4u) * 8u;   // 32-bit byte offset (host-checked: the chain is < 4 GiB)
+    PfFoot f;
+    f.r0 = *reinterpret_cast<const pf_u4*>(q);
+    f.r1 = *reinterpret_cast<const pf_u4*>(q + 16);
+    const float wy1 = fy * wl, wy0 = wl - wy1;
+    f.w10 = fx * wy0; f.w00 = wy0 - f.w10;
+    f.w11 = fx * wy1; f.w01 = wy1 - f.w11;
+    return f;
+}
+struct PfFootOff { uint32_t off[16]; float fsize[16]; };   // footprint mip l: texel offset (env_padded_mip_offset of the source chain), edge as float
+
+__global__ __launch_bounds__(256) void k_prefilter_foot(const pbr_half* __restrict__ foot, PfFootOff fo, const float4* __restrict__ tables,
+                                                          PfLaunch pl, pbr_half* __restrict__ out) {
+    __shared__ float4 tab[PBR_SAMPLE_COUNT];    // (L_t.x, L_t.y, L_t.z = N.L, LOD) of the mip's samples
+    __shared__ float2 lvl[PBR_SAMPLE_COUNT];    // the sample's two level weights, N.L folded in: ((1 - f) N.L, f N.L), f = the LOD's x.8 fraction
+    uint32_t mip = 1;
+    while (mip + 1 < pl.mips && blockIdx.x >= pl.first_block[mip + 1]) mip++;
+    const uint32_t count = pl.count[mip];
+    for (uint32_t i = threadIdx.x; i < count; i += 256) {
+        const float4 e = tables[(size_t)mip * PBR_SAMPLE_COUNT + i];
+        const float f = e.w - floorf(e.w);
+        tab[i] = e;
+        lvl[i] = make_float2((1.0f - f) * e.z, f * e.z);
+    }
+    __syncthreads();
+    const uint32_t s = pl.size >> mip;
+    const uint32_t n = 6u * s * s;
+    const uint32_t t = (blockIdx.x - pl.first_block[mip]) * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t x = t % s, y = (t / s) % s, face_o = t / (s * s);
+    const float u = (float)x / (float)s, v = (float)y / (float)s;   // texel corner (Q8)
+    const V3 N = normalize3_exact(cube_dir_raw(face_o, 2.0f * u - 1.0f, 2.0f * v - 1.0f));
+    const V3 up = fabsf(N.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+    const V3 T = normalize3_exact(cross3(N, up));
+    const V3 Bt = cross3(N, T);
+    float ar = 0.0f, ag = 0.0f, ab = 0.0f, br = 0.0f, bg = 0.0f, bb = 0.0f;   // level-l0 and level-l1 halves of the sum: two chains
+    for (uint32_t j = 0; j < count; j++) {
+        const float4 e = tab[j];   // wave-uniform: one broadcast LDS read
+        const V3 L = T * e.x + Bt * e.y + N * e.z;
+        const float ma = 0.5f * fabsf(__builtin_amdgcn_cubema(L.x, L.y, L.z));
+        const float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z), tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
+        const uint32_t face = (uint32_t)__builtin_amdgcn_cubeid(L.x, L.y, L.z);
+        const float inv = rcp(ma);
+        const float cu = (sc * inv + 1.0f) * 0.5f, cv = (tc * inv + 1.0f) * 0.5f;
+        // the sample's level: uniform by construction — moved to scalar registers so that level offsets and sizes are scalar loads
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w), l1 = min(l0 + 1u, pl.sky_mips - 1u);
+        const float2 wl = lvl[j];
+        const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl.x)));
+        const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl.y)));
+        const PfFoot fa = pf_foot(foot, fo.off[l0], (pl.sky_size >> l0) + 1u, fo.fsize[l0], face, cu, cv, w0);
+        pf_accumulate(ar, ag, ab, fa);
+        if (w1 != 0.0f && l1 != l0) {   // wave-uniform
+            const PfFoot fb = pf_foot(foot, fo.off[l1], (pl.sky_size >> l1) + 1u, fo.fsize[l1], face, cu, cv, w1);
+            pf_accumulate(br, bg, bb, fb);
+        }
+    }
+    const float w = pl.wsum[mip];   // 0 samples -> 0/0 = NaN like the reference
+    store_h4(out + 4 * (cube_mip_offset(pl.size, mip) + (size_t)t), f4((ar + br) / w, (ag + bg) / w, (ab + bb) / w, 1.0f));
+}
+
+// footprint copy of one fp32 source mip as half4 (the layout of pbr_env_pad, see shade.hip k_env_pad): one thread per stored texel
+__global__ __launch_bounds__(256) void k_cube_foot_h4(const float4* __restrict__ src, pbr_half* __restrict__ dst, int s) {
+    const int sq = s + 1;
+    const size_t n = (size_t)6 * sq * sq * 4;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int k = (int)(t & 3), xq = (int)((t >> 2) % sq), yq = (int)(((t >> 2) / sq) % sq);
+    uint32_t face = (uint32_t)((t >> 2) / ((size_t)sq * sq));
+    int x = xq - 1 + (k & 1), y = yq - 1 + (k >> 1);
+    const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
+    if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
+        if (xo & yo) y = clampi(y, 0, s - 1);
+        const float uu = 2.0f * ((float)x + 0.5f) / (float)s - 1.0f;
+        const float vv = 2.0f * ((float)y + 0.5f) / (float)s - 1.0f;
+        float u2, v2;
+        cube_face_uv(cube_dir_raw(face, uu, vv), face, u2, v2);
+        x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
+        y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
+    }
+    const float4 c = src[((size_t)face * s + y) * s + x];
+    store_h4(dst + 4 * t, f4(c.x, c.y, c.z, c.w));
+}
+
 // roughness 0: H = L = N for every sample, weight 1: the filtered value IS the bilinear fetch at the texel-corner
 // direction (the reference's 1 024-fold running sum of one value differs from it by < 1e-4 relative, far inside the fp16 ULP)
 __global__ __launch_bounds__(256) void k_prefilter_mip0(const float4* __restrict__ sky_padded, PfLaunch pl, pbr_half* __restrict__ out) {
@@ -587,24 +712,42 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     }
     pl.first_block[mips] = blocks;
     const size_t table_bytes = (size_t)mips * PBR_SAMPLE_COUNT * 16;
+    // which kernel samples mips >= 1: the half footprint chain (default) or the padded fp32 chain (knobs build: PBR_PREFILTER_F32=1,
+    // the round-2 kernel, kept as the measured alternative); the footprint chain needs 32-bit texel offsets
+    const size_t foot_texels = env_padded_mip_offset(sky->size, sky->mips);
+    static const bool force_f32 = pbr::knob_set("PBR_PREFILTER_F32");
+    const bool use_foot = !force_f32 && !wave_per_texel && foot_texels * 8u < (1ull << 32) && mips > 1;
     float4* padded = nullptr;
     float4* tables = nullptr;
-    PBR_HIP(ctx, hipMallocAsync((void**)&padded, padded_texels * 16 + table_bytes, ctx->stream));
+    pbr_half* foot = nullptr;
+    PBR_HIP(ctx, hipMallocAsync((void**)&padded, padded_texels * 16 + table_bytes + (use_foot ? foot_texels * 8 : 0), ctx->stream));
     tables = padded + padded_texels;
+    foot = reinterpret_cast<pbr_half*>(tables + (size_t)mips * PBR_SAMPLE_COUNT);
     pbr_status r = PBR_OK;
     hipError_t e = hipMemcpyAsync(tables, ctx->host_tmp.data(), table_bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) r = hip_fail(ctx, e, "hipMemcpyAsync(prefilter tables)");
+    PfFootOff fo{};
     for (uint32_t l = 0; l < sky->mips && r == PBR_OK; l++) {
         const int sl = (int)(sky->size >> l);
-        const size_t n = (size_t)6 * (sl + 2) * (sl + 2);
-        hipLaunchKernelGGL(k_cube_pad_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const float4*>(sky->data) + cube_mip_offset(sky->size, l), padded + pl.src_off[l], sl);
-        r = launched(ctx, "k_cube_pad_f32");
+        const float4* src_l = reinterpret_cast<const float4*>(sky->data) + cube_mip_offset(sky->size, l);
+        if (l == 0 || !use_foot) {   // the fp32 padded copy: every level for the fp32 kernels, level 0 for mip 0's single fetch
+            const size_t n = (size_t)6 * (sl + 2) * (sl + 2);
+            hipLaunchKernelGGL(k_cube_pad_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, padded + pl.src_off[l], sl);
+            r = launched(ctx, "k_cube_pad_f32");
+        }
+        if (use_foot && r == PBR_OK) {
+            fo.off[l] = (uint32_t)env_padded_mip_offset(sky->size, l);
+            fo.fsize[l] = (float)sl;
+            const size_t n = (size_t)6 * (sl + 1) * (sl + 1) * 4;
+            hipLaunchKernelGGL(k_cube_foot_h4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, foot + 4 * (size_t)fo.off[l], sl);
+            r = launched(ctx, "k_cube_foot_h4");
+        }
     }
     if (r == PBR_OK && blocks) {
         if (wave_per_texel) hipLaunchKernelGGL(k_prefilter_fast, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
+        else if (use_foot) hipLaunchKernelGGL(k_prefilter_foot, dim3(blocks), dim3(256), 0, ctx->stream, foot, fo, tables, pl, out);
         else hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
-        r = launched(ctx, "k_prefilter_tex");
+        r = launched(ctx, "k_prefilter_*");
     }
     if (r == PBR_OK) {
         const size_t n0 = (size_t)6 * size * size;
