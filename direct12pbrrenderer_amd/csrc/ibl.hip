@@ -333,11 +333,11 @@ __global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict_
     store_h4(out + 4 * (cube_mip_offset(pl.size, mip) + (size_t)t), f4(cr / w, cg / w, cb / w, 1.0f));
 }
 
-// ---- the same table-driven, texel-per-lane loop on a HALF-precision FOOTPRINT copy of the source chain (what pbr_prefilter_env
+// ---- the same table-driven, texel-per-lane loop on a HALF-precision padded copy of the source chain (what pbr_prefilter_env
 // launches for mips >= 1).  Counters of k_prefilter_tex (profiles/r03_*): VALU busy ~100 % (168 instructions per sample) AND
 // the texture addresser 74 % busy — eight 16-byte gathers per lane and sample move 128 B through a 64 B / clk path.  Here:
-//  * the source chain is copied once per call into the footprint layout the shade samples (k_cube_foot_h4: the four texels of
-//    every bilinear footprint, seams resolved, stored together) as half4: a trilinear sample is FOUR 16-byte loads = 64 B.
+//  * the source chain is copied once per call as half4 with its seam borders (k_cube_pad_h4): a trilinear sample is FOUR
+//    16-byte loads = 64 B.
 //    Rounding the fp32 source to half costs <= 2^-11 relative per texel, spread over ~500-1000 samples of a texel whose
 //    result is rounded to half anyway (the reference's own source went through BC6H_UF16 on disk, BasicStorage.h:10-11);
 //    mip 0 — one fetch per texel, no averaging — stays on the fp32 chain (k_prefilter_mip0);
@@ -369,22 +369,24 @@ __device__ __forceinline__ void pf_accumulate(float& r, float& g, float& b, cons
         : "v"(f.r0.x), "v"(f.r0.y), "v"(f.r0.z), "v"(f.r0.w), "v"(f.r1.x), "v"(f.r1.y), "v"(f.r1.z), "v"(f.r1.w),
           "v"(f.w00), "v"(f.w10), "v"(f.w01), "v"(f.w11));
 }
-__device__ __forceinline__ PfFoot pf_foot(const pbr_half* __restrict__ foot, uint32_t mip_off, uint32_t sq, float fs, uint32_t face, float cu, float cv, float wl) {
-    // mip_off, sq, fs, wl are wave-uniform (scalar registers): the sample's level comes from the table
+struct alignas(8) PfRow { uint32_t x, y, z, w; };   // two x-adjacent half4 texels of a padded row: 8-byte aligned, one 16-byte load
+__device__ __forceinline__ PfFoot pf_foot(const pbr_half* __restrict__ foot, uint32_t mip_off, uint32_t sp, float fs, uint32_t face, float cu, float cv, float wl) {
+    // mip_off, sp (= level edge + 2), fs, wl are wave-uniform (scalar registers): the sample's level comes from the table
     const float fxp = snap8(cu * fs) - 0.5f, fyp = snap8(cv * fs) - 0.5f;
     const float flx = floorf(fxp), fly = floorf(fyp);
     const float fx = fxp - flx, fy = fyp - fly;
-    const uint32_t o = __umul24(__umul24(face, sq) + (uint32_t)((int)fly + 1), sq) + (uint32_t)((int)flx + 1);
-    const char* q = reinterpret_cast<const char*>(foot) + (mip_off + o * 4u) * 8u;   // 32-bit byte offset (host-checked: the chain is < 4 GiB)
+    const uint32_t o = __umul24(__umul24(face, sp) + (uint32_t)((int)fly + 1), sp) + (uint32_t)((int)flx + 1);
+    const char* q = reinterpret_cast<const char*>(foot) + (mip_off + o) * 8u;   // 32-bit byte offset (host-checked: the chain is < 4 GiB)
     PfFoot f;
-    f.r0 = *reinterpret_cast<const pf_u4*>(q);
-    f.r1 = *reinterpret_cast<const pf_u4*>(q + 16);
+    const PfRow a = *reinterpret_cast<const PfRow*>(q), b = *reinterpret_cast<const PfRow*>(q + sp * 8u);
+    f.r0 = pf_u4{a.x, a.y, a.z, a.w};
+    f.r1 = pf_u4{b.x, b.y, b.z, b.w};
     const float wy1 = fy * wl, wy0 = wl - wy1;
     f.w10 = fx * wy0; f.w00 = wy0 - f.w10;
     f.w11 = fx * wy1; f.w01 = wy1 - f.w11;
     return f;
 }
-struct PfFootOff { uint32_t off[16]; float fsize[16]; };   // footprint mip l: texel offset (env_padded_mip_offset of the source chain), edge as float
+struct PfFootOff { uint32_t off[16]; float fsize[16]; };   // padded half4 level l: texel offset (cube_border_mip_offset of the source chain), edge as float
 
 __global__ __launch_bounds__(256) void k_prefilter_foot(const pbr_half* __restrict__ foot, PfFootOff fo, const float4* __restrict__ tables,
                                                           PfLaunch pl, pbr_half* __restrict__ out) {
@@ -424,10 +426,10 @@ __global__ __launch_bounds__(256) void k_prefilter_foot(const pbr_half* __restri
         const float2 wl = lvl[j];
         const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl.x)));
         const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl.y)));
-        const PfFoot fa = pf_foot(foot, fo.off[l0], (pl.sky_size >> l0) + 1u, fo.fsize[l0], face, cu, cv, w0);
+        const PfFoot fa = pf_foot(foot, fo.off[l0], (pl.sky_size >> l0) + 2u, fo.fsize[l0], face, cu, cv, w0);
         pf_accumulate(ar, ag, ab, fa);
         if (w1 != 0.0f && l1 != l0) {   // wave-uniform
-            const PfFoot fb = pf_foot(foot, fo.off[l1], (pl.sky_size >> l1) + 1u, fo.fsize[l1], face, cu, cv, w1);
+            const PfFoot fb = pf_foot(foot, fo.off[l1], (pl.sky_size >> l1) + 2u, fo.fsize[l1], face, cu, cv, w1);
             pf_accumulate(br, bg, bb, fb);
         }
     }
@@ -435,15 +437,19 @@ __global__ __launch_bounds__(256) void k_prefilter_foot(const pbr_half* __restri
     store_h4(out + 4 * (cube_mip_offset(pl.size, mip) + (size_t)t), f4((ar + br) / w, (ag + bg) / w, (ab + bb) / w, 1.0f));
 }
 
-// footprint copy of one fp32 source mip as half4 (the layout of pbr_env_pad, see shade.hip k_env_pad): one thread per stored texel
-__global__ __launch_bounds__(256) void k_cube_foot_h4(const float4* __restrict__ src, pbr_half* __restrict__ dst, int s) {
-    const int sq = s + 1;
-    const size_t n = (size_t)6 * sq * sq * 4;
+// padded copy of one fp32 source mip as half4: every face with the 1-texel border the seamless rule selects (k_cube_pad_f32's
+// layout at 8 bytes per texel): a bilinear footprint is two 16-byte loads, and the lanes of a wave — 64 neighbouring output
+// texels taking the same sample — share the rows' cache lines.  (The shade's FOOTPRINT layout — four texels of a footprint
+// stored together — was tried first: its fourfold duplication of every texel cost more L1 misses than its one-line-per-level
+// saved here, FETCH 2.5 -> 4.5 GB per call; it suits the shade's incoherent gathers, not this kernel's coherent ones.)
+__global__ __launch_bounds__(256) void k_cube_pad_h4(const float4* __restrict__ src, pbr_half* __restrict__ dst, int s) {
+    const int sp = s + 2;
+    const size_t n = (size_t)6 * sp * sp;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
-    const int k = (int)(t & 3), xq = (int)((t >> 2) % sq), yq = (int)(((t >> 2) / sq) % sq);
-    uint32_t face = (uint32_t)((t >> 2) / ((size_t)sq * sq));
-    int x = xq - 1 + (k & 1), y = yq - 1 + (k >> 1);
+    const int xp = (int)(t % sp), yp = (int)((t / sp) % sp);
+    uint32_t face = (uint32_t)(t / ((size_t)sp * sp));
+    int x = xp - 1, y = yp - 1;
     const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
     if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
         if (xo & yo) y = clampi(y, 0, s - 1);
@@ -714,7 +720,7 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     const size_t table_bytes = (size_t)mips * PBR_SAMPLE_COUNT * 16;
     // which kernel samples mips >= 1: the half footprint chain (default) or the padded fp32 chain (knobs build: PBR_PREFILTER_F32=1,
     // the round-2 kernel, kept as the measured alternative); the footprint chain needs 32-bit texel offsets
-    const size_t foot_texels = env_padded_mip_offset(sky->size, sky->mips);
+    const size_t foot_texels = padded_texels + 1;   // the half4 copy has the padded fp32 chain's layout (+ 1: the last row pair reads 8 bytes past a texel)
     static const bool force_f32 = pbr::knob_set("PBR_PREFILTER_F32");
     const bool use_foot = !force_f32 && !wave_per_texel && foot_texels * 8u < (1ull << 32) && mips > 1;
     float4* padded = nullptr;
@@ -736,11 +742,11 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
             r = launched(ctx, "k_cube_pad_f32");
         }
         if (use_foot && r == PBR_OK) {
-            fo.off[l] = (uint32_t)env_padded_mip_offset(sky->size, l);
+            fo.off[l] = pl.src_off[l];
             fo.fsize[l] = (float)sl;
-            const size_t n = (size_t)6 * (sl + 1) * (sl + 1) * 4;
-            hipLaunchKernelGGL(k_cube_foot_h4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, foot + 4 * (size_t)fo.off[l], sl);
-            r = launched(ctx, "k_cube_foot_h4");
+            const size_t n = (size_t)6 * (sl + 2) * (sl + 2);
+            hipLaunchKernelGGL(k_cube_pad_h4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, foot + 4 * (size_t)fo.off[l], sl);
+            r = launched(ctx, "k_cube_pad_h4");
         }
     }
     if (r == PBR_OK && blocks) {
