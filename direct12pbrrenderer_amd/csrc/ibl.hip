@@ -303,8 +303,11 @@ __global__ __launch_bounds__(256) void k_prefilter_fast(const float4* __restrict
 // cache lines (measured: 2.4x faster than the wave-per-texel mapping, whose 64 lanes scatter over the whole lobe and
 // pull ~256 lines per trip through a 32 KB L1).  The sum runs in sample order like the shader's.  This is what
 // pbr_prefilter_env launches; k_prefilter_fast stays selectable (PBR_PREFILTER_WAVE=1) as the measured alternative.
+// run_if_lossy: nullptr = always; else the kernel runs only when *run_if_lossy != 0 (pbr_prefilter_env launches this kernel AND
+// k_prefilter_foot; the flag written by k_cube_pad_h4 decides on the device which of the two does the work)
 __global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict__ sky_padded, const float4* __restrict__ tables,
-                                                         PfLaunch pl, pbr_half* __restrict__ out) {
+                                                         PfLaunch pl, pbr_half* __restrict__ out, const uint32_t* __restrict__ run_if_lossy) {
+    if (run_if_lossy && *run_if_lossy == 0u) return;
     __shared__ float4 tab[PBR_SAMPLE_COUNT];
     uint32_t mip = 1;
     while (mip + 1 < pl.mips && blockIdx.x >= pl.first_block[mip + 1]) mip++;
@@ -337,10 +340,12 @@ __global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict_
 // launches for mips >= 1).  Counters of k_prefilter_tex (profiles/r03_*): VALU busy ~100 % (168 instructions per sample) AND
 // the texture addresser 74 % busy — eight 16-byte gathers per lane and sample move 128 B through a 64 B / clk path.  Here:
 //  * the source chain is copied once per call as half4 with its seam borders (k_cube_pad_h4): a trilinear sample is FOUR
-//    16-byte loads = 64 B.
-//    Rounding the fp32 source to half costs <= 2^-11 relative per texel, spread over ~500-1000 samples of a texel whose
-//    result is rounded to half anyway (the reference's own source went through BC6H_UF16 on disk, BasicStorage.h:10-11);
-//    mip 0 — one fetch per texel, no averaging — stays on the fp32 chain (k_prefilter_mip0);
+//    16-byte loads = 64 B.  The copy is used ONLY WHEN IT IS EXACT: k_cube_pad_h4 raises a flag when any texel does not
+//    survive the conversion bit for bit, and then this kernel returns at once and k_prefilter_tex (fp32 chain) does the work —
+//    decided on the device, no host round trip.  The reference's sky textures are BC6H_UF16 on disk (BasicStorage.h:10-11,
+//    TextureCompression.cpp:95-110): every texel of every mip it can feed this pass IS a half value, so its inputs take this
+//    path; an arbitrary fp32 cube keeps the fp32 path and its result.
+//    mip 0 — one fetch per texel — stays on the fp32 chain either way (k_prefilter_mip0);
 //  * cube face / coordinates from v_cubeid / v_cubesc / v_cubetc / v_cubema + one v_rcp (continuous consumers only);
 //  * the sample's eight texels enter the sum as eight weighted v_fma_mix_f32 per channel, the sample weight N.L folded into
 //    the weights: no separate lerps, no fp16 -> fp32 converts.
@@ -389,7 +394,8 @@ __device__ __forceinline__ PfFoot pf_foot(const pbr_half* __restrict__ foot, uin
 struct PfFootOff { uint32_t off[16]; float fsize[16]; };   // padded half4 level l: texel offset (cube_border_mip_offset of the source chain), edge as float
 
 __global__ __launch_bounds__(256) void k_prefilter_foot(const pbr_half* __restrict__ foot, PfFootOff fo, const float4* __restrict__ tables,
-                                                          PfLaunch pl, pbr_half* __restrict__ out) {
+                                                          PfLaunch pl, pbr_half* __restrict__ out, const uint32_t* __restrict__ skip_if_lossy) {
+    if (*skip_if_lossy != 0u) return;   // the half copy lost bits of this source: k_prefilter_tex does the work on the fp32 chain
     __shared__ float4 tab[PBR_SAMPLE_COUNT];    // (L_t.x, L_t.y, L_t.z = N.L, LOD) of the mip's samples
     __shared__ float2 lvl[PBR_SAMPLE_COUNT];    // the sample's two level weights, N.L folded in: ((1 - f) N.L, f N.L), f = the LOD's x.8 fraction
     uint32_t mip = 1;
@@ -442,7 +448,8 @@ __global__ __launch_bounds__(256) void k_prefilter_foot(const pbr_half* __restri
 // texels taking the same sample — share the rows' cache lines.  (The shade's FOOTPRINT layout — four texels of a footprint
 // stored together — was tried first: its fourfold duplication of every texel cost more L1 misses than its one-line-per-level
 // saved here, FETCH 2.5 -> 4.5 GB per call; it suits the shade's incoherent gathers, not this kernel's coherent ones.)
-__global__ __launch_bounds__(256) void k_cube_pad_h4(const float4* __restrict__ src, pbr_half* __restrict__ dst, int s) {
+// *lossy is set when a texel's rgb does not survive the conversion to half bit for bit.
+__global__ __launch_bounds__(256) void k_cube_pad_h4(const float4* __restrict__ src, pbr_half* __restrict__ dst, int s, uint32_t* __restrict__ lossy) {
     const int sp = s + 2;
     const size_t n = (size_t)6 * sp * sp;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -462,6 +469,8 @@ __global__ __launch_bounds__(256) void k_cube_pad_h4(const float4* __restrict__ 
     }
     const float4 c = src[((size_t)face * s + y) * s + x];
     store_h4(dst + 4 * t, f4(c.x, c.y, c.z, c.w));
+    const bool lost = (float)to_half_rn(c.x) != c.x || (float)to_half_rn(c.y) != c.y || (float)to_half_rn(c.z) != c.z;   // (NaN counts as lost)
+    if (__any(lost) && (threadIdx.x & 63) == 0) atomicOr(lossy, 1u);
 }
 
 // roughness 0: H = L = N for every sample, weight 1: the filtered value IS the bilinear fetch at the texel-corner
@@ -726,9 +735,11 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     float4* padded = nullptr;
     float4* tables = nullptr;
     pbr_half* foot = nullptr;
-    PBR_HIP(ctx, hipMallocAsync((void**)&padded, padded_texels * 16 + table_bytes + (use_foot ? foot_texels * 8 : 0), ctx->stream));
+    PBR_HIP(ctx, hipMallocAsync((void**)&padded, padded_texels * 16 + table_bytes + (use_foot ? foot_texels * 8 : 0) + 16, ctx->stream));
     tables = padded + padded_texels;
     foot = reinterpret_cast<pbr_half*>(tables + (size_t)mips * PBR_SAMPLE_COUNT);
+    uint32_t* lossy = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(foot) + (use_foot ? foot_texels * 8 : 0));   // 1 = the half copy is not exact
+    PBR_HIP(ctx, hipMemsetAsync(lossy, 0, 16, ctx->stream));
     pbr_status r = PBR_OK;
     hipError_t e = hipMemcpyAsync(tables, ctx->host_tmp.data(), table_bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) r = hip_fail(ctx, e, "hipMemcpyAsync(prefilter tables)");
@@ -736,7 +747,7 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     for (uint32_t l = 0; l < sky->mips && r == PBR_OK; l++) {
         const int sl = (int)(sky->size >> l);
         const float4* src_l = reinterpret_cast<const float4*>(sky->data) + cube_mip_offset(sky->size, l);
-        if (l == 0 || !use_foot) {   // the fp32 padded copy: every level for the fp32 kernels, level 0 for mip 0's single fetch
+        {   // the fp32 padded copy: mip 0's single fetch, and the fp32 kernel (which runs when the half copy is not exact)
             const size_t n = (size_t)6 * (sl + 2) * (sl + 2);
             hipLaunchKernelGGL(k_cube_pad_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, padded + pl.src_off[l], sl);
             r = launched(ctx, "k_cube_pad_f32");
@@ -745,15 +756,18 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
             fo.off[l] = pl.src_off[l];
             fo.fsize[l] = (float)sl;
             const size_t n = (size_t)6 * (sl + 2) * (sl + 2);
-            hipLaunchKernelGGL(k_cube_pad_h4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, foot + 4 * (size_t)fo.off[l], sl);
+            hipLaunchKernelGGL(k_cube_pad_h4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, foot + 4 * (size_t)fo.off[l], sl, lossy);
             r = launched(ctx, "k_cube_pad_h4");
         }
     }
     if (r == PBR_OK && blocks) {
         if (wave_per_texel) hipLaunchKernelGGL(k_prefilter_fast, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
-        else if (use_foot) hipLaunchKernelGGL(k_prefilter_foot, dim3(blocks), dim3(256), 0, ctx->stream, foot, fo, tables, pl, out);
-        else hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
-        r = launched(ctx, "k_prefilter_*");
+        else if (use_foot) {   // both kernels; the flag k_cube_pad_h4 wrote picks the one that works, the other returns at once
+            hipLaunchKernelGGL(k_prefilter_foot, dim3(blocks), dim3(256), 0, ctx->stream, foot, fo, tables, pl, out, lossy);
+            r = launched(ctx, "k_prefilter_foot");
+            if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out, lossy);
+        } else hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out, (const uint32_t*)nullptr);
+        if (r == PBR_OK) r = launched(ctx, "k_prefilter_*");
     }
     if (r == PBR_OK) {
         const size_t n0 = (size_t)6 * size * size;

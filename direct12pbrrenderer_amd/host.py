@@ -29,6 +29,7 @@ SIGNATURES = {
     "pbrh_set_halo_loopback": (_int, [_vp, _int]),
     "pbrh_halo_copy_from": (_int, [_vp, _vp]),
     "pbrh_set_frames_in_flight": (_int, [_vp, _int]),
+    "pbrh_set_tail_overlap": (_int, [_vp, _int]),
     "pbrh_set_external_histogram": (_int, [_vp, _vp]),
     "pbrh_capture_histogram": (_int, [_vp, _int]),
     "pbrh_captured_histogram": (_int, [_vp, _vp]),
@@ -121,6 +122,9 @@ class HostRenderer:
 
     def set_frames_in_flight(self, k):
         self._check(self.lib.pbrh_set_frames_in_flight(self.h, int(k)))
+
+    def set_tail_overlap(self, on):
+        self._check(self.lib.pbrh_set_tail_overlap(self.h, 1 if on else 0))
 
     def comm_init(self, world, rank, unique_id):
         buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None

@@ -87,7 +87,13 @@ void FrameGraph::Compile() {
         if (lc.Valid) mFGResourceAllocator.AllocateTransientResource(lc.ResourceId, Describe(lc.ResourceId));
 }
 
+void FrameGraph::DoubleBufferResources(const std::vector<FGResourceId>& ids) {
+    for (FGResourceId id : ids) mFGResourceAllocator.DoubleBuffer(id, Describe(id));
+    mDoubleBuffered = !ids.empty();
+}
+
 void FrameGraph::Execute(HipCommandList* cmd, Scene* scene, Camera* camera) {
+    if (mDoubleBuffered) mFGResourceAllocator.SetParity((uint32)(mFrameCount++ & 1u));
     FGContext context{cmd, scene, camera, this};
     const auto& order = mParser.GetExecutionOrder();
     for (mExecutionPass = 0; mExecutionPass < order.size(); mExecutionPass++) {

@@ -29,6 +29,9 @@ public:
     void Setup();     // construct the passes (IRenderPipeline::Setup)
     void Compile();   // execution order + transient resource allocation
     void Execute(HipCommandList* cmd, Scene* scene, Camera* camera);
+    // Frames alternate between two instances of these transient resources (the overlapped frame tail: the HDR target and the
+    // luminance histogram of frame i are still read on the side stream while frame i + 1 is shaded).  Call after Compile.
+    void DoubleBufferResources(const std::vector<FGResourceId>& ids);
     IRenderPipeline* GetPipeline() const { return mRenderPipeline; }
     IDeviceResource* GetFGResource(IRenderPass* pass, FGResourceId id);
     // by id, outside Execute (read-back by the host program / tests)
@@ -43,6 +46,8 @@ private:
     std::vector<IRenderPass*> mPipelinePasses;
     IRenderPipeline* mRenderPipeline;
     uint32 mExecutionPass;
+    bool mDoubleBuffered = false;
+    uint64_t mFrameCount = 0;
 };
 
 }  // namespace MRendererHip

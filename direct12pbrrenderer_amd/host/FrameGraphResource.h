@@ -236,21 +236,33 @@ private:
 
 class FGResourceAllocator {
 public:
-    void Reset() { mTransient.assign(FGResourceIDs::Instance()->NumResources(), nullptr); }
-    void AllocateTransientResource(FGResourceId id, const FGResourceDescriptionTable::Description& d) {
-        if (auto* t = std::get_if<FGTransientTextureDescription>(&d)) {
-            mTransient[id] = std::make_shared<DeviceTexture2D>(t->Width, t->Height, t->MipLevels, t->Format);
-        } else if (auto* b = std::get_if<FGTransientBufferDescription>(&d)) {
-            mTransient[id] = std::make_shared<DeviceStructuredBuffer>(b->Size, b->Stride);
-        }
+    void Reset() {
+        mTransient.assign(FGResourceIDs::Instance()->NumResources(), nullptr);
+        mSecond.assign(FGResourceIDs::Instance()->NumResources(), nullptr);
+        mParity = 0;
     }
+    void AllocateTransientResource(FGResourceId id, const FGResourceDescriptionTable::Description& d) { mTransient[id] = Make(d); }
+    // A second instance of a transient resource: frames alternate between the two (SetParity), so that work of frame i that is
+    // still in flight on another stream — the overlapped frame tail — does not see frame i + 1 write the same memory.  Not in
+    // the reference (its frames are strictly serial).
+    void DoubleBuffer(FGResourceId id, const FGResourceDescriptionTable::Description& d) {
+        if (!mSecond.at(id)) mSecond[id] = Make(d);
+    }
+    void SetParity(uint32 p) { mParity = p & 1u; }
+    uint32 Parity() const { return mParity; }
     IDeviceResource* GetResource(FGResourceId id) const {
-        IDeviceResource* r = mTransient.at(id).get();
+        IDeviceResource* r = (mParity && mSecond.at(id)) ? mSecond[id].get() : mTransient.at(id).get();
         if (!r) throw HipException("FGResourceAllocator: resource not allocated: " + std::string(FGResourceIDs::Instance()->IdToName(id)));
         return r;
     }
 private:
-    std::vector<std::shared_ptr<IDeviceResource>> mTransient;
+    static std::shared_ptr<IDeviceResource> Make(const FGResourceDescriptionTable::Description& d) {
+        if (auto* t = std::get_if<FGTransientTextureDescription>(&d)) return std::make_shared<DeviceTexture2D>(t->Width, t->Height, t->MipLevels, t->Format);
+        if (auto* b = std::get_if<FGTransientBufferDescription>(&d)) return std::make_shared<DeviceStructuredBuffer>(b->Size, b->Stride);
+        return nullptr;
+    }
+    std::vector<std::shared_ptr<IDeviceResource>> mTransient, mSecond;
+    uint32 mParity = 0;
 };
 
 class Scene;

@@ -131,7 +131,9 @@ void HipCommandList::Check(pbr_status st, const char* what) {
 }
 void HipCommandList::WaitIdle() {
     FlushPendingBloom();
-    Check(pbr_sync(mCtx), "pbr_sync");
+    EndTail();
+    Check(pbr_sync(mCtx), "pbr_sync");   // the context's stream and the side stream's un-joined tail
+    if (mTailOverlap) Check(pbr_ctx_side_join(mCtx), "pbr_ctx_side_join");
 }
 void HipCommandList::SetFramesInFlight(uint32 k) {
     WaitIdle();
@@ -143,8 +145,25 @@ void HipCommandList::SetFramesInFlight(uint32 k) {
     mFrameFence.resize(k, nullptr);
     for (hipEvent_t& e : mFrameFence) ThrowIfFailed(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
 }
+void HipCommandList::SetTailOverlap(bool on) {
+    WaitIdle();
+    if (on && mFrameFence.empty()) throw HipException("SetTailOverlap: throughput mode only (SetFramesInFlight(k > 1) first): with the per-frame fence there is no next frame to overlap");
+    mTailOverlap = on;
+}
+void HipCommandList::BeginTail() {
+    if (!mTailOverlap || mInTail) return;
+    Check(pbr_ctx_side_join(mCtx), "pbr_ctx_side_join");     // the tail of the frame BEFORE last is ordered ahead of this point (long finished)
+    Check(pbr_ctx_side_begin(mCtx), "pbr_ctx_side_begin");   // the side stream waits for everything enqueued so far (this frame's bloom + histogram)
+    mInTail = true;
+}
+void HipCommandList::EndTail() {
+    if (!mInTail) return;
+    Check(pbr_ctx_side_end(mCtx), "pbr_ctx_side_end");
+    mInTail = false;
+}
 void HipCommandList::EndFrame() {
     FlushPendingBloom();
+    EndTail();
     if (mFrameFence.empty()) {   // D3D12Device::EndFrame: signal + wait, every frame
         Check(pbr_sync(mCtx), "pbr_sync");
         return;
@@ -319,6 +338,7 @@ void HipCommandList::Dispatch(ShadingState* s, uint32 gx, uint32 gy, uint32 gz) 
         const auto& c = s->Constants<AverageLuminanceConstant>();
         ExpectGroups(f, gx, gy, gz, 1, 1, 1);
         uint32_t* hist = (uint32_t*)s->Buffer("LuminanceHistogram")->DevicePtr();
+        BeginTail();   // overlapped frame tail: all-reduce + average (+ the tone-map that follows) on the side stream
         // new step: with several GPUs the tile histograms are summed first; no-op on one GPU
         Check(pbr_allreduce_hist(mCtx, hist), "pbr_allreduce_hist");
         if (!mExternalHistogram.empty()) {   // the same sum where the other tiles' counts arrive through the host
@@ -369,6 +389,7 @@ void HipCommandList::DrawScreen(ShadingState* s) {
         if (r.x + r.w > in.w || r.y + r.h > in.h || mRenderTarget->Width() < in.w) throw HipException("hdr_tone_mapping: interior rectangle outside the target");
         Check(pbr_tonemap(mCtx, in.ptr + 4 * ((size_t)r.y * in.w + r.x), r.w, r.h, in.w, (const float*)s->Buffer("AverageLuminance")->DevicePtr(),
                           (uint32_t*)mRenderTarget->DevicePtr() + (size_t)r.y * mRenderTarget->Width() + r.x, mRenderTarget->Width()), "pbr_tonemap");
+        EndTail();
     } else {
         throw HipException("DrawScreen: " + std::string(f) + " is not a full-screen kernel of this build");
     }

@@ -27,6 +27,12 @@ public:
     // the host records frame i + 1 while the GPU still runs frame i; WaitIdle() drains.
     void EndFrame();
     void SetFramesInFlight(uint32 k);
+    // Overlapped frame tail (not in the reference; throughput mode only): from the average-luminance dispatch on — histogram
+    // all-reduce, average, tone-map — a frame's commands go to the context's high-priority side stream (pbr_ctx_side_*), so that
+    // the collective's latency and the two small launches run beside the NEXT frame's cluster pass and shade.  The frame graph
+    // must double-buffer what the tail reads (FrameGraph::DoubleBufferResources: HDR target, histogram).
+    void SetTailOverlap(bool on);
+    bool TailOverlap() const { return mTailOverlap; }
     uint32 FramesInFlight() const { return (uint32)mFrameFence.size() ? (uint32)mFrameFence.size() : 1; }
     void WaitIdle();
 
@@ -140,6 +146,9 @@ private:
     PendingBloom mPendingBloom;
     std::vector<hipEvent_t> mFrameFence;   // ring of per-frame completion events (throughput mode)
     uint64_t mFrameIndex = 0;
+    bool mTailOverlap = false, mInTail = false;
+    void BeginTail();
+    void EndTail();
     std::vector<uint32> mExternalHistogram, mCapturedHistogram;
     bool mCaptureHistogram = false;
     std::vector<std::string> mEventLog;

@@ -244,6 +244,14 @@ int pbrh_set_frames_in_flight(pbrh_renderer* r, int k) {
     return guarded(r, [&] { r->scheduler->CommandList()->SetFramesInFlight(k < 1 ? 1u : (uint32)k); });
 }
 
+int pbrh_set_tail_overlap(pbrh_renderer* r, int on) {
+    return guarded(r, [&] {
+        HipCommandList* cmd = r->scheduler->CommandList();
+        cmd->SetTailOverlap(on != 0);
+        if (on) r->scheduler->GetFrameGraph()->DoubleBufferResources({DeferredPipelineResource::DeferredShadingRT, DeferredPipelineResource::LuminanceHistogram});
+    });
+}
+
 int pbrh_set_external_histogram(pbrh_renderer* r, const uint32_t* counts256) {
     return guarded(r, [&] { r->scheduler->CommandList()->SetExternalHistogram(counts256); });
 }

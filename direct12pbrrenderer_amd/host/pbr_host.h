@@ -33,6 +33,10 @@ int pbrh_halo_copy_from(pbrh_renderer* dst, pbrh_renderer* src);
 /* 1 (default) = the reference's frame loop: every frame ends with the fence wait (D3D12Device.cpp:993-1003).  k > 1 =
  * throughput mode: a frame's end waits for frame i - k + 1 only, so the host records ahead of the GPU. */
 int pbrh_set_frames_in_flight(pbrh_renderer* r, int k);
+/* throughput mode only (after pbrh_set_frames_in_flight(k > 1)): a frame's tail — histogram all-reduce, average, tone-map — on
+ * the context's high-priority side stream, beside the next frame's cluster pass and shade; the HDR target and the histogram are
+ * double-buffered.  Same frames as the plain order (pbrh_read waits for everything in flight). */
+int pbrh_set_tail_overlap(pbrh_renderer* r, int on);
 void pbrh_destroy(pbrh_renderer* r);
 const char* pbrh_last_error(const pbrh_renderer* r);
 /* fp32 RGBA cube mip 0 (host, 6*size*size*4 floats): uploaded, box mips + SH9 computed on the GPU */

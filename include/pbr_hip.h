@@ -188,7 +188,11 @@ pbr_status pbr_cube_gen_mips(pbr_ctx* ctx, float* cube_data, uint32_t size, uint
 
 /* env_map_gen.hlsl:50-105, all PBR_ENV_MIPS dispatches of PreFilterEnvMapPass::Execute
  * (DeferredPipeline.cpp:77-115): mip i is filtered with roughness i/(mips-1).
- * out: half4 cube chain, layout as pbr_cube_f32 with edge `size`. */
+ * out: half4 cube chain, layout as pbr_cube_f32 with edge `size`.
+ * Mips >= 1 are sampled from a half-precision copy of the source chain WHEN THAT COPY IS EXACT — every rgb texel of every
+ * source mip survives fp32 -> half -> fp32 bit for bit, which is the case for everything the reference can feed this pass (its
+ * sky assets are BC6H_UF16: BasicStorage.h:10-11) — and from the fp32 chain otherwise; decided on the device, the call stays
+ * asynchronous.  Either way <= 1 fp16 ULP (or 1e-3 relative) from the shader's sequential sum. */
 pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t size, uint32_t mips,
                              pbr_half* out_rgba);
 /* ONE dispatch of env_map_gen.hlsl: cbuffer {Roughness, MipLevel, PrefilterEnvMapTextureSize}

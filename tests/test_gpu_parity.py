@@ -437,6 +437,25 @@ def test_deferred_shade_band_with_the_bench_ibl(ctx, orc, bench_ibl, w, h, rows)
     _check_shade(orc, to_np_half(hdr), want, want_f32, truth, gb["stencil"], f"{w}x{h} band fp16, bench IBL", hard_ulp=None)
 
 
+@pytest.mark.parametrize("size", [16, 64])
+def test_prefilter_env_on_a_half_representable_source_takes_the_half_copy_and_stays_within_one_ulp(ctx, orc, size):
+    """pbr_prefilter_env samples mips >= 1 from a half-precision copy of the source chain when that copy is exact (what the
+    reference's BC6H_UF16 sky assets decode to), from the fp32 chain otherwise.  A source chain rounded to half — every mip,
+    as the reference's per-mip block compression leaves it — against the oracle on the same chain: every texel of every mip
+    <= 1 fp16 ULP or 1e-3 relative; and the same call on the un-rounded fp32 chain (fp32 path) keeps that bound too."""
+    mips = int(np.log2(size)) + 1
+    sky = synth.env_cube(size, mips)
+    orc.cube_gen_mips(sky, size, mips)
+    for name, chain in (("half-representable", sky.astype(np.float16).astype(np.float32)), ("fp32", sky)):
+        want = orc.prefilter_env(chain, size, mips, size, 5)
+        got = to_np_half(ctx.prefilter_env(ctx.upload(chain), size, mips, size, 5))
+        ctx.sync()
+        d = common.half_ulp_diff(got[:, :3], want[:, :3])
+        rel = np.abs(got[:, :3].astype(np.float32) - want[:, :3].astype(np.float32)) <= 1e-3 * np.abs(want[:, :3].astype(np.float32))
+        assert ((d <= 1) | rel).all(), (name, size, int(d.max()))
+        assert (d > 0).mean() < 0.25, (name, size, float((d > 0).mean()))
+
+
 # ------------------------------------------------------------------------------------------ a14-a15
 def _levels(flat, w, h):
     return [flat[bloom_level_offset(w, h, l): bloom_level_offset(w, h, l + 1)].reshape(h >> l, w >> l, 4) for l in range(5)]

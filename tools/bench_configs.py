@@ -105,6 +105,12 @@ if CPU:
                            "cores": orc.num_threads(), "kind": "port",
                            "sample": f"{n_s} random texels of each of the 5 mips (orc_prefilter_env_texels, OpenMP), each mip's time scaled to its texel count"}
 emit(**rec)
+# the same on a source chain whose texels are half values — what the reference's BC6H_UF16 sky assets decode to: pbr_prefilter_env
+# then samples mips >= 1 from its (exact) half-precision copy instead of the fp32 chain
+sky_h = sky.half().float()
+ms_h = bench.time_stage(lambda: ctx.prefilter_env(sky_h, 512, sky_mips, 512, ENV_MIPS, out=envbuf), 5)
+emit(config="cfg3", what="GGX prefilter 512^2 cube, 5 mips, 1024 spp, source chain half-representable (as BC6H_UF16 assets decode)", ms=round(ms_h, 3),
+     Gsamples_per_s_reference_equivalent=round(texels * 1024 / ms_h / 1e6, 2), Gsamples_per_s_evaluated=round(evaluated / ms_h / 1e6, 2))
 shbuf = ctx.empty((28,), torch.float32)
 ms = bench.time_stage(lambda: ctx.sh9_project(sky, 512, sky_mips, out=shbuf), 10)
 rec = dict(config="cfg3", what="SH9 projection of the 512^2 cube (quadrature, 25.2 MB in)", ms=round(ms, 4), GBps=round(6 * 512 * 512 * 16 / ms / 1e6, 1),

@@ -15,4 +15,6 @@ sky = ctx.upload(synth.env_cube(512, sky_mips))
 ctx.cube_gen_mips(sky, 512, sky_mips)
 envbuf = ctx.prefilter_env(sky, 512, sky_mips, 512, ENV_MIPS)
 ms = bench.time_stage(lambda: ctx.prefilter_env(sky, 512, sky_mips, 512, ENV_MIPS, out=envbuf), 5)
-print(f"{sys.argv[1] if len(sys.argv) > 1 else ''}: prefilter 512^2 x 5 mips x 1024 spp: {ms:.3f} ms", flush=True)
+sky_h = sky.half().float()   # every texel a half value (what BC6H_UF16 assets decode to): the exact half-precision copy is sampled
+ms_h = bench.time_stage(lambda: ctx.prefilter_env(sky_h, 512, sky_mips, 512, ENV_MIPS, out=envbuf), 5)
+print(f"{sys.argv[1] if len(sys.argv) > 1 else ''}: prefilter 512^2 x 5 mips x 1024 spp: fp32 source {ms:.3f} ms, half-representable source {ms_h:.3f} ms", flush=True)

@@ -28,4 +28,8 @@ for fused in (0, 1):
         ms = r.render_n(frames)
         print(f"host pass graph, {'fused passes' if fused else 'dispatch by dispatch'}, {'fence per frame' if in_flight == 1 else '3 frames in flight'}: "
               f"{ms:.4f} ms/frame ({r.dispatch_count()} dispatches/frame) = {W * H / ms / 1e3:.0f} Mpixel/s", flush=True)
+r.set_tail_overlap(True)
+r.render_n(frames)
+ms = r.render_n(frames)
+print(f"host pass graph, fused passes, 3 frames in flight, frame tail on the side stream: {ms:.4f} ms/frame = {W * H / ms / 1e3:.0f} Mpixel/s", flush=True)
 r.close()
