@@ -391,11 +391,37 @@ __device__ __forceinline__ PfFoot pf_foot(const pbr_half* __restrict__ foot, uin
     f.w11 = fx * wy1; f.w01 = wy1 - f.w11;
     return f;
 }
+// the fp32 twin (the padded fp32 chain has the same texel layout at 16 bytes per texel): what runs when the half copy is not exact
+struct PfFoot32 { float4 t00, t10, t01, t11; float w00, w10, w01, w11; };
+__device__ __forceinline__ PfFoot32 pf_foot32(const float4* __restrict__ chain, uint32_t mip_off, uint32_t sp, float fs, uint32_t face, float cu, float cv, float wl) {
+    const float fxp = snap8(cu * fs) - 0.5f, fyp = snap8(cv * fs) - 0.5f;
+    const float flx = floorf(fxp), fly = floorf(fyp);
+    const float fx = fxp - flx, fy = fyp - fly;
+    const uint32_t o = __umul24(__umul24(face, sp) + (uint32_t)((int)fly + 1), sp) + (uint32_t)((int)flx + 1);
+    const float4* q = chain + (size_t)(mip_off + o);
+    PfFoot32 f;
+    f.t00 = q[0]; f.t10 = q[1]; f.t01 = q[sp]; f.t11 = q[sp + 1];
+    const float wy1 = fy * wl, wy0 = wl - wy1;
+    f.w10 = fx * wy0; f.w00 = wy0 - f.w10;
+    f.w11 = fx * wy1; f.w01 = wy1 - f.w11;
+    return f;
+}
+__device__ __forceinline__ void pf_accumulate32(float& r, float& g, float& b, const PfFoot32& f) {
+    r = __builtin_fmaf(f.t00.x, f.w00, r); g = __builtin_fmaf(f.t00.y, f.w00, g); b = __builtin_fmaf(f.t00.z, f.w00, b);
+    r = __builtin_fmaf(f.t10.x, f.w10, r); g = __builtin_fmaf(f.t10.y, f.w10, g); b = __builtin_fmaf(f.t10.z, f.w10, b);
+    r = __builtin_fmaf(f.t01.x, f.w01, r); g = __builtin_fmaf(f.t01.y, f.w01, g); b = __builtin_fmaf(f.t01.z, f.w01, b);
+    r = __builtin_fmaf(f.t11.x, f.w11, r); g = __builtin_fmaf(f.t11.y, f.w11, g); b = __builtin_fmaf(f.t11.z, f.w11, b);
+}
 struct PfFootOff { uint32_t off[16]; float fsize[16]; };   // padded half4 level l: texel offset (cube_border_mip_offset of the source chain), edge as float
 
-__global__ __launch_bounds__(256) void k_prefilter_foot(const pbr_half* __restrict__ foot, PfFootOff fo, const float4* __restrict__ tables,
-                                                          PfLaunch pl, pbr_half* __restrict__ out, const uint32_t* __restrict__ skip_if_lossy) {
-    if (*skip_if_lossy != 0u) return;   // the half copy lost bits of this source: k_prefilter_tex does the work on the fp32 chain
+// HALF: sample the half copy (runs when it is exact: *lossy == 0); !HALF: the same loop on the padded fp32 chain (runs when
+// *lossy != 0).  pbr_prefilter_env launches both; the flag k_cube_pad_h4 wrote picks the one that works on the device.
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_prefilter_foot(const void* __restrict__ chain, PfFootOff fo, const float4* __restrict__ tables,
+                                                          PfLaunch pl, pbr_half* __restrict__ out, const uint32_t* __restrict__ lossy) {
+    if ((*lossy != 0u) == HALF) return;
+    const pbr_half* foot = reinterpret_cast<const pbr_half*>(chain);
+    const float4* chain32 = reinterpret_cast<const float4*>(chain);
     __shared__ float4 tab[PBR_SAMPLE_COUNT];    // (L_t.x, L_t.y, L_t.z = N.L, LOD) of the mip's samples
     __shared__ float2 lvl[PBR_SAMPLE_COUNT];    // the sample's two level weights, N.L folded in: ((1 - f) N.L, f N.L), f = the LOD's x.8 fraction
     uint32_t mip = 1;
@@ -422,21 +448,42 @@ __global__ __launch_bounds__(256) void k_prefilter_foot(const pbr_half* __restri
     for (uint32_t j = 0; j < count; j++) {
         const float4 e = tab[j];   // wave-uniform: one broadcast LDS read
         const V3 L = T * e.x + Bt * e.y + N * e.z;
-        const float ma = 0.5f * fabsf(__builtin_amdgcn_cubema(L.x, L.y, L.z));
-        const float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z), tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
-        const uint32_t face = (uint32_t)__builtin_amdgcn_cubeid(L.x, L.y, L.z);
-        const float inv = rcp(ma);
-        const float cu = (sc * inv + 1.0f) * 0.5f, cv = (tc * inv + 1.0f) * 0.5f;
+        uint32_t face;
+        float cu, cv;
+        if (e.x == 0.0f && e.y == 0.0f) {
+            // L = N exactly (sample 0: H = N).  N is a texel CORNER, so for a whole row and column of every face it lies exactly on
+            // a face edge, at the cube's corners on three faces at once: an exact tie, which v_cubeid breaks towards z, y, x and the
+            // shader towards x, y, z.  On the coarsest source levels (1 x 1 texels) the two faces' footprints differ enough to move
+            // a 2 x 2 output mip by 3 fp16 ULP (tools/prefilter_small_diag.py: 32^2 cube, mip 4, texel (0,0) of +X): this one
+            // sample takes the shader's rule.  Wave-uniform branch.
+            cube_face_uv(L, face, cu, cv);
+        } else {
+            const float ma = 0.5f * fabsf(__builtin_amdgcn_cubema(L.x, L.y, L.z));
+            const float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z), tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
+            face = (uint32_t)__builtin_amdgcn_cubeid(L.x, L.y, L.z);
+            const float inv = rcp(ma);
+            cu = (sc * inv + 1.0f) * 0.5f;
+            cv = (tc * inv + 1.0f) * 0.5f;
+        }
         // the sample's level: uniform by construction — moved to scalar registers so that level offsets and sizes are scalar loads
         const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w), l1 = min(l0 + 1u, pl.sky_mips - 1u);
         const float2 wl = lvl[j];
         const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl.x)));
         const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl.y)));
-        const PfFoot fa = pf_foot(foot, fo.off[l0], (pl.sky_size >> l0) + 2u, fo.fsize[l0], face, cu, cv, w0);
-        pf_accumulate(ar, ag, ab, fa);
-        if (w1 != 0.0f && l1 != l0) {   // wave-uniform
-            const PfFoot fb = pf_foot(foot, fo.off[l1], (pl.sky_size >> l1) + 2u, fo.fsize[l1], face, cu, cv, w1);
-            pf_accumulate(br, bg, bb, fb);
+        if (HALF) {
+            const PfFoot fa = pf_foot(foot, fo.off[l0], (pl.sky_size >> l0) + 2u, fo.fsize[l0], face, cu, cv, w0);
+            pf_accumulate(ar, ag, ab, fa);
+            if (w1 != 0.0f && l1 != l0) {   // wave-uniform
+                const PfFoot fb = pf_foot(foot, fo.off[l1], (pl.sky_size >> l1) + 2u, fo.fsize[l1], face, cu, cv, w1);
+                pf_accumulate(br, bg, bb, fb);
+            }
+        } else {
+            const PfFoot32 fa = pf_foot32(chain32, fo.off[l0], (pl.sky_size >> l0) + 2u, fo.fsize[l0], face, cu, cv, w0);
+            pf_accumulate32(ar, ag, ab, fa);
+            if (w1 != 0.0f && l1 != l0) {
+                const PfFoot32 fb = pf_foot32(chain32, fo.off[l1], (pl.sky_size >> l1) + 2u, fo.fsize[l1], face, cu, cv, w1);
+                pf_accumulate32(br, bg, bb, fb);
+            }
         }
     }
     const float w = pl.wsum[mip];   // 0 samples -> 0/0 = NaN like the reference
@@ -764,10 +811,10 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     }
     if (r == PBR_OK && blocks) {
         if (wave_per_texel) hipLaunchKernelGGL(k_prefilter_fast, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
-        else if (use_foot) {   // both kernels; the flag k_cube_pad_h4 wrote picks the one that works, the other returns at once
-            hipLaunchKernelGGL(k_prefilter_foot, dim3(blocks), dim3(256), 0, ctx->stream, foot, fo, tables, pl, out, lossy);
-            r = launched(ctx, "k_prefilter_foot");
-            if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out, lossy);
+        else if (use_foot) {   // both instances; the flag k_cube_pad_h4 wrote picks the one that works, the other returns at once
+            hipLaunchKernelGGL(k_prefilter_foot<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const void*)foot, fo, tables, pl, out, lossy);
+            r = launched(ctx, "k_prefilter_foot<half>");
+            if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_foot<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const void*)padded, fo, tables, pl, out, lossy);
         } else hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out, (const uint32_t*)nullptr);
         if (r == PBR_OK) r = launched(ctx, "k_prefilter_*");
     }

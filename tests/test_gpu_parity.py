@@ -437,7 +437,7 @@ def test_deferred_shade_band_with_the_bench_ibl(ctx, orc, bench_ibl, w, h, rows)
     _check_shade(orc, to_np_half(hdr), want, want_f32, truth, gb["stencil"], f"{w}x{h} band fp16, bench IBL", hard_ulp=None)
 
 
-@pytest.mark.parametrize("size", [16, 64])
+@pytest.mark.parametrize("size", [16, 32, 64])   # 32: mip 4 is 2 x 2 — its corner texel is an exact three-way face tie for sample 0
 def test_prefilter_env_on_a_half_representable_source_takes_the_half_copy_and_stays_within_one_ulp(ctx, orc, size):
     """pbr_prefilter_env samples mips >= 1 from a half-precision copy of the source chain when that copy is exact (what the
     reference's BC6H_UF16 sky assets decode to), from the fp32 chain otherwise.  A source chain rounded to half — every mip,
