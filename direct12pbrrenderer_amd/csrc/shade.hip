@@ -13,7 +13,7 @@
 //    fall back to the global list);
 //  * the env chain is sampled from its padded layout (pbr_env_pad): no seam branches, each bilinear row is one
 //    16-byte load;
-//  * with 256 lights the kernel is FP32-VALU-issue-bound (47 packed + 4 transcendental + 2 plain instructions per pair
+//  * with 256 lights the kernel is FP32-VALU-issue-bound (46 packed + 4 transcendental + 2 plain instructions per pair
 //    of lights, ~500 per pixel around the loop), not HBM-bound.
 #include <type_traits>
 #include "pbr_internal.hpp"
@@ -260,7 +260,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // 5 waves per SIMD, cycles per wave-instruction per SIMD): v_pk_{fma,mul,add}_f32 4.7 (two lights per instruction),
         // plain v_fma 2.6 / v_mul 3.0, v_max / v_min 4.6, v_rsq / v_rcp 8.5.  Two lights per trip in the halves of packed
         // registers therefore buy ~1.2x per flop, not 2x; the SoA light planes put the same component of both lights into
-        // an adjacent VGPR pair with no moves.  Per trip: 47 packed + 4 transcendental + the loop's compare and pointer step (+ 2 / 4 v_max on the slow paths).
+        // an adjacent VGPR pair with no moves.  Per trip: 46 packed + 4 transcendental + the loop's compare and pointer step (+ 2 / 4 v_max on the slow paths).
         // the nine packed sums start at zero: ONE v_pk_mov_b32 per register pair (the compiler writes two v_mov_b32 per pair)
         f2 a1x = zero2(), a1y = zero2(), a1z = zero2(), a2x = zero2(), a2y = zero2(), a2z = zero2(), a3x = zero2(), a3y = zero2(), a3z = zero2();
         const float att_c0 = llds[6 * LSTRIDE], att_c1 = llds[7 * LSTRIDE], att_c2 = llds[8 * LSTRIDE];   // light 0's polynomial (ATT: everyone's)
@@ -270,7 +270,6 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             const f2 dx = comp(0) - f2s(pos.x), dy = comp(1) - f2s(pos.y), dz = comp(2) - f2s(pos.z);
             const f2 d2 = dx * dx + dy * dy + dz * dz;
             const f2 invd = rsq2(d2);
-            const f2 dist = d2 * invd;
             const f2 dn = dx * n.x + dy * n.y + dz * n.z;
             const f2 NdotL = mul2_sat(dn, invd);   // max(N.L, 0)
             // |L + V|^2 is summed from the components of L + V, NOT taken as 2 + 2 L.V: at grazing incidence (L ~ -V,
@@ -296,8 +295,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             // attenuation(): max(C0 + C1 d + C2 d^2, 1e-6).  QSAFE: every staged light has C0 >= 1e-6 and C1, C2 >= 0,
             // so the floor never binds (checked once per block while the table is staged)
             f2 Q;
-            if constexpr (ATT) Q = f2s(att_c0) + f2s(att_c1) * dist + f2s(att_c2) * d2;   // the scene's one polynomial (the null light takes it too: its colour is 0 and Q stays finite)
-            else Q = comp(6) + comp(7) * dist + comp(8) * d2;
+            // C0 + C1 d + C2 d^2 with d = d2 / sqrt(d2) never formed: d2 (C1 invd + C2) + C0 — two fused operations
+            if constexpr (ATT) Q = d2 * (invd * f2s(att_c1) + f2s(att_c2)) + f2s(att_c0);   // the scene's one polynomial (the null light takes it too: its colour is 0 and Q stays finite)
+            else Q = d2 * (invd * comp(7) + comp(8)) + comp(6);
             if constexpr (!QSAFE) Q = max2(Q, f2s(EPSILON_F));
             const f2 TA = Tn * A;
             const f2 r = rcp2(Q * TA);                       // 1 / (Q A t^2 h2^2)
