@@ -354,7 +354,8 @@ typedef uint32_t pf_u4 __attribute__((ext_vector_type(4)));   // two x-adjacent 
 struct PfFoot { pf_u4 r0, r1; float w00, w10, w01, w11; };
 // rgb += the footprint's four texels x their weights: twelve v_fma_mix_f32 (fp16 operand converted inside the instruction).
 // Written as asm because the compiler pairs the channels into v_pk_fma_f32 behind sixteen separate converts whichever way the
-// C is written (5 cycles per product instead of ~2.8).  The s_nop is the wait state a consumer needs behind a packed-fp32
+// C is written: measured issue costs at >= 5 waves per SIMD (profiles/r03_valu_rate3.txt): v_cvt_f32_f16 4.5 cycles, v_pk_fma_f32
+// 4.7 -> 6.9 cycles per product that way, against 4.6 for one v_fma_mix_f32 (which, like the converts, is NOT a 2.6-cycle op).  The s_nop is the wait state a consumer needs behind a packed-fp32
 // producer (the weights may come out of v_pk_mul_f32), which the compiler cannot insert for asm (see shade.hip mul2_sat).
 __device__ __forceinline__ void pf_accumulate(float& r, float& g, float& b, const PfFoot& f) {
     asm("s_nop 0\n\t"

@@ -42,6 +42,17 @@ typedef float f2 __attribute__((ext_vector_type(2)));
     asm volatile(INS " %0, %0\n\t" INS " %1, %1\n\t" INS " %2, %2\n\t" INS " %3, %3\n\t" INS " %4, %4\n\t" INS " %5, %5\n\t" INS " %6, %6\n\t" INS " %7, %7" \
                  : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
 
+#define MIX8 /* v_fma_mix_f32 d, half(y0.lo), y1, d: the fp16 -> fp32 convert rides in the instruction */ \
+    asm volatile("v_fma_mix_f32 %0, %8, %9, %0 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %8, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+                 "v_fma_mix_f32 %2, %8, %9, %2 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %8, %9, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+                 "v_fma_mix_f32 %4, %8, %9, %4 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, %8, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+                 "v_fma_mix_f32 %6, %8, %9, %6 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %7, %8, %9, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]" \
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y0), "v"(y1));
+#define CUBE8 /* v_cubeid_f32 d, d, y0, y1 */ \
+    asm volatile("v_cubeid_f32 %0, %0, %8, %9\n\tv_cubesc_f32 %1, %1, %9, %8\n\tv_cubetc_f32 %2, %2, %8, %9\n\tv_cubema_f32 %3, %3, %9, %8\n\t" \
+                 "v_cubeid_f32 %4, %4, %8, %9\n\tv_cubesc_f32 %5, %5, %9, %8\n\tv_cubetc_f32 %6, %6, %8, %9\n\tv_cubema_f32 %7, %7, %9, %8" \
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y0), "v"(y1));
+
 struct Stamp { uint64_t c0, c1, r0, r1; uint32_t hw_id, xcc; };
 
 template <int MODE>
@@ -63,6 +74,12 @@ __global__ void k(float* out, Stamp* st, int iters) {
         else if (MODE == 7) { OP8U("v_rcp_f32") }
         else if (MODE == 8) { OP8U("v_rsq_f32") }
         else if (MODE == 9) { OP8("v_max_f32") }
+        else if (MODE == 11) { MIX8 }
+        else if (MODE == 12) { OP8U("v_cvt_f32_f16") }
+        else if (MODE == 13) { OP8("v_fmac_f32") }
+        else if (MODE == 14) { CUBE8 }
+        else if (MODE == 15) { OP8U("v_log_f32") }
+        else if (MODE == 16) { OP8U("v_floor_f32") }
         else { OP8U("v_mov_b32") }
     }
     const uint64_t c1 = clock64(), r1 = wall_clock64();
@@ -123,6 +140,9 @@ int main() {
         run<0>("v_mul_f32", w, out, st); run<1>("v_add_f32", w, out, st); run<2>("v_fma_f32 3vgpr", w, out, st); run<3>("v_mul_f32 sgpr", w, out, st);
         run<4>("v_pk_fma_f32", w, out, st); run<5>("v_pk_mul_f32", w, out, st); run<6>("v_pk_add_f32", w, out, st);
         run<7>("v_rcp_f32", w, out, st); run<8>("v_rsq_f32", w, out, st); run<9>("v_max_f32", w, out, st); run<10>("v_mov_b32", w, out, st);
+        // round 3: the instructions the prefilter / bloom / shade trims were choosing between
+        run<11>("v_fma_mix_f32", w, out, st); run<12>("v_cvt_f32_f16", w, out, st); run<13>("v_fmac_f32", w, out, st); run<14>("v_cube*_f32", w, out, st);
+        run<15>("v_log_f32", w, out, st); run<16>("v_floor_f32", w, out, st);
         printf("\n");
     }
     return 0;
