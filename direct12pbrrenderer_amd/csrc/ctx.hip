@@ -100,6 +100,7 @@ void pbr_ctx_destroy(pbr_ctx* ctx) {
     if (ctx->ev_side_fork) (void)hipEventDestroy(ctx->ev_side_fork);
     if (ctx->ev_side_join) (void)hipEventDestroy(ctx->ev_side_join);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->pf_dev) (void)hipFree(ctx->pf_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -207,27 +207,6 @@ struct PfLaunch {
     uint32_t mips, size, sky_size, sky_mips;
 };
 
-__global__ __launch_bounds__(256) void k_cube_pad_f32(const float4* __restrict__ src, float4* __restrict__ dst, int s) {
-    const int sp = s + 2;
-    const size_t n = (size_t)6 * sp * sp;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const int xp = (int)(t % sp), yp = (int)((t / sp) % sp);
-    uint32_t face = (uint32_t)(t / ((size_t)sp * sp));
-    int x = xp - 1, y = yp - 1;
-    const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
-    if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
-        if (xo & yo) y = clampi(y, 0, s - 1);
-        const float uu = 2.0f * ((float)x + 0.5f) / (float)s - 1.0f;
-        const float vv = 2.0f * ((float)y + 0.5f) / (float)s - 1.0f;
-        float u2, v2;
-        cube_face_uv(cube_dir_raw(face, uu, vv), face, u2, v2);
-        x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
-        y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
-    }
-    dst[t] = src[((size_t)face * s + y) * s + x];
-}
-
 // trilinear fetch of the padded fp32 chain along `d` at the (already clamped and x.8-snapped) LOD; rgb only
 __device__ __forceinline__ V3 padded_trilinear(const float4* __restrict__ sky, const PfLaunch& pl, V3 d, float lod_s) {
     uint32_t face;
@@ -304,7 +283,7 @@ __global__ __launch_bounds__(256) void k_prefilter_fast(const float4* __restrict
 // pull ~256 lines per trip through a 32 KB L1).  The sum runs in sample order like the shader's.  This is what
 // pbr_prefilter_env launches; k_prefilter_fast stays selectable (PBR_PREFILTER_WAVE=1) as the measured alternative.
 // run_if_lossy: nullptr = always; else the kernel runs only when *run_if_lossy != 0 (pbr_prefilter_env launches this kernel AND
-// k_prefilter_foot; the flag written by k_cube_pad_h4 decides on the device which of the two does the work)
+// k_prefilter_foot; the flag written by k_cube_pad_chain decides on the device which of the two does the work)
 __global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict__ sky_padded, const float4* __restrict__ tables,
                                                          PfLaunch pl, pbr_half* __restrict__ out, const uint32_t* __restrict__ run_if_lossy) {
     if (run_if_lossy && *run_if_lossy == 0u) return;
@@ -339,8 +318,8 @@ __global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict_
 // ---- the same table-driven, texel-per-lane loop on a HALF-precision padded copy of the source chain (what pbr_prefilter_env
 // launches for mips >= 1).  Counters of k_prefilter_tex (profiles/r03_*): VALU busy ~100 % (168 instructions per sample) AND
 // the texture addresser 74 % busy — eight 16-byte gathers per lane and sample move 128 B through a 64 B / clk path.  Here:
-//  * the source chain is copied once per call as half4 with its seam borders (k_cube_pad_h4): a trilinear sample is FOUR
-//    16-byte loads = 64 B.  The copy is used ONLY WHEN IT IS EXACT: k_cube_pad_h4 raises a flag when any texel does not
+//  * the source chain is copied once per call as half4 with its seam borders (k_cube_pad_chain): a trilinear sample is FOUR
+//    16-byte loads = 64 B.  The copy is used ONLY WHEN IT IS EXACT: k_cube_pad_chain raises a flag when any texel does not
 //    survive the conversion bit for bit, and then this kernel returns at once and k_prefilter_tex (fp32 chain) does the work —
 //    decided on the device, no host round trip.  The reference's sky textures are BC6H_UF16 on disk (BasicStorage.h:10-11,
 //    TextureCompression.cpp:95-110): every texel of every mip it can feed this pass IS a half value, so its inputs take this
@@ -375,69 +354,105 @@ __device__ __forceinline__ void pf_accumulate(float& r, float& g, float& b, cons
         : "v"(f.r0.x), "v"(f.r0.y), "v"(f.r0.z), "v"(f.r0.w), "v"(f.r1.x), "v"(f.r1.y), "v"(f.r1.z), "v"(f.r1.w),
           "v"(f.w00), "v"(f.w10), "v"(f.w01), "v"(f.w11));
 }
+// One level of the padded chain as the kernel wants it, 16 bytes = one scalar load (the sample's level is wave-uniform)
+struct PfLevel { uint32_t off, sp; float fs256, spf; };   // texel offset of the level, padded edge (level edge + 2), level edge x 256, padded edge as float
+struct PfLevels { PfLevel lev[16]; };
 struct alignas(8) PfRow { uint32_t x, y, z, w; };   // two x-adjacent half4 texels of a padded row: 8-byte aligned, one 16-byte load
-__device__ __forceinline__ PfFoot pf_foot(const pbr_half* __restrict__ foot, uint32_t mip_off, uint32_t sp, float fs, uint32_t face, float cu, float cv, float wl) {
-    // mip_off, sp (= level edge + 2), fs, wl are wave-uniform (scalar registers): the sample's level comes from the table
-    const float fxp = snap8(cu * fs) - 0.5f, fyp = snap8(cv * fs) - 0.5f;
-    const float flx = floorf(fxp), fly = floorf(fyp);
-    const float fx = fxp - flx, fy = fyp - fly;
-    const uint32_t o = __umul24(__umul24(face, sp) + (uint32_t)((int)fly + 1), sp) + (uint32_t)((int)flx + 1);
-    const char* q = reinterpret_cast<const char*>(foot) + (mip_off + o) * 8u;   // 32-bit byte offset (host-checked: the chain is < 4 GiB)
+// The sampler's fixed-point footprint of (cu, cv) on one level: texel index of its upper-left texel in the level + the two x.8
+// fractions.  Instruction choice follows the measured issue classes (profiles/r03_valu_rate3b.txt: fp32 mul / add / fma and
+// integer add / and issue in ~2.7 cycles per wave; converts, floor, shifts, integer multiply-adds, v_readfirstlane in ~4.5):
+// everything stays in fp32, where x.8 coordinates below 2^15 and texel indices below 2^24 are exact, up to ONE convert:
+//   t  = floor(c * size * 256 + 0.5)            snap8(c * size) in 1/256 texels: bit for bit the shader-side snap8 (* 256 is exact)
+//   q  = t / 256 + 0.5                          = snap - 0.5 (texel-centre convention) + 1 (the border column of the padded layout)
+//   i  = floor(q), f = q - i                    footprint origin and fraction, both exact
+//   o  = (face * sp + iy) * sp + ix             two fp32 FMAs while 6 sp^2 < 2^24 (levels up to 1670 texels), integer multiply-adds above
+struct PfCoord { uint32_t o; float fx, fy; };
+__device__ __forceinline__ PfCoord pf_coord(const PfLevel& lv, float facef, float cu, float cv) {
+    const float tx = floorf(cu * lv.fs256 + 0.5f), ty = floorf(cv * lv.fs256 + 0.5f);
+    const float xq = __builtin_fmaf(tx, 1.0f / 256.0f, 0.5f), yq = __builtin_fmaf(ty, 1.0f / 256.0f, 0.5f);
+    const float ixf = floorf(xq), iyf = floorf(yq);
+    PfCoord c;
+    c.fx = xq - ixf; c.fy = yq - iyf;
+    c.o = (uint32_t)__builtin_fmaf(__builtin_fmaf(facef, lv.spf, iyf), lv.spf, ixf);
+    if (lv.sp > 1672u) c.o = __umul24(__umul24((uint32_t)facef, lv.sp) + (uint32_t)iyf, lv.sp) + (uint32_t)ixf;   // wave-uniform (scalar) branch
+    return c;
+}
+struct PfWeights { float w00, w10, w01, w11; };
+__device__ __forceinline__ PfWeights pf_weights(const PfCoord& c, float wl) {   // bilinear weights x the level's weight (N.L folded in)
+    PfWeights w;
+    const float wy1 = c.fy * wl, wy0 = wl - wy1;
+    w.w10 = c.fx * wy0; w.w00 = wy0 - w.w10;
+    w.w11 = c.fx * wy1; w.w01 = wy1 - w.w11;
+    return w;
+}
+__device__ __forceinline__ void pf_level_half(float& r, float& g, float& b, const pbr_half* __restrict__ foot, const PfLevel& lv, float facef, float cu, float cv, float wl) {
+    const PfCoord c = pf_coord(lv, facef, cu, cv);
+    // scalar bases of the two rows, one 32-bit vector offset (host-checked: a level is < 4 GiB)
+    const char* row0 = reinterpret_cast<const char*>(foot) + (size_t)lv.off * 8u;
+    const char* row1 = row0 + (size_t)lv.sp * 8u;
+    const uint32_t vo = c.o * 8u;
     PfFoot f;
-    const PfRow a = *reinterpret_cast<const PfRow*>(q), b = *reinterpret_cast<const PfRow*>(q + sp * 8u);
+    const PfRow a = *reinterpret_cast<const PfRow*>(row0 + vo), bb = *reinterpret_cast<const PfRow*>(row1 + vo);
     f.r0 = pf_u4{a.x, a.y, a.z, a.w};
-    f.r1 = pf_u4{b.x, b.y, b.z, b.w};
-    const float wy1 = fy * wl, wy0 = wl - wy1;
-    f.w10 = fx * wy0; f.w00 = wy0 - f.w10;
-    f.w11 = fx * wy1; f.w01 = wy1 - f.w11;
-    return f;
+    f.r1 = pf_u4{bb.x, bb.y, bb.z, bb.w};
+    const PfWeights w = pf_weights(c, wl);
+    f.w00 = w.w00; f.w10 = w.w10; f.w01 = w.w01; f.w11 = w.w11;
+    pf_accumulate(r, g, b, f);
 }
 // the fp32 twin (the padded fp32 chain has the same texel layout at 16 bytes per texel): what runs when the half copy is not exact
-struct PfFoot32 { float4 t00, t10, t01, t11; float w00, w10, w01, w11; };
-__device__ __forceinline__ PfFoot32 pf_foot32(const float4* __restrict__ chain, uint32_t mip_off, uint32_t sp, float fs, uint32_t face, float cu, float cv, float wl) {
-    const float fxp = snap8(cu * fs) - 0.5f, fyp = snap8(cv * fs) - 0.5f;
-    const float flx = floorf(fxp), fly = floorf(fyp);
-    const float fx = fxp - flx, fy = fyp - fly;
-    const uint32_t o = __umul24(__umul24(face, sp) + (uint32_t)((int)fly + 1), sp) + (uint32_t)((int)flx + 1);
-    const float4* q = chain + (size_t)(mip_off + o);
-    PfFoot32 f;
-    f.t00 = q[0]; f.t10 = q[1]; f.t01 = q[sp]; f.t11 = q[sp + 1];
-    const float wy1 = fy * wl, wy0 = wl - wy1;
-    f.w10 = fx * wy0; f.w00 = wy0 - f.w10;
-    f.w11 = fx * wy1; f.w01 = wy1 - f.w11;
-    return f;
+__device__ __forceinline__ void pf_level_f32(float& r, float& g, float& b, const float4* __restrict__ chain, const PfLevel& lv, float facef, float cu, float cv, float wl) {
+    const PfCoord c = pf_coord(lv, facef, cu, cv);
+    const char* row0 = reinterpret_cast<const char*>(chain) + (size_t)lv.off * 16u;
+    const char* row1 = row0 + (size_t)lv.sp * 16u;
+    const uint32_t vo = c.o * 16u;   // host-checked: the fp32 chain is < 4 GiB
+    const float4 t00 = *reinterpret_cast<const float4*>(row0 + vo), t10 = *reinterpret_cast<const float4*>(row0 + vo + 16u);
+    const float4 t01 = *reinterpret_cast<const float4*>(row1 + vo), t11 = *reinterpret_cast<const float4*>(row1 + vo + 16u);
+    const PfWeights w = pf_weights(c, wl);
+    r = __builtin_fmaf(t00.x, w.w00, r); g = __builtin_fmaf(t00.y, w.w00, g); b = __builtin_fmaf(t00.z, w.w00, b);
+    r = __builtin_fmaf(t10.x, w.w10, r); g = __builtin_fmaf(t10.y, w.w10, g); b = __builtin_fmaf(t10.z, w.w10, b);
+    r = __builtin_fmaf(t01.x, w.w01, r); g = __builtin_fmaf(t01.y, w.w01, g); b = __builtin_fmaf(t01.z, w.w01, b);
+    r = __builtin_fmaf(t11.x, w.w11, r); g = __builtin_fmaf(t11.y, w.w11, g); b = __builtin_fmaf(t11.z, w.w11, b);
 }
-__device__ __forceinline__ void pf_accumulate32(float& r, float& g, float& b, const PfFoot32& f) {
-    r = __builtin_fmaf(f.t00.x, f.w00, r); g = __builtin_fmaf(f.t00.y, f.w00, g); b = __builtin_fmaf(f.t00.z, f.w00, b);
-    r = __builtin_fmaf(f.t10.x, f.w10, r); g = __builtin_fmaf(f.t10.y, f.w10, g); b = __builtin_fmaf(f.t10.z, f.w10, b);
-    r = __builtin_fmaf(f.t01.x, f.w01, r); g = __builtin_fmaf(f.t01.y, f.w01, g); b = __builtin_fmaf(f.t01.z, f.w01, b);
-    r = __builtin_fmaf(f.t11.x, f.w11, r); g = __builtin_fmaf(f.t11.y, f.w11, g); b = __builtin_fmaf(f.t11.z, f.w11, b);
-}
-struct PfFootOff { uint32_t off[16]; float fsize[16]; };   // padded half4 level l: texel offset (cube_border_mip_offset of the source chain), edge as float
 
 // HALF: sample the half copy (runs when it is exact: *lossy == 0); !HALF: the same loop on the padded fp32 chain (runs when
-// *lossy != 0).  pbr_prefilter_env launches both; the flag k_cube_pad_h4 wrote picks the one that works on the device.
+// *lossy != 0).  pbr_prefilter_env launches both; the flag k_cube_pad_chain wrote picks the one that works on the device.
+constexpr uint32_t PF_TWO_LEVELS = 0x100u, PF_EXACT_FACE = 0x200u;   // flags beside the level number in a table entry's .w
+// Blocks of 512 lanes: the two sample tables take 24 KB of LDS, and the 8 192 waves of a 512^2 cube's mips 1-4 are exactly 8 per
+// SIMD — with 256-lane blocks LDS allowed 6 of them at a time and the last two ran alone, their load latency exposed.
+constexpr uint32_t PF_FOOT_BLOCK = 512u;
 template <bool HALF>
-__global__ __launch_bounds__(256) void k_prefilter_foot(const void* __restrict__ chain, PfFootOff fo, const float4* __restrict__ tables,
+__global__ __launch_bounds__(PF_FOOT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_prefilter_foot(const void* __restrict__ chain, PfLevels fo, const float4* __restrict__ tables,
                                                           PfLaunch pl, pbr_half* __restrict__ out, const uint32_t* __restrict__ lossy) {
     if ((*lossy != 0u) == HALF) return;
     const pbr_half* foot = reinterpret_cast<const pbr_half*>(chain);
     const float4* chain32 = reinterpret_cast<const float4*>(chain);
-    __shared__ float4 tab[PBR_SAMPLE_COUNT];    // (L_t.x, L_t.y, L_t.z = N.L, LOD) of the mip's samples
-    __shared__ float2 lvl[PBR_SAMPLE_COUNT];    // the sample's two level weights, N.L folded in: ((1 - f) N.L, f N.L), f = the LOD's x.8 fraction
+    // per sample of this block's mip: (L_t.x, L_t.y, L_t.z = N.L, level | flags) and its two level weights with N.L folded in,
+    // ((1 - f) N.L, f N.L), f = the LOD's x.8 fraction.  One v_readfirstlane per sample (the .w word) makes level, "second level
+    // used" and "exact face rule" scalar: level constants come by scalar loads, branches are scalar.
+    __shared__ float4 tab[PBR_SAMPLE_COUNT];
+    __shared__ float2 lvl[PBR_SAMPLE_COUNT];
     uint32_t mip = 1;
     while (mip + 1 < pl.mips && blockIdx.x >= pl.first_block[mip + 1]) mip++;
     const uint32_t count = pl.count[mip];
-    for (uint32_t i = threadIdx.x; i < count; i += 256) {
-        const float4 e = tables[(size_t)mip * PBR_SAMPLE_COUNT + i];
-        const float f = e.w - floorf(e.w);
+    for (uint32_t i = threadIdx.x; i < count; i += PF_FOOT_BLOCK) {
+        float4 e = tables[(size_t)mip * PBR_SAMPLE_COUNT + i];
+        const float fl = floorf(e.w), f = e.w - fl;
+        const uint32_t l0 = (uint32_t)fl, l1 = min(l0 + 1u, pl.sky_mips - 1u);
+        const float w1 = f * e.z;
+        // e.x == e.y == 0: L = N exactly (sample 0: H = N).  N is a texel CORNER, so for a whole row and column of every face it lies
+        // exactly on a face edge, at the cube's corners on three faces at once: an exact tie, which v_cubeid breaks towards z, y, x
+        // and the shader towards x, y, z.  On the coarsest source levels (1 x 1 texels) the two faces' footprints differ enough to
+        // move a 2 x 2 output mip by 3 fp16 ULP (tools/prefilter_small_diag.py: 32^2 cube, mip 4, texel (0,0) of +X): such a sample
+        // takes the shader's rule.
+        const uint32_t word = l0 | (w1 != 0.0f && l1 != l0 ? PF_TWO_LEVELS : 0u) | (e.x == 0.0f && e.y == 0.0f ? PF_EXACT_FACE : 0u);
+        lvl[i] = make_float2((1.0f - f) * e.z, w1);
+        e.w = __builtin_bit_cast(float, word);
         tab[i] = e;
-        lvl[i] = make_float2((1.0f - f) * e.z, f * e.z);
     }
     __syncthreads();
     const uint32_t s = pl.size >> mip;
     const uint32_t n = 6u * s * s;
-    const uint32_t t = (blockIdx.x - pl.first_block[mip]) * 256u + threadIdx.x;
+    const uint32_t t = (blockIdx.x - pl.first_block[mip]) * PF_FOOT_BLOCK + threadIdx.x;
     if (t >= n) return;
     const uint32_t x = t % s, y = (t / s) % s, face_o = t / (s * s);
     const float u = (float)x / (float)s, v = (float)y / (float)s;   // texel corner (Q8)
@@ -448,62 +463,61 @@ __global__ __launch_bounds__(256) void k_prefilter_foot(const void* __restrict__
     float ar = 0.0f, ag = 0.0f, ab = 0.0f, br = 0.0f, bg = 0.0f, bb = 0.0f;   // level-l0 and level-l1 halves of the sum: two chains
     for (uint32_t j = 0; j < count; j++) {
         const float4 e = tab[j];   // wave-uniform: one broadcast LDS read
-        const V3 L = T * e.x + Bt * e.y + N * e.z;
-        uint32_t face;
-        float cu, cv;
-        if (e.x == 0.0f && e.y == 0.0f) {
-            // L = N exactly (sample 0: H = N).  N is a texel CORNER, so for a whole row and column of every face it lies exactly on
-            // a face edge, at the cube's corners on three faces at once: an exact tie, which v_cubeid breaks towards z, y, x and the
-            // shader towards x, y, z.  On the coarsest source levels (1 x 1 texels) the two faces' footprints differ enough to move
-            // a 2 x 2 output mip by 3 fp16 ULP (tools/prefilter_small_diag.py: 32^2 cube, mip 4, texel (0,0) of +X): this one
-            // sample takes the shader's rule.  Wave-uniform branch.
-            cube_face_uv(L, face, cu, cv);
-        } else {
-            const float ma = 0.5f * fabsf(__builtin_amdgcn_cubema(L.x, L.y, L.z));
-            const float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z), tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
-            face = (uint32_t)__builtin_amdgcn_cubeid(L.x, L.y, L.z);
-            const float inv = rcp(ma);
-            cu = (sc * inv + 1.0f) * 0.5f;
-            cv = (tc * inv + 1.0f) * 0.5f;
-        }
-        // the sample's level: uniform by construction — moved to scalar registers so that level offsets and sizes are scalar loads
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w), l1 = min(l0 + 1u, pl.sky_mips - 1u);
         const float2 wl = lvl[j];
-        const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl.x)));
-        const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wl.y)));
-        if (HALF) {
-            const PfFoot fa = pf_foot(foot, fo.off[l0], (pl.sky_size >> l0) + 2u, fo.fsize[l0], face, cu, cv, w0);
-            pf_accumulate(ar, ag, ab, fa);
-            if (w1 != 0.0f && l1 != l0) {   // wave-uniform
-                const PfFoot fb = pf_foot(foot, fo.off[l1], (pl.sky_size >> l1) + 2u, fo.fsize[l1], face, cu, cv, w1);
-                pf_accumulate(br, bg, bb, fb);
-            }
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, e.w));
+        // L = T e.x + Bt e.y + N e.z as nine plain multiply-adds (they issue faster than the five packed ops of the unfused form)
+        const V3 L = v3(__builtin_fmaf(T.x, e.x, __builtin_fmaf(Bt.x, e.y, N.x * e.z)), __builtin_fmaf(T.y, e.x, __builtin_fmaf(Bt.y, e.y, N.y * e.z)),
+                        __builtin_fmaf(T.z, e.x, __builtin_fmaf(Bt.z, e.y, N.z * e.z)));
+        float facef, cu, cv;
+        if (word & PF_EXACT_FACE) {   // scalar branch
+            uint32_t face;
+            cube_face_uv(L, face, cu, cv);
+            facef = (float)face;
         } else {
-            const PfFoot32 fa = pf_foot32(chain32, fo.off[l0], (pl.sky_size >> l0) + 2u, fo.fsize[l0], face, cu, cv, w0);
-            pf_accumulate32(ar, ag, ab, fa);
-            if (w1 != 0.0f && l1 != l0) {
-                const PfFoot32 fb = pf_foot32(chain32, fo.off[l1], (pl.sky_size >> l1) + 2u, fo.fsize[l1], face, cu, cv, w1);
-                pf_accumulate32(br, bg, bb, fb);
-            }
+            const float hinv = rcp(fabsf(__builtin_amdgcn_cubema(L.x, L.y, L.z)));   // v_cubema = 2 x the major axis: (sc / ma + 1) / 2 = sc * hinv + 0.5
+            const float sc = __builtin_amdgcn_cubesc(L.x, L.y, L.z), tc = __builtin_amdgcn_cubetc(L.x, L.y, L.z);
+            facef = __builtin_amdgcn_cubeid(L.x, L.y, L.z);
+            cu = __builtin_fmaf(sc, hinv, 0.5f);
+            cv = __builtin_fmaf(tc, hinv, 0.5f);
+        }
+        const uint32_t l0 = word & 0xFFu;
+        const PfLevel la = fo.lev[l0];
+        if (HALF) pf_level_half(ar, ag, ab, foot, la, facef, cu, cv, wl.x);
+        else pf_level_f32(ar, ag, ab, chain32, la, facef, cu, cv, wl.x);
+        if (word & PF_TWO_LEVELS) {   // scalar branch
+            const PfLevel lb = fo.lev[l0 + 1u];
+            if (HALF) pf_level_half(br, bg, bb, foot, lb, facef, cu, cv, wl.y);
+            else pf_level_f32(br, bg, bb, chain32, lb, facef, cu, cv, wl.y);
         }
     }
     const float w = pl.wsum[mip];   // 0 samples -> 0/0 = NaN like the reference
     store_h4(out + 4 * (cube_mip_offset(pl.size, mip) + (size_t)t), f4((ar + br) / w, (ag + bg) / w, (ab + bb) / w, 1.0f));
 }
 
-// padded copy of one fp32 source mip as half4: every face with the 1-texel border the seamless rule selects (k_cube_pad_f32's
-// layout at 8 bytes per texel): a bilinear footprint is two 16-byte loads, and the lanes of a wave — 64 neighbouring output
-// texels taking the same sample — share the rows' cache lines.  (The shade's FOOTPRINT layout — four texels of a footprint
-// stored together — was tried first: its fourfold duplication of every texel cost more L1 misses than its one-line-per-level
-// saved here, FETCH 2.5 -> 4.5 GB per call; it suits the shade's incoherent gathers, not this kernel's coherent ones.)
+// Padded copies of the WHOLE fp32 source chain in one launch: every face of every level with the 1-texel border the seamless rule
+// selects, as float4 (mip 0's single fetch and the fp32 instance read it) and, when `half_dst` is given,
+// as half4 at 8 bytes per texel: a bilinear footprint is two 16-byte loads, and the lanes of a wave — 64 neighbouring output texels
+// taking the same sample — share the rows' cache lines.  (The shade's FOOTPRINT layout — four texels of a footprint stored together
+// — was tried first: its fourfold duplication of every texel cost more L1 misses than its one-line-per-level saved here, FETCH
+// 2.5 -> 4.5 GB per call; it suits the shade's incoherent gathers, not this kernel's coherent ones.)
 // *lossy is set when a texel's rgb does not survive the conversion to half bit for bit.
-__global__ __launch_bounds__(256) void k_cube_pad_h4(const float4* __restrict__ src, pbr_half* __restrict__ dst, int s, uint32_t* __restrict__ lossy) {
-    const int sp = s + 2;
-    const size_t n = (size_t)6 * sp * sp;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+// (One launch instead of two per level: the twenty small launches of a ten-level chain cost ~0.15 ms of gaps, see profiles/r03_n_*.)
+struct PfPad {
+    uint32_t first_block[17];   // first block of source level l, [mips] = total
+    uint32_t src_off[16];       // texel offset of level l in the unpadded chain
+    uint32_t dst_off[16];       // ... in the padded chains
+    uint32_t size, mips;
+};
+__global__ __launch_bounds__(256) void k_cube_pad_chain(const float4* __restrict__ chain, float4* __restrict__ dst, pbr_half* __restrict__ half_dst, PfPad pp,
+                                                          uint32_t* __restrict__ lossy) {
+    uint32_t l = 0;
+    while (l + 1 < pp.mips && blockIdx.x >= pp.first_block[l + 1]) l++;
+    const int s = (int)(pp.size >> l), sp = s + 2;
+    const uint32_t n = 6u * (uint32_t)sp * (uint32_t)sp;   // host-checked: the padded chain has < 2^32 texels
+    const uint32_t t = (blockIdx.x - pp.first_block[l]) * 256u + threadIdx.x;
     if (t >= n) return;
-    const int xp = (int)(t % sp), yp = (int)((t / sp) % sp);
-    uint32_t face = (uint32_t)(t / ((size_t)sp * sp));
+    const int xp = (int)(t % (uint32_t)sp), yp = (int)((t / (uint32_t)sp) % (uint32_t)sp);
+    uint32_t face = t / ((uint32_t)sp * (uint32_t)sp);
     int x = xp - 1, y = yp - 1;
     const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
     if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
@@ -515,8 +529,10 @@ __global__ __launch_bounds__(256) void k_cube_pad_h4(const float4* __restrict__ 
         x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
         y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
     }
-    const float4 c = src[((size_t)face * s + y) * s + x];
-    store_h4(dst + 4 * t, f4(c.x, c.y, c.z, c.w));
+    const float4 c = chain[(size_t)pp.src_off[l] + ((size_t)face * s + y) * s + x];
+    dst[(size_t)pp.dst_off[l] + t] = c;
+    if (!half_dst) return;
+    store_h4(half_dst + 4 * ((size_t)pp.dst_off[l] + t), f4(c.x, c.y, c.z, c.w));
     const bool lost = (float)to_half_rn(c.x) != c.x || (float)to_half_rn(c.y) != c.y || (float)to_half_rn(c.z) != c.z;   // (NaN counts as lost)
     // one atomic per wave at most, and none once the flag is up (a lossy source would otherwise serialise ~25 000 atomics of its
     // level 0 on one address: measured +0.4 ms)
@@ -525,7 +541,9 @@ __global__ __launch_bounds__(256) void k_cube_pad_h4(const float4* __restrict__ 
 
 // roughness 0: H = L = N for every sample, weight 1: the filtered value IS the bilinear fetch at the texel-corner
 // direction (the reference's 1 024-fold running sum of one value differs from it by < 1e-4 relative, far inside the fp16 ULP)
-__global__ __launch_bounds__(256) void k_prefilter_mip0(const float4* __restrict__ sky_padded, PfLaunch pl, pbr_half* __restrict__ out) {
+// (the call's last kernel: it also lowers the "half copy is lossy" flag again for the next call)
+__global__ __launch_bounds__(256) void k_prefilter_mip0(const float4* __restrict__ sky_padded, PfLaunch pl, pbr_half* __restrict__ out, uint32_t* __restrict__ lossy) {
+    if (lossy && blockIdx.x == 0 && threadIdx.x == 0) *lossy = 0u;
     const uint32_t s = pl.size;
     const size_t n = (size_t)6 * s * s;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -758,70 +776,84 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
         hipLaunchKernelGGL(k_prefilter_env_all, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sky->data, sky->size, sky->mips, size, mips, out);
         return launched(ctx, "k_prefilter_env_all");
     }
-    // ---- wave-parallel path: padded source chain + per-mip sample tables (stream-ordered scratch)
+    // ---- wave-parallel path: padded source chain (stream-ordered scratch) + per-mip sample tables (kept on the device)
     PfLaunch pl{};
     pl.mips = mips; pl.size = size; pl.sky_size = sky->size; pl.sky_mips = sky->mips;
     for (uint32_t l = 0; l < sky->mips; l++) pl.src_off[l] = (uint32_t)cube_border_mip_offset(sky->size, l);
     const size_t padded_texels = cube_border_mip_offset(sky->size, sky->mips);
     PBR_REQUIRE(ctx, padded_texels <= 0xFFFFFFFFull, "pbr_prefilter_env: sky cube too large");
-    ctx->host_tmp.assign((size_t)mips * PBR_SAMPLE_COUNT * 4, 0.0f);
     static const bool wave_per_texel = pbr::knob_set("PBR_PREFILTER_WAVE");   // A/B switch: the other mapping
-    const uint32_t per_block = wave_per_texel ? (uint32_t)PF_TEXELS_PER_BLOCK : 256u;
+    // which kernel samples mips >= 1: the half / fp32 padded chains through k_prefilter_foot (default) or the round-2 kernel on the
+    // padded fp32 chain (knobs build: PBR_PREFILTER_F32=1, kept as the measured alternative); k_prefilter_foot takes 32-bit byte offsets
+    static const bool force_f32 = pbr::knob_set("PBR_PREFILTER_F32");
+    const bool use_foot = !force_f32 && !wave_per_texel && padded_texels * 16u < (1ull << 32) && mips > 1;
+    const uint32_t per_block = wave_per_texel ? (uint32_t)PF_TEXELS_PER_BLOCK : use_foot ? PF_FOOT_BLOCK : 256u;
+    // The sample tables depend on (size, mips, sky mips) only: built on the host and uploaded when that key changes, then reused
+    // (a renderer prefilters the same shapes again and again; the build is ~0.1 ms of libm and the upload a blocking copy).  A new key
+    // takes a NEW device buffer — hipFree of the old one waits for whatever still reads it, whichever stream that is on.
+    const size_t table_bytes = (size_t)mips * PBR_SAMPLE_COUNT * 16;
+    if (!ctx->pf_dev || ctx->pf_key[0] != size || ctx->pf_key[1] != mips || ctx->pf_key[2] != sky->mips) {
+        ctx->host_tmp.assign((size_t)mips * PBR_SAMPLE_COUNT * 4, 0.0f);
+        for (uint32_t m = 1; m < mips; m++) {
+            const float roughness = (float)m / (float)(mips - 1);   // DeferredPipeline.cpp:99
+            ctx->pf_count[m] = build_prefilter_table(roughness, size, sky->mips, ctx->host_tmp.data() + (size_t)m * PBR_SAMPLE_COUNT * 4, &ctx->pf_wsum[m]);
+        }
+        if (ctx->pf_dev) { (void)hipFree(ctx->pf_dev); ctx->pf_dev = nullptr; }
+        PBR_HIP(ctx, hipSetDevice(ctx->device));
+        PBR_HIP(ctx, hipMalloc(&ctx->pf_dev, table_bytes + 16));
+        hipError_t e = hipMemcpy(ctx->pf_dev, ctx->host_tmp.data(), table_bytes, hipMemcpyHostToDevice);   // blocking: host_tmp may be reused at once
+        // the flag: zeroed IN STREAM ORDER (hipMemset on the null stream is not ordered against a non-blocking stream's kernels), then
+        // lowered again by each call's last kernel
+        if (e == hipSuccess) e = hipMemsetAsync(reinterpret_cast<char*>(ctx->pf_dev) + table_bytes, 0, 16, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(ctx->pf_dev); ctx->pf_dev = nullptr; return hip_fail(ctx, e, "prefilter tables"); }
+        ctx->pf_key[0] = size; ctx->pf_key[1] = mips; ctx->pf_key[2] = sky->mips;
+    }
+    const float4* tables = reinterpret_cast<const float4*>(ctx->pf_dev);
+    uint32_t* lossy = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->pf_dev) + table_bytes);   // 1 = the half copy is not exact
     uint32_t blocks = 0;
     for (uint32_t m = 1; m < mips; m++) {
-        const float roughness = (float)m / (float)(mips - 1);   // DeferredPipeline.cpp:99
-        pl.count[m] = build_prefilter_table(roughness, size, sky->mips, ctx->host_tmp.data() + (size_t)m * PBR_SAMPLE_COUNT * 4, &pl.wsum[m]);
+        pl.count[m] = ctx->pf_count[m];
+        pl.wsum[m] = ctx->pf_wsum[m];
         pl.first_block[m] = blocks;
         const uint32_t sm = size >> m;
         blocks += (6u * sm * sm + per_block - 1) / per_block;
     }
     pl.first_block[mips] = blocks;
-    const size_t table_bytes = (size_t)mips * PBR_SAMPLE_COUNT * 16;
-    // which kernel samples mips >= 1: the half footprint chain (default) or the padded fp32 chain (knobs build: PBR_PREFILTER_F32=1,
-    // the round-2 kernel, kept as the measured alternative); the footprint chain needs 32-bit texel offsets
     const size_t foot_texels = padded_texels + 1;   // the half4 copy has the padded fp32 chain's layout (+ 1: the last row pair reads 8 bytes past a texel)
-    static const bool force_f32 = pbr::knob_set("PBR_PREFILTER_F32");
-    const bool use_foot = !force_f32 && !wave_per_texel && foot_texels * 8u < (1ull << 32) && mips > 1;
     float4* padded = nullptr;
-    float4* tables = nullptr;
-    pbr_half* foot = nullptr;
-    PBR_HIP(ctx, hipMallocAsync((void**)&padded, padded_texels * 16 + table_bytes + (use_foot ? foot_texels * 8 : 0) + 16, ctx->stream));
-    tables = padded + padded_texels;
-    foot = reinterpret_cast<pbr_half*>(tables + (size_t)mips * PBR_SAMPLE_COUNT);
-    uint32_t* lossy = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(foot) + (use_foot ? foot_texels * 8 : 0));   // 1 = the half copy is not exact
-    PBR_HIP(ctx, hipMemsetAsync(lossy, 0, 16, ctx->stream));
+    PBR_HIP(ctx, hipMallocAsync((void**)&padded, padded_texels * 16 + (use_foot ? foot_texels * 8 : 0), ctx->stream));
+    pbr_half* foot = use_foot ? reinterpret_cast<pbr_half*>(padded + padded_texels) : nullptr;
     pbr_status r = PBR_OK;
-    hipError_t e = hipMemcpyAsync(tables, ctx->host_tmp.data(), table_bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e != hipSuccess) r = hip_fail(ctx, e, "hipMemcpyAsync(prefilter tables)");
-    PfFootOff fo{};
-    for (uint32_t l = 0; l < sky->mips && r == PBR_OK; l++) {
-        const int sl = (int)(sky->size >> l);
-        const float4* src_l = reinterpret_cast<const float4*>(sky->data) + cube_mip_offset(sky->size, l);
-        {   // the fp32 padded copy: mip 0's single fetch, and the fp32 kernel (which runs when the half copy is not exact)
-            const size_t n = (size_t)6 * (sl + 2) * (sl + 2);
-            hipLaunchKernelGGL(k_cube_pad_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, padded + pl.src_off[l], sl);
-            r = launched(ctx, "k_cube_pad_f32");
-        }
-        if (use_foot && r == PBR_OK) {
-            fo.off[l] = pl.src_off[l];
-            fo.fsize[l] = (float)sl;
-            const size_t n = (size_t)6 * (sl + 2) * (sl + 2);
-            hipLaunchKernelGGL(k_cube_pad_h4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, src_l, foot + 4 * (size_t)fo.off[l], sl, lossy);
-            r = launched(ctx, "k_cube_pad_h4");
-        }
+    PfLevels fo{};
+    PfPad pp{};
+    pp.size = sky->size; pp.mips = sky->mips;
+    uint64_t pad_blocks = 0;
+    for (uint32_t l = 0; l < sky->mips; l++) {
+        const uint32_t sl = sky->size >> l;
+        fo.lev[l] = PfLevel{pl.src_off[l], sl + 2u, (float)sl * 256.0f, (float)(sl + 2u)};
+        pp.first_block[l] = (uint32_t)pad_blocks;
+        pp.src_off[l] = (uint32_t)cube_mip_offset(sky->size, l);
+        pp.dst_off[l] = pl.src_off[l];
+        pad_blocks += ((uint64_t)6 * (sl + 2) * (sl + 2) + 255) / 256;
+    }
+    pp.first_block[sky->mips] = (uint32_t)pad_blocks;
+    if (pad_blocks > 0x7FFFFFFFull) r = pbr::fail(ctx, PBR_ERR_INVALID, "pbr_prefilter_env: sky cube too large");
+    if (r == PBR_OK) {
+        hipLaunchKernelGGL(k_cube_pad_chain, dim3((unsigned)pad_blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(sky->data), padded, foot, pp, lossy);
+        r = launched(ctx, "k_cube_pad_chain");
     }
     if (r == PBR_OK && blocks) {
         if (wave_per_texel) hipLaunchKernelGGL(k_prefilter_fast, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
-        else if (use_foot) {   // both instances; the flag k_cube_pad_h4 wrote picks the one that works, the other returns at once
-            hipLaunchKernelGGL(k_prefilter_foot<true>, dim3(blocks), dim3(256), 0, ctx->stream, (const void*)foot, fo, tables, pl, out, lossy);
+        else if (use_foot) {   // both instances; the flag k_cube_pad_chain wrote picks the one that works, the other returns at once
+            hipLaunchKernelGGL(k_prefilter_foot<true>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)foot, fo, tables, pl, out, lossy);
             r = launched(ctx, "k_prefilter_foot<half>");
-            if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_foot<false>, dim3(blocks), dim3(256), 0, ctx->stream, (const void*)padded, fo, tables, pl, out, lossy);
+            if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_foot<false>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)padded, fo, tables, pl, out, lossy);
         } else hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out, (const uint32_t*)nullptr);
         if (r == PBR_OK) r = launched(ctx, "k_prefilter_*");
     }
     if (r == PBR_OK) {
         const size_t n0 = (size_t)6 * size * size;
-        hipLaunchKernelGGL(k_prefilter_mip0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, padded, pl, out);
+        hipLaunchKernelGGL(k_prefilter_mip0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, padded, pl, out, use_foot ? lossy : (uint32_t*)nullptr);
         r = launched(ctx, "k_prefilter_mip0");
     }
     (void)hipFreeAsync(padded, ctx->stream);

@@ -14,7 +14,12 @@ struct pbr_ctx {
     void* scratch = nullptr;          // device scratch (SH partials, ...)
     size_t scratch_bytes = 0;
     std::string err;
-    std::vector<float> host_tmp;      // host staging that must outlive an enqueued copy (prefilter sample tables)
+    std::vector<float> host_tmp;      // host staging (prefilter sample tables)
+    // pbr_prefilter_env: the sample tables of the last (size, mips, sky mips) + the 16-byte "half copy is lossy" word behind them
+    void* pf_dev = nullptr;
+    uint32_t pf_key[3] = {0, 0, 0};
+    uint32_t pf_count[16] = {};
+    float pf_wsum[16] = {};
     // RCCL (loaded lazily with dlopen so a 1-GPU run never needs librccl)
     void* rccl_lib = nullptr;
     void* comm = nullptr;             // frame communicator: halo exchange (ncclSend / ncclRecv)

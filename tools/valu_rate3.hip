@@ -53,6 +53,18 @@ typedef float f2 __attribute__((ext_vector_type(2)));
                  "v_cubeid_f32 %4, %4, %8, %9\n\tv_cubesc_f32 %5, %5, %9, %8\n\tv_cubetc_f32 %6, %6, %8, %9\n\tv_cubema_f32 %7, %7, %9, %8" \
                  : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y0), "v"(y1));
 
+#define OP8T(INS) /* three sources: d, d, y0, y1 */ \
+    asm volatile(INS " %0, %0, %8, %9\n\t" INS " %1, %1, %9, %8\n\t" INS " %2, %2, %8, %9\n\t" INS " %3, %3, %9, %8\n\t" \
+                 INS " %4, %4, %8, %9\n\t" INS " %5, %5, %9, %8\n\t" INS " %6, %6, %8, %9\n\t" INS " %7, %7, %9, %8" \
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y0), "v"(y1));
+#define RFL8 /* v_readfirstlane_b32 into eight SGPRs */ \
+    { int s0, s1, s2, s3, s4, s5, s6, s7; \
+      asm volatile("v_readfirstlane_b32 %0, %8\n\tv_readfirstlane_b32 %1, %9\n\tv_readfirstlane_b32 %2, %10\n\tv_readfirstlane_b32 %3, %11\n\t" \
+                   "v_readfirstlane_b32 %4, %12\n\tv_readfirstlane_b32 %5, %13\n\tv_readfirstlane_b32 %6, %14\n\tv_readfirstlane_b32 %7, %15" \
+                   : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7) \
+                   : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7)); \
+      asm volatile("" :: "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7)); }
+
 struct Stamp { uint64_t c0, c1, r0, r1; uint32_t hw_id, xcc; };
 
 template <int MODE>
@@ -80,6 +92,25 @@ __global__ void k(float* out, Stamp* st, int iters) {
         else if (MODE == 14) { CUBE8 }
         else if (MODE == 15) { OP8U("v_log_f32") }
         else if (MODE == 16) { OP8U("v_floor_f32") }
+        else if (MODE == 17) { OP8U("v_cvt_rpi_i32_f32") }
+        else if (MODE == 18) { OP8U("v_cvt_flr_i32_f32") }
+        else if (MODE == 19) { OP8U("v_cvt_f32_ubyte0") }
+        else if (MODE == 20) { OP8U("v_cvt_i32_f32") }
+        else if (MODE == 21) { OP8T("v_mad_u32_u24") }
+        else if (MODE == 22) { OP8("v_mul_lo_u32") }
+        else if (MODE == 23) { OP8("v_mul_u32_u24") }
+        else if (MODE == 24) { OP8T("v_lshl_add_u32") }
+        else if (MODE == 25) { OP8("v_add_u32") }
+        else if (MODE == 26) { OP8("v_lshlrev_b32") }
+        else if (MODE == 27) { OP8("v_and_b32") }
+        else if (MODE == 28) { RFL8 }
+        else if (MODE == 29) { OP8U("v_fract_f32") }
+        else if (MODE == 30) { OP8("v_cvt_pkrtz_f16_f32") }
+        else if (MODE == 31) { OP8T("v_add3_u32") }
+        else if (MODE == 32) { OP8T("v_med3_f32") }
+        else if (MODE == 33) { OP8U("v_cvt_f32_i32") }
+        else if (MODE == 34) { OP8U("v_exp_f32") }
+        else if (MODE == 35) { OP8U("v_sqrt_f32") }
         else { OP8U("v_mov_b32") }
     }
     const uint64_t c1 = clock64(), r1 = wall_clock64();
@@ -133,10 +164,59 @@ void run(const char* name, int w, float* out, Stamp* st_dev) {
            clk / waves, ms, ms * 1e6 * (clk / waves) / (n * w));
 }
 
-int main() {
+// what v_cvt_rpi_i32_f32 computes: (int)floorf(x + 0.5f) with the fp32 add's rounding, or the exact floor(x + 0.5)?
+__global__ void k_rpi(const float* x, int* rpi, int* flr, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int a, b;
+    const float y = x[i] + 0.5f;
+    asm volatile("v_cvt_rpi_i32_f32 %0, %1" : "=v"(a) : "v"(x[i]));
+    asm volatile("v_cvt_flr_i32_f32 %0, %1" : "=v"(b) : "v"(y));
+    rpi[i] = a; flr[i] = b;
+}
+static void rpi_probe() {
+    std::vector<float> x;
+    for (int k = -2; k < 20; k++) for (int j = -40; j <= 40; j++) {
+        const float base = ldexpf(1.0f, k);
+        float v = base - 0.5f;
+        for (int t = 0; t < abs(j); t++) v = nextafterf(v, j < 0 ? -1e30f : 1e30f);
+        x.push_back(v);
+        float u = (float)(k + 3) + 0.5f;
+        for (int t = 0; t < abs(j); t++) u = nextafterf(u, j < 0 ? -1e30f : 1e30f);
+        x.push_back(u);
+    }
+    uint32_t r = 12345u;
+    for (int i = 0; i < 1 << 20; i++) { r = r * 1664525u + 1013904223u; x.push_back((float)(r >> 8) * (1.0f / 16777216.0f) * 140000.0f); }
+    const int n = (int)x.size();
+    float* dx; int *da, *db;
+    (void)hipMalloc(&dx, n * 4); (void)hipMalloc(&da, n * 4); (void)hipMalloc(&db, n * 4);
+    (void)hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_rpi, dim3((n + 255) / 256), dim3(256), 0, 0, dx, da, db, n);
+    std::vector<int> a(n), b(n);
+    (void)hipMemcpy(a.data(), da, n * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(b.data(), db, n * 4, hipMemcpyDeviceToHost);
+    long vs_float = 0, vs_exact = 0, flr_bad = 0, shown = 0;
+    for (int i = 0; i < n; i++) {
+        const int f = (int)floorf(x[i] + 0.5f), e = (int)floor((double)x[i] + 0.5);
+        vs_float += a[i] != f; vs_exact += a[i] != e; flr_bad += b[i] != f;
+        if (f != e && shown < 6) { printf("  x = %.9g: floorf(x + 0.5f) = %d, exact floor(x + 0.5) = %d, v_cvt_rpi = %d, v_add + v_cvt_flr = %d\n", x[i], f, e, a[i], b[i]); shown++; }
+    }
+    printf("v_cvt_rpi_i32_f32 on %d inputs: %ld differ from (int)floorf(x + 0.5f), %ld differ from the exact floor(x + 0.5); v_add_f32 0.5 + v_cvt_flr_i32_f32: %ld differ from (int)floorf(x + 0.5f)\n\n",
+           n, vs_float, vs_exact, flr_bad);
+}
+
+int main(int argc, char** argv) {
+    const bool only_new = argc > 1;   // any argument: only the round-3b rows (integer / convert instructions), at 5 and 8 waves per SIMD
+    rpi_probe();
     float* out; (void)hipMalloc(&out, 256 * 8 * 256 * 4);
     Stamp* st; (void)hipMalloc(&st, 256 * 8 * 4 * sizeof(Stamp));
     for (int w : {1, 2, 4, 5, 8}) {
+        if (only_new && w != 5 && w != 8) continue;
+        run<17>("v_cvt_rpi_i32", w, out, st); run<18>("v_cvt_flr_i32", w, out, st); run<19>("v_cvt_f32_ubyte0", w, out, st); run<20>("v_cvt_i32_f32", w, out, st);
+        run<33>("v_cvt_f32_i32", w, out, st); run<21>("v_mad_u32_u24", w, out, st); run<22>("v_mul_lo_u32", w, out, st); run<23>("v_mul_u32_u24", w, out, st);
+        run<24>("v_lshl_add_u32", w, out, st); run<25>("v_add_u32", w, out, st); run<26>("v_lshlrev_b32", w, out, st); run<27>("v_and_b32", w, out, st);
+        run<28>("v_readfirstlane", w, out, st); run<29>("v_fract_f32", w, out, st); run<30>("v_cvt_pkrtz_f16", w, out, st); run<31>("v_add3_u32", w, out, st);
+        run<32>("v_med3_f32", w, out, st); run<34>("v_exp_f32", w, out, st); run<35>("v_sqrt_f32", w, out, st);
+        if (only_new) { printf("\n"); continue; }
         run<0>("v_mul_f32", w, out, st); run<1>("v_add_f32", w, out, st); run<2>("v_fma_f32 3vgpr", w, out, st); run<3>("v_mul_f32 sgpr", w, out, st);
         run<4>("v_pk_fma_f32", w, out, st); run<5>("v_pk_mul_f32", w, out, st); run<6>("v_pk_add_f32", w, out, st);
         run<7>("v_rcp_f32", w, out, st); run<8>("v_rsq_f32", w, out, st); run<9>("v_max_f32", w, out, st); run<10>("v_mov_b32", w, out, st);
