@@ -515,28 +515,31 @@ __global__ __launch_bounds__(256) void k_cube_pad_chain(const float4* __restrict
     const int s = (int)(pp.size >> l), sp = s + 2;
     const uint32_t n = 6u * (uint32_t)sp * (uint32_t)sp;   // host-checked: the padded chain has < 2^32 texels
     const uint32_t t = (blockIdx.x - pp.first_block[l]) * 256u + threadIdx.x;
-    if (t >= n) return;
-    const int xp = (int)(t % (uint32_t)sp), yp = (int)((t / (uint32_t)sp) % (uint32_t)sp);
-    uint32_t face = t / ((uint32_t)sp * (uint32_t)sp);
-    int x = xp - 1, y = yp - 1;
-    const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
-    if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
-        if (xo & yo) y = clampi(y, 0, s - 1);
-        const float uu = 2.0f * ((float)x + 0.5f) / (float)s - 1.0f;
-        const float vv = 2.0f * ((float)y + 0.5f) / (float)s - 1.0f;
-        float u2, v2;
-        cube_face_uv(cube_dir_raw(face, uu, vv), face, u2, v2);
-        x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
-        y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
+    bool lost = false;
+    if (t < n) {
+        const int xp = (int)(t % (uint32_t)sp), yp = (int)((t / (uint32_t)sp) % (uint32_t)sp);
+        uint32_t face = t / ((uint32_t)sp * (uint32_t)sp);
+        int x = xp - 1, y = yp - 1;
+        const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
+        if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
+            if (xo & yo) y = clampi(y, 0, s - 1);
+            const float uu = 2.0f * ((float)x + 0.5f) / (float)s - 1.0f;
+            const float vv = 2.0f * ((float)y + 0.5f) / (float)s - 1.0f;
+            float u2, v2;
+            cube_face_uv(cube_dir_raw(face, uu, vv), face, u2, v2);
+            x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
+            y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
+        }
+        const float4 c = chain[(size_t)pp.src_off[l] + ((size_t)face * s + y) * s + x];
+        dst[(size_t)pp.dst_off[l] + t] = c;
+        if (half_dst) {
+            store_h4(half_dst + 4 * ((size_t)pp.dst_off[l] + t), f4(c.x, c.y, c.z, c.w));
+            lost = (float)to_half_rn(c.x) != c.x || (float)to_half_rn(c.y) != c.y || (float)to_half_rn(c.z) != c.z;   // (NaN counts as lost)
+        }
     }
-    const float4 c = chain[(size_t)pp.src_off[l] + ((size_t)face * s + y) * s + x];
-    dst[(size_t)pp.dst_off[l] + t] = c;
-    if (!half_dst) return;
-    store_h4(half_dst + 4 * ((size_t)pp.dst_off[l] + t), f4(c.x, c.y, c.z, c.w));
-    const bool lost = (float)to_half_rn(c.x) != c.x || (float)to_half_rn(c.y) != c.y || (float)to_half_rn(c.z) != c.z;   // (NaN counts as lost)
-    // one atomic per wave at most, and none once the flag is up (a lossy source would otherwise serialise ~25 000 atomics of its
-    // level 0 on one address: measured +0.4 ms)
-    if (__any(lost) && (threadIdx.x & 63) == 0 && __hip_atomic_load(lossy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(lossy, 1u);
+    // one look at the flag per BLOCK at most, and no atomic once it is up: a lossy source would otherwise serialise one device-scope
+    // access per wave (~25 000 for a 512^2 level 0) on one address — measured +0.4 ms as atomicOr, +0.09 ms as guarded loads per wave
+    if (half_dst && __syncthreads_or(lost) && threadIdx.x == 0 && __hip_atomic_load(lossy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(lossy, 1u);
 }
 
 // roughness 0: H = L = N for every sample, weight 1: the filtered value IS the bilinear fetch at the texel-corner
