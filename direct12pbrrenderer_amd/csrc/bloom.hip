@@ -609,12 +609,17 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
 //   * V pass: a thread owns a column and TH/4 CONSECUTIVE rows, so the rows it taps overlap: TH/4 + 8 reads of the
 //     fp16 tile for TH/4 outputs instead of nine per output.
 // One block (512 threads, 8 waves) = one 128 x TH tile.  Operation order per sample / tap is k_blur_hv's.
+// texel `byte_off / 8` of a half4 image: a (wave-uniform or not) base + an UNSIGNED 32-bit byte offset, the form that loads as
+// `global_load_dwordx2 v, v_off, s[base]` — a signed index makes every load pay a 64-bit vector add (slow issue class, §4.7).
+// Images here are < 4 GiB (8 192^2 half4 = 512 MB).
+__device__ __forceinline__ H4 ld_h4(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const H4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 __device__ __forceinline__ void pair_tap_up(const pbr_half* __restrict__ in, int iw, int cm, int c0, int cp, int ay0, int ay1, float fy,
                                             V3& even, V3& odd) {
-    const H4* ra = reinterpret_cast<const H4*>(in) + (size_t)ay0 * iw;
-    const H4* rb = reinterpret_cast<const H4*>(in) + (size_t)ay1 * iw;
-    const V3 am = h3f(ra[cm]), a0 = h3f(ra[c0]), ap = h3f(ra[cp]);
-    const V3 bm = h3f(rb[cm]), b0 = h3f(rb[c0]), bp = h3f(rb[cp]);
+    const uint32_t ra = (uint32_t)(ay0 * iw) * 8u, rb = (uint32_t)(ay1 * iw) * 8u, om = (uint32_t)cm * 8u, o0 = (uint32_t)c0 * 8u, op = (uint32_t)cp * 8u;
+    const V3 am = h3f(ld_h4(in, ra + om)), a0 = h3f(ld_h4(in, ra + o0)), ap = h3f(ld_h4(in, ra + op));
+    const V3 bm = h3f(ld_h4(in, rb + om)), b0 = h3f(ld_h4(in, rb + o0)), bp = h3f(ld_h4(in, rb + op));
     const float wy0 = 1.0f - fy;
     // even column 2p: taps (p-1, p), second-tap weight 3/4; odd column 2p+1: (p, p+1), 1/4 (tap1d<M_UP>; finish_tap2_rgb)
     even = fma3(fma3(b0, 0.75f, bm * 0.25f), fy, fma3(a0, 0.75f, am * 0.25f) * wy0);
@@ -639,7 +644,7 @@ extern "C" int pbr_debug_tail_stamps(unsigned long long* host, int n) { return (
 #define TWAIT_VM() do {} while (0)
 #endif
 template <bool DUAL, int TAIL, int TH>
-__global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restrict__ in, int iw, int ih,
+__global__ __launch_bounds__(512, TH == 16 ? 6 : 4) void k_blur_up_wide(const pbr_half* __restrict__ in, int iw, int ih,
                                                           const pbr_half* __restrict__ in2,   // DUAL: ow x oh, same-size
                                                           pbr_half* __restrict__ out, int ow, int oh, int out_pitch,
                                                           int tiles_x, int n_tiles,
@@ -674,8 +679,11 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
     TSTAMP(0);
     H4 hdr_in[PER_O];
     const bool in_mx = TAIL != 0 && xv >= tr.mx0 && xv < tr.mx1;
-    // this thread's first HDR texel (dereferenced only inside the merge rect); rows follow at out_pitch
-    H4* const hdr_px = reinterpret_cast<H4*>(out) + ((ptrdiff_t)(y0 + rbase - tr.by) * out_pitch + (xv - tr.bx));
+    // this thread's HDR texels (dereferenced only inside the merge rect): row k of the thread = a wave-uniform base + the lane's
+    // unsigned byte offset
+    char* const hdr_row0 = reinterpret_cast<char*>(out) + (ptrdiff_t)(y0 + rbase - tr.by) * out_pitch * 8;
+    const uint32_t hdr_x = (uint32_t)(xv - tr.bx) * 8u;
+    const size_t hdr_pitch = (size_t)out_pitch * 8u;
     // sample positions: columns x0-4 .. x0+131 = pair entries 0..67 (entry q = level texel pair index x0/2 - 2 + q),
     // rows clamp(y0-4+r).  Main entry of a row: q = lane; the four halo entries 64..67 of the wave's PER_T rows are one
     // extra tap: lane -> (row lane / 4, entry 64 + lane % 4).
@@ -693,10 +701,11 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
             constexpr int NR = PER_T / 2 + 2;
             const int base = (first >> 1) - 1 + (first & 1);
             V3 hrE[NR], hrO[NR];
+            const uint32_t om = (uint32_t)cm * 8u, o0 = (uint32_t)c0 * 8u, op = (uint32_t)cp * 8u;
 #pragma unroll
             for (int j = 0; j < NR; j++) {
-                const H4* row = reinterpret_cast<const H4*>(in) + (size_t)min(base + j, ih - 1) * iw;
-                const V3 tm = h3f(row[cm]), t0 = h3f(row[c0]), tp = h3f(row[cp]);
+                const char* row = reinterpret_cast<const char*>(in) + (size_t)min(base + j, ih - 1) * iw * 8u;   // wave-uniform: a scalar base
+                const V3 tm = h3f(ld_h4(row, om)), t0 = h3f(ld_h4(row, o0)), tp = h3f(ld_h4(row, op));
                 hrE[j] = fma3(t0, 0.75f, tm * 0.25f);
                 hrO[j] = fma3(tp, 0.25f, t0 * 0.75f);
             }
@@ -724,8 +733,8 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
         if (DUAL) {
 #pragma unroll
             for (int k = 0; k < PER_T; k++) {
-                const H4* row = reinterpret_cast<const H4*>(in2) + (size_t)clampi(first + k, 0, oh - 1) * ow;
-                upE[k] = row[sxe]; upO[k] = row[sxo];
+                const char* row = reinterpret_cast<const char*>(in2) + (size_t)clampi(first + k, 0, oh - 1) * ow * 8u;   // wave-uniform
+                upE[k] = ld_h4(row, (uint32_t)sxe * 8u); upO[k] = ld_h4(row, (uint32_t)sxo * 8u);
             }
         }
         if (has_halo) {
@@ -735,8 +744,8 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
             tap1d<M_UP>(jj, ih, ay0, ay1, fy);
             pair_tap_up(in, iw, clampi(hp - 1, 0, iw - 1), clampi(hp, 0, iw - 1), clampi(hp + 1, 0, iw - 1), ay0, ay1, fy, hE, hO);
             if (DUAL) {
-                const H4* row = reinterpret_cast<const H4*>(in2) + (size_t)jj * ow;
-                hupE = row[clampi(x0 - 4 + 2 * hq, 0, ow - 1)]; hupO = row[clampi(x0 - 3 + 2 * hq, 0, ow - 1)];
+                const uint32_t row = (uint32_t)(jj * ow) * 8u;
+                hupE = ld_h4(in2, row + (uint32_t)clampi(x0 - 4 + 2 * hq, 0, ow - 1) * 8u); hupO = ld_h4(in2, row + (uint32_t)clampi(x0 - 3 + 2 * hq, 0, ow - 1) * 8u);
             }
         }
         // the HDR texels of the merge: issued AFTER the level's texels (loads return in order, and the samples below wait
@@ -745,7 +754,7 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
 #pragma unroll
             for (int k = 0; k < PER_O; k++) {
                 const int y = y0 + rbase + k;
-                if (in_mx && y >= tr.my0 && y < tr.my1) hdr_in[k] = hdr_px[(ptrdiff_t)k * out_pitch];
+                if (in_mx && y >= tr.my0 && y < tr.my1) hdr_in[k] = ld_h4(hdr_row0 + k * hdr_pitch, hdr_x);
             }
         }
         TSTAMP(1);
@@ -787,6 +796,9 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
     TSTAMP(4);
     // ---- V-gauss over a sliding window of the fp16 tile + tail
     {
+        // (the compiler folds the window's fp16 -> fp32 converts into one v_fma_mix_f32 per tap; converting the window once and
+        //  tapping with plain FMAs — 4.5 + n x 2.7 against n x 4.6 issue cycles, DESIGN 4.7 — was measured: 216 fewer slow-class
+        //  instructions per thread and tile, the launch's time unchanged, profiles/r03_n_bloom_tail_experiments.md)
         H4 win[PER_O + 8];
 #pragma unroll
         for (int i = 0; i < PER_O + 8; i++) win[i] = sT[rbase + i][vc];
@@ -809,7 +821,7 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_wide(const pbr_half* __restr
                 struct alignas(8) O4 { half2v lo, hi; } o;
                 o.lo = round_h2(s.x + (float)a01.x, s.y + (float)a01.y);
                 o.hi = round_h2(s.z + (float)a2, s.w + a0w);
-                *reinterpret_cast<O4*>(hdr_px + (ptrdiff_t)k * out_pitch) = o;
+                *reinterpret_cast<O4*>(hdr_row0 + k * hdr_pitch + hdr_x) = o;
                 if (TAIL == 2) {   // plain per-lane LDS atomics: wave-aggregating equal bins first (exposure.hip) costs more VALU here than it saves
                     if (xv >= tr.hx0 && xv < tr.hx1 && y >= tr.hy0 && y < tr.hy1)
                         atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.lo.x, (float)o.lo.y, (float)o.hi.x, min_log, inv_range)], 1u);
@@ -864,10 +876,22 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
     if constexpr (MODE == M_UP) {
         // 2x-up levels big enough to fill the chip with 128 x 32 tiles: the two-columns-per-lane kernel (PBR_BLOOM_WIDE=0|1 forces)
         static const int wide_forced = pbr::knob_int("PBR_BLOOM_WIDE", -1);
+#ifdef PBR_DEBUG_KNOBS
+        static const int wide_th = pbr::knob_int("PBR_BLOOM_WIDE_TH", 32);   // experiment (knobs build): 128 x 16 tiles at 6 waves per SIMD — 53.4 us against 49.2
+#endif
         const int wtx0 = tr.mx0 / 128, wty0 = tr.my0 / 32;
         const int wtiles_x = (tr.mx1 + 127) / 128 - wtx0, wn = wtiles_x * ((tr.my1 + 31) / 32 - wty0);
         if (wide_forced >= 0 ? wide_forced == 1 : wn >= 400) {
             tr.tx0 = wtx0; tr.ty0 = wty0;
+#ifdef PBR_DEBUG_KNOBS
+            if (wide_th == 16) {
+                tr.ty0 = tr.my0 / 16;
+                const int wn16 = wtiles_x * ((tr.my1 + 15) / 16 - tr.ty0);
+                hipLaunchKernelGGL((k_blur_up_wide<DUAL, TAIL, 16>), dim3(TAIL == 2 ? even_blocks(wn16) : wn16), dim3(512), 0, ctx->stream,
+                                   in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, wtiles_x, wn16, tr, min_log, inv_range, hist);
+                return launched(ctx, "k_blur_up_wide<16>");
+            }
+#endif
             hipLaunchKernelGGL((k_blur_up_wide<DUAL, TAIL, 32>), dim3(TAIL == 2 ? even_blocks(wn) : wn), dim3(512), 0, ctx->stream,
                                in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, wtiles_x, wn, tr, min_log, inv_range, hist);
             return launched(ctx, "k_blur_up_wide");
