@@ -14,15 +14,69 @@ using namespace pbr;
 
 // ============================================================================ BRDF LUT (a3)
 // grid (res, ceil(res/256)), block 256: one block = one roughness column x, 256 NdotV rows.
+// a * b and a + b saturated to [0, 1] through the clamp modifier: a plain-class instruction where `max(x, 0)` is a second one of the
+// slow class (v_max_f32 issues at ~4.6 cycles per wave against 2.7, profiles/r03_valu_rate3b.txt).  The operands here never exceed 1
+// by more than rounding.  (s_nop: the wait state a VALU consumer needs behind v_rsq / v_rcp, which the compiler cannot see into asm.)
+__device__ __forceinline__ float mul_sat(float a, float b) {
+    float r;
+    asm("s_nop 0\n\tv_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float add_sat(float a, float b) {
+    float r;
+    asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * b + c saturated to [0, 1]
+__device__ __forceinline__ float fma_sat(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// The sample loop of one LUT texel.  Same estimator as IntegrateBRDF (brdf.hlsli:137-167 — restated in oracle/pbr_oracle.cpp
+// orc_brdf_lut), arranged for what gfx950 issues fast (fp32 mul / add / fma ~2.7 cycles per wave, v_max / v_min ~4.6,
+// transcendentals 8.5); each step stays within a few 1e-7 relative of the shader's expression, three orders below the fp16
+// rounding of the result (every texel within 1 fp16 ULP of the oracle: tests/test_gpu_parity.py):
+//  * L = 2 (V.H) H - V is a unit vector to ~3e-7 when V and H are: normalize(L) — two more components, a dot product and a v_rsq
+//    — is dropped, N.L = L.z comes out of one FMA whose clamp modifier is the max(., 0);
+//  * 1 / max(NdotH NdotV, 1e-4) = (1 / NdotV) min(1 / NdotH, 1e4 NdotV): 1 / NdotH rides in the sample table, 1 / NdotV and the
+//    per-texel factor gv leave the loop: no reciprocal here, and ONE transcendental per sample (the v_rcp of gl's denominator);
+//  * no branch on NdotL > 0: the sample's weight is an exact +0 there and every factor is finite;
+//  * multiply-adds are fused (this TU is built -ffp-contract=off for the table's sin(theta), not for this loop).
+// tab[i] = (H.x, 2 H.z, H.z, 1 / max(H.z, 0)).  KSAFE: k = roughness^2 / 2 >= 1e-6, the shader's max(NdotL (1 - k) + k, 1e-6)
+// never binds (NdotL >= 0).
+template <bool KSAFE>
+__device__ __forceinline__ void brdf_lut_samples(const float4* tab, float Vx, float Vz, float NdotV, float k, float one_k, float& A_out, float& B_out) {
+    float A = 0.0f, B = 0.0f;
+    const float c1 = 1.0e4f * NdotV, nVz = -Vz;
+#pragma unroll 4
+    for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
+        const float4 H = tab[i];
+        const float vx = Vx * H.x, vz = Vz * H.z;   // V.y == 0
+        const float VdH = vx + vz;
+        const float VdotH = add_sat(vx, vz);        // max(V.H, 0)
+        const float NdotL = fma_sat(VdH, H.y, nVz); // max(2 (V.H) H.z - V.z, 0)
+        const float omv = 1.0f - VdotH;
+        const float o2 = omv * omv;
+        const float Fc = o2 * o2 * omv;
+        float den = __builtin_fmaf(NdotL, one_k, k);
+        if (!KSAFE) den = fmaxf(den, EPSILON_F);
+        const float g = (NdotL * __builtin_amdgcn_rcpf(den)) * (VdotH * fminf(H.w, c1));   // G_Vis / (gv / NdotV)
+        A = __builtin_fmaf(1.0f - Fc, g, A);
+        B = __builtin_fmaf(Fc, g, B);
+    }
+    A_out = A; B_out = B;
+}
+
 __global__ __launch_bounds__(256) void k_brdf_lut(uint32_t res, pbr_half* __restrict__ out) {
-    __shared__ float4 tab[PBR_SAMPLE_COUNT];   // normalized H in the N=(0,0,1) frame
+    __shared__ float4 tab[PBR_SAMPLE_COUNT];   // per sample, from the normalized H in the N=(0,0,1) frame: (H.x, 2 H.z, H.z, 1 / NdotH)
     const uint32_t x = blockIdx.x;
     const float roughness = (float)x / (float)(res - 1);
     for (uint32_t i = threadIdx.x; i < PBR_SAMPLE_COUNT; i += 256) {
         float xi_x = (float)i / (float)PBR_SAMPLE_COUNT;
         float xi_y = radical_inverse_vdc(i);
         V3 H = ggx_important_sample(roughness, v3(0.0f, 0.0f, 1.0f), xi_x, xi_y);
-        tab[i] = make_float4(H.x, H.y, H.z, 0.0f);
+        tab[i] = make_float4(H.x, 2.0f * H.z, H.z, 1.0f / fmaxf(H.z, 0.0f));   // 1 / 0 = +inf: min(inf, 1e4 NdotV) in the loop is the shader's floor
     }
     __syncthreads();
     const uint32_t y = blockIdx.y * 256 + threadIdx.x;
@@ -32,32 +86,11 @@ __global__ __launch_bounds__(256) void k_brdf_lut(uint32_t res, pbr_half* __rest
     const float k = roughness * roughness / 2.0f;   // Q6: k = r^2/2 in the LUT
     const float one_k = 1.0f - k;
     const float gv = NdotV / fmaxf(NdotV * one_k + k, EPSILON_F);
-    // The sample loop is issue-bound (268 M sample steps at 512^2): reciprocals and the L normalisation use the 1-ulp
-    // hardware v_rcp_f32 / v_rsq_f32 instead of IEEE divide / sqrt sequences (3 transcendentals + ~30 plain ops per
-    // sample instead of ~78 instructions).  The per-sample error (~3e-7 relative) is three orders below the fp16
-    // rounding of the result: the plane stays within 1 fp16 ULP of the oracle (tests/test_gpu_parity.py).
-    float A = 0.0f, B = 0.0f;
-#pragma unroll 4
-    for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
-        const float4 H = tab[i];
-        const float VdH = Vx * H.x + Vz * H.z;   // V.y == 0
-        const float t2 = 2.0f * VdH;
-        const float Lx = t2 * H.x - Vx, Ly = t2 * H.y, Lz = t2 * H.z - Vz;
-        const float invl = __builtin_amdgcn_rsqf(Lx * Lx + Ly * Ly + Lz * Lz);
-        const float NdotL = fmaxf(Lz * invl, 0.0f);
-        const float NdotH = fmaxf(H.z, 0.0f);
-        const float VdotH = fmaxf(VdH, 0.0f);
-        if (NdotL > 0.0f) {
-            const float omv = 1.0f - VdotH;
-            const float o2 = omv * omv;
-            const float Fc = o2 * o2 * omv;
-            const float gl = NdotL * __builtin_amdgcn_rcpf(fmaxf(NdotL * one_k + k, EPSILON_F));
-            const float G = gv * gl;
-            const float G_Vis = (G * VdotH) * __builtin_amdgcn_rcpf(fmaxf(NdotH * NdotV, 0.0001f));
-            A += (1.0f - Fc) * G_Vis;
-            B += Fc * G_Vis;
-        }
-    }
+    float A, B;
+    if (k >= EPSILON_F) brdf_lut_samples<true>(tab, Vx, Vz, NdotV, k, one_k, A, B);   // block-uniform (every column but roughness ~ 0)
+    else brdf_lut_samples<false>(tab, Vx, Vz, NdotV, k, one_k, A, B);
+    const float scale = gv / NdotV;   // the factors of G_Vis that do not depend on the sample
+    A *= scale; B *= scale;
     A = A / (float)PBR_SAMPLE_COUNT;
     B = B / (float)PBR_SAMPLE_COUNT;
     H2 o;
