@@ -192,7 +192,10 @@ pbr_status pbr_cube_gen_mips(pbr_ctx* ctx, float* cube_data, uint32_t size, uint
  * Mips >= 1 are sampled from a half-precision copy of the source chain WHEN THAT COPY IS EXACT — every rgb texel of every
  * source mip survives fp32 -> half -> fp32 bit for bit, which is the case for everything the reference can feed this pass (its
  * sky assets are BC6H_UF16: BasicStorage.h:10-11) — and from the fp32 chain otherwise; decided on the device, the call stays
- * asynchronous.  Either way <= 1 fp16 ULP (or 1e-3 relative) from the shader's sequential sum. */
+ * asynchronous.  Either way <= 1 fp16 ULP (or 1e-3 relative) from the shader's sequential sum.
+ * The per-mip GGX sample tables depend on (size, mips, sky->mips) only: the context keeps the last set on the device, so the FIRST
+ * call with a new shape builds and uploads them (a blocking copy, ~0.2 ms of host work) and later calls do not; like every entry
+ * point, one call at a time per context. */
 pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t size, uint32_t mips,
                              pbr_half* out_rgba);
 /* ONE dispatch of env_map_gen.hlsl: cbuffer {Roughness, MipLevel, PrefilterEnvMapTextureSize}

@@ -456,6 +456,37 @@ def test_prefilter_env_on_a_half_representable_source_takes_the_half_copy_and_st
         assert (d > 0).mean() < 0.25, (name, size, float((d > 0).mean()))
 
 
+def test_prefilter_env_source_levels_above_1670_texels(ctx, orc):
+    """k_prefilter_foot forms texel indices in fp32 (exact below 2^24) for source levels up to 1 670 texels and with integer
+    multiply-adds above.  A 2 048^2 source filtered into a 32^2 chain puts most samples on source levels 0 (2 048: the integer
+    branch) and 1 (1 024: the fp32 branch): 3 x 96 seeded texels against the oracle, on the half-representable chain (half copy
+    sampled) and on the fp32 chain (fp32 copy sampled).  The source is the 512^2 synthetic sky repeated 4 x 4 per texel under a
+    per-texel modulation (env_cube(2048) itself takes ~20 s of numpy)."""
+    S, SM, OUT, MIPS = 2048, 12, 32, 3
+    small = synth.env_cube(512, 1)[: 4 * 6 * 512 * 512].reshape(6, 512, 512, 4)
+    big = np.repeat(np.repeat(small, 4, axis=1), 4, axis=2)
+    yy, xx = np.meshgrid(np.arange(S, dtype=np.uint32), np.arange(S, dtype=np.uint32), indexing="ij")
+    big[..., :3] *= (1.0 + 0.03 * (((xx * 7 + yy * 13) % 16).astype(np.float32) / 16.0))[None, :, :, None]
+    chain = np.zeros(4 * cube_mip_offset(S, SM), dtype=np.float32)
+    chain[: big.size] = big.reshape(-1)
+    del big, small, xx, yy
+    dsky = ctx.upload(chain)
+    ctx.cube_gen_mips(dsky, S, SM)
+    rng = np.random.default_rng(20480)
+    for name, dev in (("half-representable", dsky.half().float()), ("fp32", dsky)):
+        host = dev.cpu().numpy()
+        got = to_np_half(ctx.prefilter_env(dev, S, SM, OUT, MIPS))
+        ctx.sync()
+        for m in range(MIPS):
+            n = 6 * (OUT >> m) ** 2
+            idx = np.sort(rng.choice(n, size=min(96, n), replace=False)).astype(np.uint32)
+            want = orc.prefilter_env_texels(host, S, SM, OUT, MIPS, m, idx)
+            sub = got[cube_mip_offset(OUT, m) + idx.astype(np.int64)]
+            d = common.half_ulp_diff(sub[:, :3], want[:, :3])
+            rel = np.abs(sub[:, :3].astype(np.float32) - want[:, :3].astype(np.float32)) <= 1e-3 * np.abs(want[:, :3].astype(np.float32))
+            assert ((d <= 1) | rel).all(), (name, m, int(d.max()))
+
+
 # ------------------------------------------------------------------------------------------ a14-a15
 def _levels(flat, w, h):
     return [flat[bloom_level_offset(w, h, l): bloom_level_offset(w, h, l + 1)].reshape(h >> l, w >> l, 4) for l in range(5)]
