@@ -438,8 +438,10 @@ __device__ __forceinline__ void pf_level_f32(float& r, float& g, float& b, const
     const char* row0 = reinterpret_cast<const char*>(chain) + (size_t)lv.off * 16u;
     const char* row1 = row0 + (size_t)lv.sp * 16u;
     const uint32_t vo = c.o * 16u;   // host-checked: the fp32 chain is < 4 GiB
-    const float4 t00 = *reinterpret_cast<const float4*>(row0 + vo), t10 = *reinterpret_cast<const float4*>(row0 + vo + 16u);
-    const float4 t01 = *reinterpret_cast<const float4*>(row1 + vo), t11 = *reinterpret_cast<const float4*>(row1 + vo + 16u);
+    // rgb only: a 12-byte load per texel (alpha is never sampled)
+    struct Rgb { float x, y, z; };
+    const Rgb t00 = *reinterpret_cast<const Rgb*>(row0 + vo), t10 = *reinterpret_cast<const Rgb*>(row0 + vo + 16u);
+    const Rgb t01 = *reinterpret_cast<const Rgb*>(row1 + vo), t11 = *reinterpret_cast<const Rgb*>(row1 + vo + 16u);
     const PfWeights w = pf_weights(c, wl);
     r = __builtin_fmaf(t00.x, w.w00, r); g = __builtin_fmaf(t00.y, w.w00, g); b = __builtin_fmaf(t00.z, w.w00, b);
     r = __builtin_fmaf(t10.x, w.w10, r); g = __builtin_fmaf(t10.y, w.w10, g); b = __builtin_fmaf(t10.z, w.w10, b);
