@@ -269,6 +269,7 @@ __device__ __forceinline__ V3 padded_trilinear(const float4* __restrict__ sky, c
     return v3(__builtin_fmaf(b.x, f, a.x * w0), __builtin_fmaf(b.y, f, a.y * w0), __builtin_fmaf(b.z, f, a.z * w0));
 }
 
+#ifdef PBR_DEBUG_KNOBS   // the wave-per-texel mapping: only the knobs build can select it (PBR_PREFILTER_WAVE=1); measured 2.4x slower than lane-per-texel
 __global__ __launch_bounds__(256) void k_prefilter_fast(const float4* __restrict__ sky_padded, const float4* __restrict__ tables,
                                                           PfLaunch pl, pbr_half* __restrict__ out) {
     __shared__ float4 tab[PBR_SAMPLE_COUNT];
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(256) void k_prefilter_fast(const float4* __restrict
         }
     }
 }
+#endif
 
 // The same table-driven, branch-free inner loop with the OTHER mapping: one lane per output texel, the 64 lanes of a
 // wave are 64 neighbouring texels and all of them take sample j at the same time.  Neighbouring texels reflect the same
@@ -881,8 +883,11 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
         r = launched(ctx, "k_cube_pad_chain");
     }
     if (r == PBR_OK && blocks) {
+#ifdef PBR_DEBUG_KNOBS
         if (wave_per_texel) hipLaunchKernelGGL(k_prefilter_fast, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
-        else if (use_foot) {   // both instances; the flag k_cube_pad_chain wrote picks the one that works, the other returns at once
+        else
+#endif
+        if (use_foot) {   // both instances; the flag k_cube_pad_chain wrote picks the one that works, the other returns at once
             hipLaunchKernelGGL(k_prefilter_foot<true>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)foot, fo, tables, pl, out, lossy);
             r = launched(ctx, "k_prefilter_foot<half>");
             if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_foot<false>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)padded, fo, tables, pl, out, lossy);
