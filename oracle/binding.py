@@ -269,6 +269,16 @@ def deferred_shade_f64(g, tile: Tile, gb, lut, env, env_size, env_mips, clusters
     return lo, hi, flags
 
 
+def brdf_lut_f64(res, y0=0, rows=None):
+    """Rows [y0, y0 + rows) of the split-sum LUT in double precision (pbr_oracle_f64.cpp): float64 [rows, res, 2]."""
+    rows = res - y0 if rows is None else rows
+    out = np.zeros((rows, res, 2), dtype=np.float64)
+    L = lib()
+    L.orc_brdf_lut_f64.argtypes = [_u32, _u32, _u32, _vp]
+    _ok(L.orc_brdf_lut_f64(res, y0, rows, _p(out)), "brdf_lut_f64")
+    return out
+
+
 def truth_distance(colour, lo, hi):
     """Per-pixel, per-channel distance of an fp32 colour [h,w,>=3] to the double-precision interval [lo, hi]."""
     c = colour[..., :3].astype(np.float64)

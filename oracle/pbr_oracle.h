@@ -103,6 +103,9 @@ int orc_deferred_shade_f64(const pbr_global* g, const pbr_tile* tile, const pbr_
                        const uint16_t* env, uint32_t env_size, uint32_t env_mips,
                        const pbr_cluster* clusters, const pbr_light* lights,
                        double* lo_rgb, double* hi_rgb, uint8_t* flags, uint32_t out_pitch);
+/* The split-sum LUT (a3) in double precision: rows [y0, y0 + rows) of the res x res plane as (A, B) pairs of doubles — the
+   value the estimator of precompute_brdf.hlsl:20-62 has in exact arithmetic (pbr_oracle_f64.cpp). */
+int orc_brdf_lut_f64(uint32_t res, uint32_t y0, uint32_t rows, double* out_ab);
 int orc_skybox(const pbr_global* g, const pbr_tile* tile, const float* sky, uint32_t sky_size, uint32_t sky_mips,
                const uint8_t* stencil, uint32_t pitch, uint16_t* hdr, uint32_t hdr_pitch);                  /* 8f-1 */
 int orc_gbuffer_encode(const float* m0, const float* m1, const float* m2, uint32_t w, uint32_t h, uint32_t pitch,

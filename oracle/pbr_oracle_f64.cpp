@@ -284,3 +284,55 @@ extern "C" int orc_deferred_shade_f64(const pbr_global* g, const pbr_tile* tile,
     }
     return PBR_OK;
 }
+
+// ==================================================================== a3 in double: precompute_brdf.hlsl:20-62
+// The split-sum LUT evaluated in double precision, same estimator (the 1 024 Hammersley / GGX-importance samples of
+// brdf.hlsli:71-114, IntegrateBRDF's sum, k = roughness^2 / 2): what the reference's formulas give in exact arithmetic for the
+// texel's (roughness, NdotV) = (x / (res - 1), (y + 1) / res).  No step functions on this path (the max(., eps) floors are
+// continuous), so the result is a number, not an interval.  out_ab: rows * res pairs (A, B) of doubles.
+// The third party between the GPU kernel — whose sample step is algebraically rearranged (no normalize(L), 1 / max(ab, eps) as
+// a min of reciprocals, fused multiply-adds) — and the fp32 restatement of the shader's own order of operations.
+extern "C" int orc_brdf_lut_f64(uint32_t res, uint32_t y0, uint32_t rows, double* out_ab) {
+    if (!out_ab || res < 2 || y0 + rows > res) return PBR_ERR_INVALID;
+    const double TWO_PI_D = 2.0 * PI_D;   // the shader's literal PI (global.hlsli:4) doubled, as brdf.hlsli:83 does
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t yy = 0; yy < (int64_t)rows; yy++) {
+        const uint32_t y = y0 + (uint32_t)yy;
+        for (uint32_t x = 0; x < res; x++) {
+            const double roughness = (double)x / (double)(res - 1), NdotV = (double)(y + 1) / (double)res;
+            const D3 V = d3(std::sqrt(1.0 - NdotV * NdotV), 0.0, NdotV);
+            const double a = roughness * roughness, k = roughness * roughness / 2.0;
+            double A = 0.0, B = 0.0;
+            for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
+                uint32_t bits = i;
+                bits = (bits << 16u) | (bits >> 16u);
+                bits = ((bits & 0x55555555u) << 1u) | ((bits & 0xAAAAAAAAu) >> 1u);
+                bits = ((bits & 0x33333333u) << 2u) | ((bits & 0xCCCCCCCCu) >> 2u);
+                bits = ((bits & 0x0F0F0F0Fu) << 4u) | ((bits & 0xF0F0F0F0u) >> 4u);
+                bits = ((bits & 0x00FF00FFu) << 8u) | ((bits & 0xFF00FF00u) >> 8u);
+                const double xi_x = (double)i / (double)PBR_SAMPLE_COUNT, xi_y = (double)bits * 2.3283064365386963e-10;
+                const double phi = TWO_PI_D * xi_x;
+                const double cos_theta = std::sqrt((1.0 - xi_y) / (1.0 + (a * a - 1.0) * xi_y));
+                const double sin_theta = std::sqrt(std::max(1.0 - cos_theta * cos_theta, 0.0));
+                // N = (0,0,1): tangent frame of ggx_important_sample = (up x ... ) -> H = normalize(T hx + B hy + N hz) with
+                // up = (1,0,0) for |N.z| >= 0.999: T = normalize(N x up) = (0,1,0), B = N x T = (-1,0,0)
+                const D3 H = normalize(d3(-(sin_theta * std::sin(phi)), sin_theta * std::cos(phi), cos_theta));
+                const double VdH = dot(V, H);
+                const D3 L = normalize(H * (2.0 * VdH) - V);
+                const double NdotL = std::max(L.z, 0.0), NdotH = std::max(H.z, 0.0), VdotH = std::max(VdH, 0.0);
+                if (NdotL > 0.0) {
+                    const double Fc = std::pow(1.0 - VdotH, 5.0);
+                    const double gv = NdotV / std::max(NdotV * (1.0 - k) + k, EPS_D);
+                    const double gl = NdotL / std::max(NdotL * (1.0 - k) + k, EPS_D);
+                    const double G_Vis = (gv * gl * VdotH) / std::max(NdotH * NdotV, 0.0001);
+                    A += (1.0 - Fc) * G_Vis;
+                    B += Fc * G_Vis;
+                }
+            }
+            out_ab[2 * ((size_t)yy * res + x) + 0] = A / (double)PBR_SAMPLE_COUNT;
+            out_ab[2 * ((size_t)yy * res + x) + 1] = B / (double)PBR_SAMPLE_COUNT;
+        }
+    }
+    return PBR_OK;
+}
+

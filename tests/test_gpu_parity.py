@@ -78,6 +78,23 @@ def test_brdf_lut_whole_plane_vs_oracle(ctx, orc, golden2, res):
     print(f"LUT {res}^2: {(d == 0).mean() * 100:.2f} % of the plane bit-identical to the oracle, max 1 ULP")
 
 
+@pytest.mark.parametrize("res", [256, 512])
+def test_brdf_lut_against_the_double_precision_truth(ctx, orc, res):
+    """The LUT kernel's sample step is algebraically rearranged (no normalize(L), the floor of NdotH NdotV as a min of
+    reciprocals, fused multiply-adds, clamp modifiers): besides staying within 1 fp16 ULP of the fp32 restatement of the shader's
+    order of operations (above), it is checked against the estimator evaluated in DOUBLE (oracle/pbr_oracle_f64.cpp
+    orc_brdf_lut_f64) — per texel no further from the correctly rounded truth than the fp32 restatement is, plus one ULP.
+    (The fp32 shader arithmetic itself is up to 7 ULP off the truth in a handful of texels at NdotV <= 2 / res and roughness
+    < 0.06: sin(theta) = sqrt(1 - cos^2) of the GGX sample cancels there; the kernel builds its table with that same arithmetic.)"""
+    truth = orc.brdf_lut_f64(res).astype(np.float16)
+    want = orc.brdf_lut(res)
+    got = to_np_half(ctx.brdf_lut(res))
+    dg, do = common.half_ulp_diff(got, truth), common.half_ulp_diff(want, truth)
+    assert (dg <= do + 1).all(), f"LUT {res}: {(dg > do + 1).sum()} texels further from the f64 truth than the fp32 restatement + 1 ULP (worst {int((dg - do).max())})"
+    print(f"LUT {res}^2 vs round(f64): kernel {(dg == 0).mean() * 100:.3f} % exact, max {int(dg.max())} ULP, {(dg > 1).sum()} texels > 1 ULP | "
+          f"fp32 restatement {(do == 0).mean() * 100:.3f} % exact, max {int(do.max())} ULP, {(do > 1).sum()} texels > 1 ULP")
+
+
 def test_prefilter_env_512_and_sh9_vs_fixture(ctx, orc, golden2):
     """cfg3 at its stated size: 512^2 cube, 5 mips, 1024 spp + SH9.  The CPU cannot afford the whole chain (2.1e9
     sample steps), so 4096 seeded texels across the five mips are compared: fixture (generated in the build container)

@@ -6,6 +6,8 @@ import math
 import numpy as np
 import pytest
 
+import common
+
 from direct12pbrrenderer_amd import scene, synth
 from direct12pbrrenderer_amd.structs import CLUSTER_X, CLUSTER_Y, CLUSTER_Z, INV_LOG_LUMINANCE_RANGE, MIN_LOG_LUMINANCE
 
@@ -364,3 +366,20 @@ def test_f64_truth_brackets_the_fp32_restatement(orc, ibl):
     ab = np.linalg.lstsq(np.stack([F0 * L, np.full(3, L)], axis=1), spec, rcond=None)[0]   # the LUT pair this pixel sampled
     assert np.allclose(np.stack([F0 * L, np.full(3, L)], axis=1) @ ab, spec, rtol=0, atol=1e-12)
     assert 0.0 <= ab[0] <= 1.01 and 0.0 <= ab[1] <= 1.01
+
+
+def test_lut_f64_truth_and_the_fp32_restatement(orc):
+    """The split-sum LUT in double (pbr_oracle_f64.cpp) against the fp32 restatement of the shader's arithmetic: at 64^2 every
+    texel within 1 fp16 ULP of the correctly rounded truth and > 99.9 % equal to it; the analytic roughness-0 column
+    (A = 1 - (1 - NdotV)^5, B = (1 - NdotV)^5) reproduced by the double evaluation to 1e-9; and where the fp32 arithmetic is
+    ill-conditioned (rows NdotV <= 2 / res of a 256^2 plane at small roughness: sin(theta) of the GGX sample cancels) it leaves
+    the truth by a few ULP — the texels the GPU test allows for."""
+    truth = orc.brdf_lut_f64(64)
+    d = common.half_ulp_diff(orc.brdf_lut(64), truth.astype(np.float16))
+    assert d.max() <= 1 and (d == 0).mean() > 0.999
+    ndv = (np.arange(64) + 1) / 64
+    assert np.abs(truth[:, 0, 1] - (1 - ndv) ** 5).max() < 1e-9 and np.abs(truth[:, 0, 0] - (1 - (1 - ndv) ** 5)).max() < 1e-9
+    rows = orc.brdf_lut_f64(256, 0, 4)
+    d4 = common.half_ulp_diff(orc.brdf_lut_rows(256, 0, 4), rows.astype(np.float16))
+    assert 2 <= d4.max() <= 8 and (d4 > 1).sum() <= 12 and (d4[:, 32:] <= 1).all()
+
