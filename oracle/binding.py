@@ -279,6 +279,16 @@ def brdf_lut_f64(res, y0=0, rows=None):
     return out
 
 
+def prefilter_env_texels_f64(sky, sky_size, sky_mips, size, mips, mip, texels):
+    """env_map_gen.hlsl in double on the chosen texels of one mip (pbr_oracle_f64.cpp): (lo, hi) float64 [count, 3]."""
+    texels = np.ascontiguousarray(texels, dtype=np.uint32)
+    lo, hi = np.zeros((len(texels), 3), dtype=np.float64), np.zeros((len(texels), 3), dtype=np.float64)
+    L = lib()
+    L.orc_prefilter_env_texels_f64.argtypes = [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _vp, _vp]
+    _ok(L.orc_prefilter_env_texels_f64(_p(sky), sky_size, sky_mips, size, mips, mip, _p(texels), len(texels), _p(lo), _p(hi)), "prefilter_env_texels_f64")
+    return lo, hi
+
+
 def truth_distance(colour, lo, hi):
     """Per-pixel, per-channel distance of an fp32 colour [h,w,>=3] to the double-precision interval [lo, hi]."""
     c = colour[..., :3].astype(np.float64)

@@ -106,6 +106,11 @@ int orc_deferred_shade_f64(const pbr_global* g, const pbr_tile* tile, const pbr_
 /* The split-sum LUT (a3) in double precision: rows [y0, y0 + rows) of the res x res plane as (A, B) pairs of doubles — the
    value the estimator of precompute_brdf.hlsl:20-62 has in exact arithmetic (pbr_oracle_f64.cpp). */
 int orc_brdf_lut_f64(uint32_t res, uint32_t y0, uint32_t rows, double* out_ab);
+/* The GGX prefilter (a4) of chosen texels in double precision: per channel the interval [lo, hi] of the estimator's exact value
+   over the admissible sides of the path's step functions (x.8 snaps of LOD and filter coordinates, cube-face ties) — count x 3
+   doubles each (pbr_oracle_f64.cpp). */
+int orc_prefilter_env_texels_f64(const float* sky, uint32_t sky_size, uint32_t sky_mips, uint32_t size, uint32_t mips,
+                                 uint32_t mip, const uint32_t* texels, uint32_t count, double* out_lo, double* out_hi);
 int orc_skybox(const pbr_global* g, const pbr_tile* tile, const float* sky, uint32_t sky_size, uint32_t sky_mips,
                const uint8_t* stencil, uint32_t pitch, uint16_t* hdr, uint32_t hdr_pitch);                  /* 8f-1 */
 int orc_gbuffer_encode(const float* m0, const float* m1, const float* m2, uint32_t w, uint32_t h, uint32_t pitch,

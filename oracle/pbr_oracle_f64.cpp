@@ -65,8 +65,8 @@ static inline SnapSet snap_set(double c, int size) {
     return r;
 }
 
-struct Cube16 {
-    const uint16_t* data; uint32_t size;
+struct Cube16 {   // a cube chain of half4 texels (the prefiltered env) or, with `f32` set, of float4 texels (a source sky)
+    const uint16_t* data; uint32_t size; const float* f32 = nullptr;
     static size_t mip_offset(uint32_t size, uint32_t mip) {
         size_t off = 0;
         for (uint32_t m = 0; m < mip; m++) { size_t s = size >> m; off += 6 * s * s; }
@@ -74,7 +74,9 @@ struct Cube16 {
     }
     D3 texel(uint32_t mip, uint32_t face, int x, int y) const {
         const int s = (int)(size >> mip);
-        const uint16_t* p = data + 4 * (mip_offset(size, mip) + ((size_t)face * s + y) * s + x);
+        const size_t at = 4 * (mip_offset(size, mip) + ((size_t)face * s + y) * s + x);
+        if (f32) return d3((double)f32[at], (double)f32[at + 1], (double)f32[at + 2]);
+        const uint16_t* p = data + at;
         return d3(half_to_double(p[0]), half_to_double(p[1]), half_to_double(p[2]));
     }
 };
@@ -134,6 +136,31 @@ static void level_interval(const Cube16& c, uint32_t mip, uint32_t face, double 
             const D3 t = bilinear_at(c, mip, face, xs.x[i], ys.x[j]);
             if (first) { lo = hi = t; first = false; } else { lo = dmin(lo, t); hi = dmax(hi, t); }
         }
+}
+
+// [lo, hi] of the trilinear cube sample along R at the (already snapped) LOD: over the admissible faces (the major axis and any
+// axis within rounding of it) and the admissible x.8 snaps of the two levels' coordinates
+static void trilinear_interval(const Cube16& cube, uint32_t mips, D3 R, double lod_s, D3& out_lo, D3& out_hi) {
+    const uint32_t l0 = (uint32_t)std::floor(lod_s), l1 = l0 + 1 < mips ? l0 + 1 : mips - 1;
+    const double lf = lod_s - (double)l0;
+    const double ab[3] = {std::fabs(R.x), std::fabs(R.y), std::fabs(R.z)};
+    const int major = (ab[0] >= ab[1] && ab[0] >= ab[2]) ? 0 : (ab[1] >= ab[2] ? 1 : 2);
+    bool first = true;
+    for (int ax = 0; ax < 3; ax++) {
+        if (ax != major && ab[ax] < ab[major] * (1.0 - 1e-6)) continue;
+        uint32_t face; double cu, cv;
+        face_uv_axis(R, ax, face, cu, cv);
+        D3 lo0, hi0, lo, hi;
+        level_interval(cube, l0, face, cu, cv, lo0, hi0);
+        lo = lo0; hi = hi0;
+        if (lf != 0.0 && l1 != l0) {
+            D3 lo1, hi1;
+            level_interval(cube, l1, face, cu, cv, lo1, hi1);
+            lo = lo0 * (1.0 - lf) + lo1 * lf;
+            hi = hi0 * (1.0 - lf) + hi1 * lf;
+        }
+        if (first) { out_lo = lo; out_hi = hi; first = false; } else { out_lo = dmin(out_lo, lo); out_hi = dmax(out_hi, hi); }
+    }
 }
 
 }  // namespace
@@ -332,6 +359,83 @@ extern "C" int orc_brdf_lut_f64(uint32_t res, uint32_t y0, uint32_t rows, double
             out_ab[2 * ((size_t)yy * res + x) + 0] = A / (double)PBR_SAMPLE_COUNT;
             out_ab[2 * ((size_t)yy * res + x) + 1] = B / (double)PBR_SAMPLE_COUNT;
         }
+    }
+    return PBR_OK;
+}
+
+// ==================================================================== a4 in double: env_map_gen.hlsl:50-105
+// The GGX prefilter of chosen texels (index (face * s + y) * s + x of mip `mip`) in double precision: the estimator of
+// env_map_gen.hlsl::cs_main on the fp32 source chain — N = V = R = the texel-CORNER direction (Q8), the 1 024 GGX-importance
+// samples, N.L-weighted trilinear fetches at LOD = 0.5 log2(sample solid angle / texel solid angle) — with the path's step
+// functions treated as in the shade: where the LOD lies within 8e-6 of an x.8 step (the fp32 chain pdf -> log2 carries ~1e-6),
+// a filter coordinate within 16 ulps of a snap edge, or the direction within 1e-6 of a face edge (texel corners on cube edges
+// are EXACT ties), every admissible side is evaluated and the result is an interval [lo, hi] per channel (radiance and the
+// weights are >= 0: interval arithmetic is exact).  out_lo / out_hi: count x 3 doubles.
+extern "C" int orc_prefilter_env_texels_f64(const float* sky, uint32_t sky_size, uint32_t sky_mips, uint32_t size, uint32_t mips,
+                                            uint32_t mip, const uint32_t* texels, uint32_t count, double* out_lo, double* out_hi) {
+    if (!sky || !out_lo || !out_hi || !texels || mips < 1 || mip >= mips || (size >> mip) == 0 || sky_mips < 1) return PBR_ERR_INVALID;
+    Cube16 cube{nullptr, sky_size, sky};
+    const uint32_t s = size >> mip;
+    const double roughness = mips > 1 ? (double)mip / (double)(mips - 1) : 0.0;   // DeferredPipeline.cpp:99
+    for (uint32_t k = 0; k < count; k++)
+        if (texels[k] >= 6u * s * s) return PBR_ERR_INVALID;
+    const double TWO_PI_D = 2.0 * PI_D, maxl = (double)(sky_mips - 1);
+    const double texel_sa = 4.0 * PI_D / (double)(6u * size * size);   // base size for every mip (Q8)
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t k = 0; k < (int64_t)count; k++) {
+        const uint32_t t = texels[k], face = t / (s * s), y = (t / s) % s, x = t % s;
+        const double u = (double)x / (double)s, v = (double)y / (double)s;
+        const D3 N = normalize(cube_dir_raw(face, 2.0 * u - 1.0, 2.0 * v - 1.0));
+        const D3 up = std::fabs(N.z) < 0.999 ? d3(0, 0, 1) : d3(1, 0, 0);
+        const D3 cr = d3(N.y * up.z - N.z * up.y, N.z * up.x - N.x * up.z, N.x * up.y - N.y * up.x);
+        const D3 T = normalize(cr);
+        const D3 Bt = d3(N.y * T.z - N.z * T.y, N.z * T.x - N.x * T.z, N.x * T.y - N.y * T.x);
+        const double a = roughness * roughness, a4 = a * a;
+        D3 sum_lo = d3(0, 0, 0), sum_hi = d3(0, 0, 0);
+        double total_w = 0.0;
+        for (uint32_t i = 0; i < PBR_SAMPLE_COUNT; i++) {
+            uint32_t bits = i;
+            bits = (bits << 16u) | (bits >> 16u);
+            bits = ((bits & 0x55555555u) << 1u) | ((bits & 0xAAAAAAAAu) >> 1u);
+            bits = ((bits & 0x33333333u) << 2u) | ((bits & 0xCCCCCCCCu) >> 2u);
+            bits = ((bits & 0x0F0F0F0Fu) << 4u) | ((bits & 0xF0F0F0F0u) >> 4u);
+            bits = ((bits & 0x00FF00FFu) << 8u) | ((bits & 0xFF00FF00u) >> 8u);
+            const double xi_x = (double)i / (double)PBR_SAMPLE_COUNT, xi_y = (double)bits * 2.3283064365386963e-10;
+            const double phi = TWO_PI_D * xi_x;
+            const double cos_theta = std::sqrt((1.0 - xi_y) / (1.0 + (a4 - 1.0) * xi_y));
+            const double sin_theta = std::sqrt(std::max(1.0 - cos_theta * cos_theta, 0.0));
+            const double hx = sin_theta * std::cos(phi), hy = sin_theta * std::sin(phi), hz = cos_theta;
+            const D3 H = normalize(T * hx + Bt * hy + N * hz);
+            const double VdH = dot(N, H);   // V = N
+            const D3 L = normalize(H * (2.0 * VdH) - N);
+            const double NdotL = std::max(dot(N, L), 0.0);
+            if (!(NdotL > 0.0)) continue;
+            const double NdotH = std::max(VdH, 0.0), HdotV = NdotH;
+            const double tt = NdotH * NdotH * (a4 - 1.0) + 1.0;
+            const double D = a4 / std::max(PI_D * tt * tt, EPS_D);
+            const double pdf = D * NdotH / (4.0 * HdotV + 0.0001);
+            const double sample_sa = 1.0 / ((double)PBR_SAMPLE_COUNT * pdf + 0.0001);
+            double lod = roughness == 0.0 ? 0.0 : 0.5 * std::log2(sample_sa / texel_sa);
+            if (!(lod == lod)) lod = 0.0;
+            lod = lod < 0.0 ? 0.0 : (lod > maxl ? maxl : lod);
+            // x.8 snap of the LOD: the exact one and, within 8e-6 of a step, its neighbour
+            const double sl = lod * 256.0 + 0.5, fl = std::floor(sl);
+            double cand[2] = {fl / 256.0, 0.0};
+            int nc = 1;
+            if (sl - fl < 2e-3 && fl >= 1.0) cand[nc++] = (fl - 1.0) / 256.0;
+            else if (fl + 1.0 - sl < 2e-3 && (fl + 1.0) / 256.0 <= maxl) cand[nc++] = (fl + 1.0) / 256.0;
+            D3 lo{}, hi{};
+            for (int c = 0; c < nc; c++) {
+                D3 l{}, h{};
+                trilinear_interval(cube, sky_mips, L, cand[c], l, h);
+                if (c == 0) { lo = l; hi = h; } else { lo = dmin(lo, l); hi = dmax(hi, h); }
+            }
+            sum_lo = sum_lo + lo * NdotL; sum_hi = sum_hi + hi * NdotL;
+            total_w += NdotL;
+        }
+        const D3 rl = sum_lo * (1.0 / total_w), rh = sum_hi * (1.0 / total_w);
+        out_lo[3 * k] = rl.x; out_lo[3 * k + 1] = rl.y; out_lo[3 * k + 2] = rl.z;
+        out_hi[3 * k] = rh.x; out_hi[3 * k + 1] = rh.y; out_hi[3 * k + 2] = rh.z;
     }
     return PBR_OK;
 }

@@ -473,6 +473,34 @@ def test_prefilter_env_on_a_half_representable_source_takes_the_half_copy_and_st
         assert (d > 0).mean() < 0.25, (name, size, float((d > 0).mean()))
 
 
+def test_prefilter_env_against_the_double_precision_truth(ctx, orc, golden2):
+    """cfg3's 512^2 x 5-mip chain, the 4 096 seeded texels of the fixture: the kernel (v_cube* + v_rcp face coordinates, weight-form
+    trilinear sums, the half-precision copy when it is exact) and the fp32 restatement of the shader's arithmetic, each against
+    env_map_gen.hlsl evaluated in DOUBLE (oracle/pbr_oracle_f64.cpp orc_prefilter_env_texels_f64: an interval per channel over the
+    admissible sides of the x.8 snaps and cube-face ties).  Per texel and channel the kernel's fp16 result lies no further from the
+    interval than the restatement's does, plus half an fp16 ULP (one result rounding) and a hundredth for the fp32 sums."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_v2 as mk
+    sky = mk.bench_sky()
+    for name, chain in (("fp32 source", sky), ("half-representable source", sky.astype(np.float16).astype(np.float32))):
+        got = to_np_half(ctx.prefilter_env(ctx.upload(chain), mk.ENV_SIZE, mk.SKY_MIPS, mk.ENV_SIZE, mk.ENV_MIPS))
+        worst, inside_g, inside_o, n = 0.0, 0, 0, 0
+        for m in range(mk.ENV_MIPS):
+            idx = golden2[f"env512_m{m}_idx"][::2]
+            lo, hi = orc.prefilter_env_texels_f64(chain, mk.ENV_SIZE, mk.SKY_MIPS, mk.ENV_SIZE, mk.ENV_MIPS, m, idx)
+            want = orc.prefilter_env_texels(chain, mk.ENV_SIZE, mk.SKY_MIPS, mk.ENV_SIZE, mk.ENV_MIPS, m, idx)[:, :3].astype(np.float64)
+            sub = got[cube_mip_offset(mk.ENV_SIZE, m) + idx.astype(np.int64)][:, :3].astype(np.float64)
+            ulp = np.spacing(np.maximum(np.abs(hi), 6.2e-5).astype(np.float16)).astype(np.float64)
+            dg = np.maximum(np.maximum(lo - sub, sub - hi), 0.0) / ulp
+            do = np.maximum(np.maximum(lo - want, want - hi), 0.0) / ulp
+            assert (dg <= do + 0.51).all(), f"{name}, mip {m}: {(dg > do + 0.51).sum()} values further from the f64 interval than the fp32 restatement + 0.51 ULP (worst {float((dg - do).max()):.2f})"
+            worst = max(worst, float(dg.max()))
+            inside_g += int((dg <= 0.5).sum()); inside_o += int((do <= 0.5).sum()); n += dg.size
+        print(f"prefilter 512^2 x 5 vs f64, {name}: kernel within half an fp16 ULP of the interval on {inside_g / n * 100:.2f} % of {n} values "
+              f"(fp32 restatement {inside_o / n * 100:.2f} %), worst {worst:.2f} ULP")
+
+
 def test_prefilter_env_source_levels_above_1670_texels(ctx, orc):
     """k_prefilter_foot forms texel indices in fp32 (exact below 2^24) for source levels up to 1 670 texels and with integer
     multiply-adds above.  A 2 048^2 source filtered into a 32^2 chain puts most samples on source levels 0 (2 048: the integer

@@ -383,3 +383,28 @@ def test_lut_f64_truth_and_the_fp32_restatement(orc):
     d4 = common.half_ulp_diff(orc.brdf_lut_rows(256, 0, 4), rows.astype(np.float16))
     assert 2 <= d4.max() <= 8 and (d4 > 1).sum() <= 12 and (d4[:, 32:] <= 1).all()
 
+
+def test_prefilter_f64_truth_and_the_fp32_restatement(orc):
+    """env_map_gen.hlsl in double (an interval per channel over the admissible snaps and face ties) against the fp32 restatement on
+    a 64^2 sky: every fp16 result within half an fp16 ULP (+ 1 %) of the interval — the restatement IS the correctly rounded value
+    up to the step functions' latitude; a constant cube filters to the constant exactly; and mip 0 (roughness 0: one bilinear fetch
+    at the texel corner) has a zero-width interval equal to the fetch."""
+    S, M = 64, 7
+    sky = synth.env_cube(S, M)
+    orc.cube_gen_mips(sky, S, M)
+    rng = np.random.default_rng(7)
+    for mip in range(5):
+        n = 6 * (S >> mip) ** 2
+        idx = np.sort(rng.choice(n, size=min(64, n), replace=False)).astype(np.uint32)
+        lo, hi = orc.prefilter_env_texels_f64(sky, S, M, S, 5, mip, idx)
+        want = orc.prefilter_env_texels(sky, S, M, S, 5, mip, idx)[:, :3].astype(np.float64)
+        ulp = np.spacing(np.maximum(np.abs(hi), 6.2e-5).astype(np.float16)).astype(np.float64)
+        d = np.maximum(np.maximum(lo - want, want - hi), 0.0) / ulp
+        assert (lo <= hi).all() and d.max() <= 0.505, (mip, float(d.max()))
+        if mip == 0:
+            assert np.array_equal(lo, hi)
+    const = np.zeros_like(sky)
+    const.reshape(-1, 4)[:] = (0.25, 0.5, 2.0, 1.0)
+    lo, hi = orc.prefilter_env_texels_f64(const, S, M, S, 5, 3, np.arange(0, 384, 7, dtype=np.uint32))
+    assert np.abs(lo - np.array([0.25, 0.5, 2.0])).max() < 1e-12 and np.abs(hi - np.array([0.25, 0.5, 2.0])).max() < 1e-12
+
