@@ -2,6 +2,7 @@
 #include "pbr_internal.hpp"
 #include "pbr_device.hpp"
 #include <dlfcn.h>
+#include <rccl/rccl.h>   // declarations only: the library is bound with dlopen (section "RCCL")
 #include <link.h>
 #include <unistd.h>
 #include <cstring>
@@ -85,17 +86,13 @@ pbr_status pbr_ctx_create(int hip_device, pbr_ctx** out) {
     return PBR_OK;
 }
 
-typedef int (*nccl_destroy_fn)(void*);
+static void comm_teardown(pbr_ctx* ctx);
 
 void pbr_ctx_destroy(pbr_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->rccl_lib) {
-        nccl_destroy_fn d = (nccl_destroy_fn)dlsym(ctx->rccl_lib, "ncclCommDestroy");
-        if (d && ctx->comm_hist) d(ctx->comm_hist);
-        if (d && ctx->comm) d(ctx->comm);
-    }
+    comm_teardown(ctx);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->ev_side_fork) (void)hipEventDestroy(ctx->ev_side_fork);
     if (ctx->ev_side_join) (void)hipEventDestroy(ctx->ev_side_join);
@@ -133,17 +130,14 @@ pbr_status pbr_sync(pbr_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------------------------- RCCL
-// ncclUniqueId is 128 opaque bytes passed BY VALUE to ncclCommInitRank (rccl.h).
-struct nccl_uid { char internal[128]; };
-typedef int (*nccl_get_uid_fn)(nccl_uid*);
-typedef int (*nccl_init_rank_fn)(void**, int, nccl_uid, int);
-typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef int (*nccl_split_fn)(void*, int, int, void**, void*);   // ncclCommSplit(comm, color, key, &newcomm, config)
-enum { NCCL_UINT32 = 3, NCCL_SUM = 0 };
+// Types, enum values and signatures come from <rccl/rccl.h> (included at the top of this file); the library itself is still
+// bound with dlopen so that a one-GPU process never needs librccl.  Every dlsym'd pointer is typed with decltype(&ncclXxx):
+// a signature drift between the header and this file fails the build instead of the first 8-GPU run.
+static_assert(sizeof(ncclUniqueId) == 128 && NCCL_UNIQUE_ID_BYTES == 128, "pbr_comm_unique_id / pbr_comm_init hand the id over as 128 opaque bytes (pbr_hip.h)");
+static_assert(ncclInt8 == 0 && ncclUint32 == 3 && ncclSum == 0 && ncclSuccess == 0, "RCCL enum values this file was written against");
+static_assert(sizeof(ncclComm_t) == sizeof(void*), "pbr_ctx keeps the communicators as opaque pointers");
 
-typedef int (*nccl_p2p_fn)(void*, size_t, int, int, void*, hipStream_t);   // ncclSend / ncclRecv (buffer, count, type, peer, comm, stream)
-typedef int (*nccl_group_fn)(void);
-enum { NCCL_INT8 = 0 };
+#define RCCL_FN(lib, name) ((lib) ? reinterpret_cast<decltype(&name)>(dlsym((lib), #name)) : nullptr)
 
 static void* open_rccl() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
@@ -163,12 +157,26 @@ pbr_status pbr_comm_unique_id(void* out_128_bytes) {
     if (!out_128_bytes) return PBR_ERR_INVALID;
     void* lib = open_rccl();
     if (!lib) return PBR_ERR_COMM;
-    nccl_get_uid_fn f = (nccl_get_uid_fn)dlsym(lib, "ncclGetUniqueId");
+    auto f = RCCL_FN(lib, ncclGetUniqueId);
     if (!f) return PBR_ERR_COMM;
-    nccl_uid id;
-    if (f(&id) != 0) return PBR_ERR_COMM;
+    ncclUniqueId id;
+    if (f(&id) != ncclSuccess) return PBR_ERR_COMM;
     std::memcpy(out_128_bytes, &id, sizeof(id));
     return PBR_OK;
+}
+
+static void comm_reset(pbr_ctx* ctx) { ctx->comm = ctx->comm_hist = nullptr; }
+
+// Destroys whatever communicators the context holds.  world / rank keep what the caller asked for: after a failed
+// pbr_comm_init(world > 1) BOTH collectives refuse ("no communicator") — a context is never half in multi-GPU mode
+// (one collective working beside one refusing), and never silently single-GPU when the caller asked for more.
+static void comm_teardown(pbr_ctx* ctx) {
+    if (ctx->rccl_lib) {
+        auto d = RCCL_FN(ctx->rccl_lib, ncclCommDestroy);
+        if (d && ctx->comm_hist) (void)d((ncclComm_t)ctx->comm_hist);
+        if (d && ctx->comm) (void)d((ncclComm_t)ctx->comm);
+    }
+    comm_reset(ctx);
 }
 
 pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_id_128_bytes) {
@@ -183,20 +191,25 @@ pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_i
     PBR_REQUIRE(ctx, ctx->comm == nullptr, "pbr_comm_init: the context already has a communicator");
     if (!ctx->rccl_lib) ctx->rccl_lib = open_rccl();
     if (!ctx->rccl_lib) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_comm_init: librccl not found");
-    nccl_init_rank_fn f = (nccl_init_rank_fn)dlsym(ctx->rccl_lib, "ncclCommInitRank");
+    auto f = RCCL_FN(ctx->rccl_lib, ncclCommInitRank);
     if (!f) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_comm_init: ncclCommInitRank missing");
-    nccl_uid id;
+    ncclUniqueId id;
     std::memcpy(&id, unique_id_128_bytes, sizeof(id));
     PBR_HIP(ctx, hipSetDevice(ctx->device));
-    int r = f(&ctx->comm, world, id, rank);
-    if (r != 0) { ctx->comm = nullptr; return pbr::fail(ctx, PBR_ERR_COMM, "ncclCommInitRank failed"); }
+    ncclComm_t comm = nullptr, comm_hist = nullptr;
+    ncclResult_t r = f(&comm, world, id, rank);
+    if (r != ncclSuccess || !comm) { comm_reset(ctx); return pbr::fail(ctx, PBR_ERR_COMM, "ncclCommInitRank failed"); }
+    ctx->comm = comm;
     // A second communicator over the same ranks for the histogram all-reduce: the halo exchange (frame stream) and the
     // all-reduce (side stream when the frame's tail is overlapped) may then be in flight at the same time without
     // relying on every rank enqueueing them in the same host order — RCCL orders operations per communicator.
-    nccl_split_fn split = (nccl_split_fn)dlsym(ctx->rccl_lib, "ncclCommSplit");
-    if (!split) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_comm_init: ncclCommSplit missing (RCCL too old)");
-    r = split(ctx->comm, 0, rank, &ctx->comm_hist, nullptr);
-    if (r != 0 || !ctx->comm_hist) { ctx->comm_hist = nullptr; return pbr::fail(ctx, PBR_ERR_COMM, "ncclCommSplit failed"); }
+    // If it cannot be made the frame communicator goes as well (no half-initialised state: a halo exchange that works
+    // beside an all-reduce that refuses would hang the other ranks at their first average).
+    auto split = RCCL_FN(ctx->rccl_lib, ncclCommSplit);
+    if (!split) { comm_teardown(ctx); return pbr::fail(ctx, PBR_ERR_COMM, "pbr_comm_init: ncclCommSplit missing (RCCL too old)"); }
+    r = split(comm, 0, rank, &comm_hist, nullptr);
+    if (r != ncclSuccess || !comm_hist) { comm_teardown(ctx); return pbr::fail(ctx, PBR_ERR_COMM, "ncclCommSplit failed"); }
+    ctx->comm_hist = comm_hist;
     return PBR_OK;
 }
 
@@ -205,10 +218,10 @@ pbr_status pbr_allreduce_hist(pbr_ctx* ctx, uint32_t* hist256) {
     PBR_REQUIRE(ctx, hist256 != nullptr, "pbr_allreduce_hist: null histogram");
     if (ctx->world <= 1 && !ctx->comm_hist) return PBR_OK;   // single GPU: the local histogram is the global one
     if (!ctx->comm_hist) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_allreduce_hist: world > 1 but no communicator");
-    nccl_allreduce_fn f = (nccl_allreduce_fn)dlsym(ctx->rccl_lib, "ncclAllReduce");
+    auto f = RCCL_FN(ctx->rccl_lib, ncclAllReduce);
     if (!f) return pbr::fail(ctx, PBR_ERR_COMM, "ncclAllReduce missing");
-    int r = f(hist256, hist256, PBR_HISTOGRAM_BINS, NCCL_UINT32, NCCL_SUM, ctx->comm_hist, ctx->stream);
-    if (r != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclAllReduce failed");
+    const ncclResult_t r = f(hist256, hist256, PBR_HISTOGRAM_BINS, ncclUint32, ncclSum, (ncclComm_t)ctx->comm_hist, ctx->stream);
+    if (r != ncclSuccess) return pbr::fail(ctx, PBR_ERR_COMM, "ncclAllReduce failed");
     return PBR_OK;
 }
 
@@ -308,10 +321,10 @@ static pbr_status halo_exchange_on(pbr_ctx* ctx, hipStream_t stream, pbr_half* p
         }
     }
     if (!ctx->comm) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_halo_exchange: no communicator (pbr_comm_init)");
-    nccl_p2p_fn f_send = (nccl_p2p_fn)dlsym(ctx->rccl_lib, "ncclSend");
-    nccl_p2p_fn f_recv = (nccl_p2p_fn)dlsym(ctx->rccl_lib, "ncclRecv");
-    nccl_group_fn f_gs = (nccl_group_fn)dlsym(ctx->rccl_lib, "ncclGroupStart");
-    nccl_group_fn f_ge = (nccl_group_fn)dlsym(ctx->rccl_lib, "ncclGroupEnd");
+    auto f_send = RCCL_FN(ctx->rccl_lib, ncclSend);
+    auto f_recv = RCCL_FN(ctx->rccl_lib, ncclRecv);
+    auto f_gs = RCCL_FN(ctx->rccl_lib, ncclGroupStart);
+    auto f_ge = RCCL_FN(ctx->rccl_lib, ncclGroupEnd);
     if (!f_send || !f_recv || !f_gs || !f_ge) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_halo_exchange: ncclSend/ncclRecv/ncclGroup* missing");
     uint2* st = (uint2*)staging;
     if (snd.n) {
@@ -320,12 +333,12 @@ static pbr_status halo_exchange_on(pbr_ctx* ctx, hipStream_t stream, pbr_half* p
         pbr_status r = pbr::launched(ctx, "k_halo_copy<pack>");
         if (r) return r;
     }
-    if (f_gs() != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclGroupStart failed");
-    int rc = 0;
-    for (int k = 0; k < snd.n && rc == 0; k++) rc = f_send(st + snd.off[k], (size_t)snd.w[k] * snd.h[k] * 8, NCCL_INT8, peer_of_s[k], ctx->comm, stream);
-    for (int k = 0; k < rcv.n && rc == 0; k++) rc = f_recv(st + rcv.off[k], (size_t)rcv.w[k] * rcv.h[k] * 8, NCCL_INT8, peer_of_r[k], ctx->comm, stream);
-    const int ge = f_ge();
-    if (rc != 0 || ge != 0) return pbr::fail(ctx, PBR_ERR_COMM, "ncclSend/ncclRecv group failed");
+    if (f_gs() != ncclSuccess) return pbr::fail(ctx, PBR_ERR_COMM, "ncclGroupStart failed");
+    ncclResult_t rc = ncclSuccess;
+    for (int k = 0; k < snd.n && rc == ncclSuccess; k++) rc = f_send(st + snd.off[k], (size_t)snd.w[k] * snd.h[k] * 8, ncclInt8, peer_of_s[k], (ncclComm_t)ctx->comm, stream);
+    for (int k = 0; k < rcv.n && rc == ncclSuccess; k++) rc = f_recv(st + rcv.off[k], (size_t)rcv.w[k] * rcv.h[k] * 8, ncclInt8, peer_of_r[k], (ncclComm_t)ctx->comm, stream);
+    const ncclResult_t ge = f_ge();
+    if (rc != ncclSuccess || ge != ncclSuccess) return pbr::fail(ctx, PBR_ERR_COMM, "ncclSend/ncclRecv group failed");
     if (rcv.n) {
         const int bx = (max_r + 255) / 256 > 256 ? 256 : (max_r + 255) / 256;
         hipLaunchKernelGGL(k_halo_copy<false>, dim3(bx, rcv.n), dim3(256), 0, stream, (uint2*)plane, (int)pitch, st, rcv);

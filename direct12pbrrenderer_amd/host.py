@@ -21,6 +21,9 @@ SIGNATURES = {
     "pbrh_set_skybox": (_int, [_vp, _vp, _u32]),
     "pbrh_load_skybox": (_int, [_vp, C.c_char_p]),
     "pbrh_set_lights": (_int, [_vp, _vp, _int]),
+    "pbrh_load_scene_lights": (_int, [_vp, C.c_char_p]),
+    "pbrh_parse_scene_lights": (_int, [C.c_char_p, C.c_size_t, _vp, _int, C.c_char_p, C.c_size_t]),
+    "pbrh_light_buffer": (_int, [_u32, _u32, _vp, _vp, _int, _vp, _int]),
     "pbrh_set_gbuffer": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "pbrh_set_materials": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "pbrh_set_initial_luminance": (_int, [_vp, C.c_float]),
@@ -109,6 +112,10 @@ class HostRenderer:
     def set_lights(self, lights):
         p = pack_lights(lights)
         self._check(self.lib.pbrh_set_lights(self.h, p.ctypes.data, len(p)))
+
+    def load_scene_lights(self, path):
+        """the mSceneLight records of a reference scene file (Asset/Scene/main.json) become the renderer's lights"""
+        self._check(self.lib.pbrh_load_scene_lights(self.h, os.fsencode(path)))
 
     def set_gbuffer(self, gb):
         planes = [np.ascontiguousarray(gb[k]) for k in ("A", "B", "C", "depth", "stencil")]

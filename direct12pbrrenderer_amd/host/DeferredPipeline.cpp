@@ -176,15 +176,8 @@ void ClusteredPass::Execute(FGContext* context) {   // DeferredPipeline.cpp:208-
     if (context->Scene->GetLightCount() > (uint32)MaxSceneLights) throw HipException("ClusteredPass: more than MaxSceneLights lights");
     std::vector<pbr_light>& lights = mLights;
     lights.assign(MaxSceneLights, pbr_light{});
-    int i = 0;
     // frustum culling point lights (DeferredPipeline.cpp:224-241): membership and buffer order come from the octree walk
-    const Matrix4x4 view_projection = context->Camera->GetProjectionMatrix() * context->Camera->GetLocalSpaceMatrix();
-    const FrustumVolume volume = FrustumVolume::FromMatrix(view_projection.m);
-    context->Scene->CullLight(volume, [&](SceneLight* light) {
-        const Vector3 p = light->GetTranslation(), c = light->GetColor();
-        const PointLightAttenuation& a = light->GetAttenuationCoefficients();
-        lights[i++] = pbr_light{{p.x, p.y, p.z}, {c.x, c.y, c.z}, light->GetIntensity(), a.Radius, a.ConstantCoefficent, a.LinearCoefficent, a.QuadraticCoefficent};
-    });
+    const int i = FillLightBuffer(context->Scene, context->Camera, lights.data(), MaxSceneLights);
     mClusteredCompute.SetConstantBuffer(ClusteredShaderConstant{i});
     mClusteredCulling.SetConstantBuffer(ClusteredShaderConstant{i});
     // the reference re-uploads the buffer every frame through its upload ring; here the device copy is rewritten only when

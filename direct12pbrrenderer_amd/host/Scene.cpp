@@ -93,6 +93,19 @@ PointLightAttenuation SceneLight::CaclAttenuationCoefficients(float radius) {
     return presets[n - 1];
 }
 
+int FillLightBuffer(Scene* scene, const Camera* camera, pbr_light* out, int capacity) {
+    const Matrix4x4 view_projection = camera->GetProjectionMatrix() * camera->GetLocalSpaceMatrix();
+    const FrustumVolume volume = FrustumVolume::FromMatrix(view_projection.m);
+    int i = 0;
+    scene->CullLight(volume, [&](SceneLight* light) {
+        if (i >= capacity) throw HipException("light buffer: more lights pass the frustum cull than the buffer holds");
+        const Vector3 p = light->GetTranslation(), c = light->GetColor();
+        const PointLightAttenuation& a = light->GetAttenuationCoefficients();
+        out[i++] = pbr_light{{p.x, p.y, p.z}, {c.x, c.y, c.z}, light->GetIntensity(), a.Radius, a.ConstantCoefficent, a.LinearCoefficent, a.QuadraticCoefficent};
+    });
+    return i;
+}
+
 RenderScheduler::RenderScheduler(IRenderPipeline* pipeline, int hip_device, uint32 width, uint32 height) : mWidth(width), mHeight(height) {
     mCommandList = std::make_unique<HipCommandList>(hip_device);
     mFrameGraph = std::make_unique<FrameGraph>(pipeline);

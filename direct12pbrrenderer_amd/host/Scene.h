@@ -70,14 +70,19 @@ public:
     // at ~1.81418 * radius the preset attenuation falls below 1/256 (Scene.h:118); Scene.cpp:122-130
     static constexpr float CullingRadiusCoefficient = 1.81418f;
     AABB GetWorldBound() const {
+        if (mHasBoundOverride) return mBoundOverride;
         const float r = mRadius * CullingRadiusCoefficient * std::sqrt(mIntensity);
         return AABB{{mTranslation.x - r, mTranslation.y - r, mTranslation.z - r}, {mTranslation.x + r, mTranslation.y + r, mTranslation.z + r}};
     }
+    // a scene object with a rotation or a non-unit scale moves its bound with its matrix (Scene.h:31; SceneFile.cpp)
+    void SetWorldBound(const AABB& b) { mBoundOverride = b; mHasBoundOverride = true; }
     static PointLightAttenuation CaclAttenuationCoefficients(float radius);   // Scene.cpp:132-165 (step function, quirk Q18)
 protected:
     Vector3 mTranslation, mColor;
     float mRadius, mIntensity;
     PointLightAttenuation mAttenuation;
+    AABB mBoundOverride{};
+    bool mHasBoundOverride = false;
 };
 
 // CubeMapResource stand-in: fp32 RGBA cube with mips + the SH pack computed at import time
@@ -129,6 +134,11 @@ private:
     std::shared_ptr<SkyBox> mSkyBox;
     GBufferSource mGBuffer;
 };
+
+// The PointLight[] ClusteredPass::Execute commits (DeferredPipeline.cpp:224-241): the lights Scene::CullLight hands out for
+// the camera's frustum, in octree order, as {Position, Color, Intensity, Attenuation}.  Returns the count; throws when it
+// exceeds `capacity` (the reference ASSERTs GetLightCount() <= MaxSceneLights).
+int FillLightBuffer(Scene* scene, const Camera* camera, pbr_light* out, int capacity);
 
 class FrameGraph;
 class IRenderPipeline;

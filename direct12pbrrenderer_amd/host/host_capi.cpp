@@ -1,6 +1,7 @@
 // host_capi.cpp — C embedding of the pass graph (see pbr_host.h).
 #include "pbr_host.h"
 #include "HdrImage.h"
+#include "SceneFile.h"
 
 #include <chrono>
 #include <cstdio>
@@ -156,6 +157,35 @@ int pbrh_set_lights(pbrh_renderer* r, const float* l, int n) {
         r->scene->ClearLights();
         for (int i = 0; i < n; i++, l += 8) r->scene->AddLight(SceneLight(Vector3{l[0], l[1], l[2]}, Vector3{l[3], l[4], l[5]}, l[6], l[7]));
     });
+}
+
+// Scene::PostDeserialized for the light list of a reference scene file (Asset/Scene/main.json): SceneFile.h
+int pbrh_load_scene_lights(pbrh_renderer* r, const char* scene_json_path) {
+    return guarded(r, [&] { AddSceneLights(r->scene.get(), LoadSceneLights(scene_json_path)); });
+}
+
+// CPU only: the "mSceneLight" records of a scene file held in memory, as the 8-float records pbrh_set_lights takes
+// (translation, colour, radius, intensity), in file order.  Returns the count (may exceed max_lights), -1 + reason on
+// malformed input or on a light whose object carries a rotation / scale (those go through pbrh_load_scene_lights).
+int pbrh_parse_scene_lights(const char* json, size_t bytes, float* lights, int max_lights, char* err, size_t err_len) {
+    try {
+        const std::vector<SceneLightRecord> recs = ParseSceneLights(json, bytes);
+        for (size_t i = 0; i < recs.size(); i++) {
+            const SceneLightRecord& q = recs[i];
+            if (q.Rotation.x != 0 || q.Rotation.y != 0 || q.Rotation.z != 0 || q.Scale.x != 1 || q.Scale.y != 1 || q.Scale.z != 1)
+                throw HipException("scene json: a light object with a rotation or scale has no 8-float record");
+            if ((int)i < max_lights && lights) {
+                float* o = lights + 8 * i;
+                o[0] = q.Translation.x; o[1] = q.Translation.y; o[2] = q.Translation.z;
+                o[3] = q.Color.x; o[4] = q.Color.y; o[5] = q.Color.z;
+                o[6] = q.Radius; o[7] = q.Intensity;
+            }
+        }
+        return (int)recs.size();
+    } catch (const std::exception& e) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", e.what());
+        return -1;
+    }
 }
 
 int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, const uint32_t* C, const float* depth, const uint8_t* stencil) {
@@ -350,6 +380,21 @@ int pbrh_cull_lights(uint32_t width, uint32_t height, const float cam_pos_yaw[4]
             count++;
         });
         return count;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+// CPU only: the PointLight[] records (44 bytes each, pbr_light) ClusteredPass::Execute would commit for these lights and this
+// camera — Scene::CullLight's membership and order, SceneLight::CaclAttenuationCoefficients' preset.  Returns the count, -1 on error.
+int pbrh_light_buffer(uint32_t width, uint32_t height, const float cam_pos_yaw[4], const float* l, int n, void* out_pbr_lights, int capacity) {
+    try {
+        Camera camera(0.333f * 3.14159265359f, width, height, 0.1f, 1000.0f);
+        camera.Move(Vector3{cam_pos_yaw[0], cam_pos_yaw[1], cam_pos_yaw[2]});
+        camera.Rotate(0, cam_pos_yaw[3], 0);
+        Scene scene;
+        for (int i = 0; i < n; i++, l += 8) scene.AddLight(SceneLight(Vector3{l[0], l[1], l[2]}, Vector3{l[3], l[4], l[5]}, l[6], l[7]));
+        return FillLightBuffer(&scene, &camera, (pbr_light*)out_pbr_lights, capacity);
     } catch (const std::exception&) {
         return -1;
     }

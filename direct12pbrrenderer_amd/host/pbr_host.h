@@ -47,6 +47,12 @@ int pbrh_load_skybox(pbrh_renderer* r, const char* dir);
 int pbrh_parse_hdr(const uint8_t* file, size_t bytes, uint32_t* w, uint32_t* h, uint8_t* rgbe, size_t rgbe_bytes, char* err, size_t err_len);
 /* n lights: position[3], color[3], radius, intensity (8 floats each) */
 int pbrh_set_lights(pbrh_renderer* r, const float* lights, int n);
+/* the "mSceneLight" records of a reference scene file (Asset/Scene/main.json: Scene.h:192, ReflectionDef.h:119-149) replace
+ * the renderer's lights, in file order (Scene::PostDeserialized, Scene.cpp:83-99) */
+int pbrh_load_scene_lights(pbrh_renderer* r, const char* scene_json_path);
+/* CPU only: the same records of a scene file held in memory as 8-float records (as pbrh_set_lights takes them); returns the
+ * count (may exceed max_lights), -1 + reason in err on malformed input */
+int pbrh_parse_scene_lights(const char* json, size_t bytes, float* lights, int max_lights, char* err, size_t err_len);
 int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, const uint32_t* C, const float* depth, const uint8_t* stencil);
 /* alternative to pbrh_set_gbuffer: the rasterizer's per-pixel material attributes (three float4 planes, see
  * pbr_gbuffer_encode in pbr_hip.h); GBufferPass encodes them on the GPU */
@@ -87,6 +93,9 @@ int pbrh_get_global(const pbrh_renderer* r, void* dst_412_bytes);
  * light buffer for the reference camera at cam_pos_yaw = (x, y, z, yaw), and in what order; returns the count
  * (may exceed max_indices), -1 if a light's culling bound leaves the world box */
 int pbrh_cull_lights(uint32_t width, uint32_t height, const float cam_pos_yaw[4], const float* lights, int n, int* indices, int max_indices);
+/* CPU only: the PointLight[] (pbr_light, 44 bytes each) ClusteredPass::Execute commits for these lights and that camera
+ * (DeferredPipeline.cpp:224-241): cull membership + order, attenuation presets (Scene.cpp:132-165); count, or -1 */
+int pbrh_light_buffer(uint32_t width, uint32_t height, const float cam_pos_yaw[4], const float* lights, int n, void* out_pbr_lights, int capacity);
 int pbrh_dry_run_execution_order(uint32_t width, uint32_t height, char* buf, size_t len);
 /* ShadingState contract probes (no GPU work): 1 = the call returned true */
 int pbrh_probe_binding(const char* shader_file, int is_compute, const char* semantic_name, int kind);

@@ -15,7 +15,8 @@ from direct12pbrrenderer_amd.structs import (BLOOM_KNEE, BLOOM_THRESHOLD, CLUSTE
                                              bloom_chain_texels, cube_mip_offset, cube_texels)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbr_oracle.so")
+# PBR_TEST_ORACLE_LIB: the sanitizer build (oracle/asan/libpbr_oracle.so, tools/asan_cpu.sh)
+LIB_PATH = os.environ.get("PBR_TEST_ORACLE_LIB") or os.path.join(_HERE, "libpbr_oracle.so")
 _lib = None
 
 _u32, _f32, _int, _vp = C.c_uint32, C.c_float, C.c_int, C.c_void_p

@@ -11,6 +11,13 @@ ENV_MIPS = 5
 LUT_RES = 32
 
 
+def host_lib_path():
+    """libpbr_host.so; PBR_TEST_HOST_LIB points the CPU tests at the sanitizer build (tools/asan_cpu.sh)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return os.environ.get("PBR_TEST_HOST_LIB") or os.path.join(root, "direct12pbrrenderer_amd", "libpbr_host.so")
+
+
 def small_ibl(orc):
     """sky cube (with box mips), prefiltered env, LUT and SH pack from the oracle (16^3 / 32^2)."""
     sky = synth.env_cube(SKY_SIZE, SKY_MIPS)
@@ -57,3 +64,29 @@ def oracle_bloom_from_level1(orc, a1):
         a[l] = orc.blur_v(orc.bloom_upsample_add(a[l], a[l + 1]), ow, oh)
     h, w = a[1].shape[0] * 2, a[1].shape[1] * 2
     return orc.blur_v(orc.blur_h(a[1], w, h), w, h)
+
+
+def reference_scene_lights():
+    """The 8 `mSceneLight` records of the reference's Asset/Scene/main.json (tests/golden/scene_lights.npz, written by
+    tests/golden/make_scene_lights.py in the build container)."""
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_lights.npz"))
+
+
+def scene_json_text(recs, extra_members=True):
+    """A scene file in the reference serializer's shape (Serialization.h:180-236: base class under "@<Base>", Vector3 as
+    {x, y, z}) holding these light records — generated test input, not the reference's asset."""
+    import json
+
+    def v(a):
+        return {"x": float(a[0]), "y": float(a[1]), "z": float(a[2])}
+    lights = [{"@SceneObject": {"mName": str(recs["name"][i]), "mTranslation": v(recs["translation"][i]),
+                                "mRotation": v(recs["rotation"][i]), "mScale": v(recs["scale"][i])},
+               "mColor": v(recs["color"][i]), "mRadius": float(recs["radius"][i]), "mIntensity": float(recs["intensity"][i])}
+              for i in range(len(recs["radius"]))]
+    doc = {"@IResource": None, "mSceneLight": lights}
+    if extra_members:   # members of the file the light path must skip over
+        doc["mSceneModel"] = [{"@SceneObject": {"mName": "mésh \"0\"", "mTranslation": v([0, 0, 0]), "mRotation": v([0, 90, 0]),
+                                                "mScale": v([0.1, 0.1, 0.1])}, "mModelFilePath": "Asset/Model/x.json"}]
+        doc["mSkyBoxPath"] = "Asset/SkyBox/none"
+    return json.dumps(doc, indent=1)

@@ -112,6 +112,101 @@ def test_one_rank_communicator_runs_the_rccl_calls():
     assert r.returncode == 0 and "self-comm ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
 
+_TWO_RANKS = r"""
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, %r)
+rank, id_file = int(sys.argv[1]), sys.argv[2]
+from direct12pbrrenderer_amd.api import PbrContext, PbrError, comm_unique_id
+ctx = PbrContext(0)                              # BOTH ranks on device 0
+if rank == 0:
+    uid = comm_unique_id()
+    with open(id_file + ".tmp", "wb") as f:
+        f.write(uid)
+    os.replace(id_file + ".tmp", id_file)
+else:
+    t0 = time.time()
+    while not os.path.exists(id_file):
+        if time.time() - t0 > 60:
+            raise SystemExit("rank 1: no unique id after 60 s")
+        time.sleep(0.05)
+    uid = open(id_file, "rb").read()
+assert len(uid) == 128
+try:
+    ctx.comm_init(2, rank, uid)                  # ncclCommInitRank(2 ranks) + ncclCommSplit
+except PbrError as e:
+    # RCCL may refuse two ranks of one communicator on one device ("Duplicate GPU detected"): then the context holds NO
+    # communicator at all and both collectives refuse (ADVICE r03: no half-initialised state)
+    hist = torch.arange(256, dtype=torch.int32, device="cuda")
+    for call in (lambda: ctx.allreduce_hist(hist),
+                 lambda: ctx.halo_exchange(torch.zeros((4, 4, 4), dtype=torch.float16, device="cuda"), 4, 4, *ctx.halo_peers([(1 - rank, (0, 0, 1, 1), (2, 2, 1, 1))]),
+                                           torch.zeros((2, 4), dtype=torch.float16, device="cuda"))):
+        try:
+            call()
+            raise SystemExit("a collective ran although pbr_comm_init had failed")
+        except PbrError as e2:
+            assert "no communicator" in str(e2), e2
+    print("REFUSED:", e)
+    ctx.close()
+    raise SystemExit(77)
+# ---- histogram all-reduce on the split communicator: rank r contributes (r + 1) * bin
+hist = (torch.arange(256, dtype=torch.int32) * (rank + 1)).cuda()
+ctx.allreduce_hist(hist)
+ctx.sync()
+assert torch.equal(hist.cpu(), torch.arange(256, dtype=torch.int32) * 3), "ncclAllReduce(sum, uint32) over two ranks"
+# ---- halo exchange between the two ranks: each sends its rectangle A, receives the other's into B
+W, H = 96, 40
+def plane_of(r):
+    return np.random.default_rng(100 + r).integers(0, 30000, (H, W, 4)).astype(np.int16)
+mine, theirs = plane_of(rank), plane_of(1 - rank)
+plane = torch.from_numpy(mine).cuda()
+send = {0: (3, 2, 17, 9), 1: (40, 11, 17, 9)}
+recv = (60, 25, 17, 9)
+peers, n = ctx.halo_peers([(1 - rank, send[rank], recv)])
+st = torch.zeros((ctx.halo_staging_bytes(peers, n) // 8, 4), dtype=torch.int16, device="cuda")
+def expect(before):
+    want = before.copy()
+    sx, sy, sw, sh = send[1 - rank]
+    want[recv[1]:recv[1] + recv[3], recv[0]:recv[0] + recv[2]] = theirs[sy:sy + sh, sx:sx + sw]
+    return want
+ctx.halo_exchange(plane.view(torch.float16), W, H, peers, n, st.view(torch.float16))
+ctx.sync()
+assert np.array_equal(plane.cpu().numpy(), expect(mine)), "ncclSend / ncclRecv between two ranks moved the wrong texels"
+# ---- both communicators in flight at once: all-reduce on the side stream, halo exchange on the main one
+plane.copy_(torch.from_numpy(mine).cuda())
+hist = (torch.arange(256, dtype=torch.int32) * (rank + 1)).cuda()
+torch.cuda.synchronize()
+ctx.side_begin()
+ctx.allreduce_hist(hist)
+ctx.side_end()
+ctx.halo_exchange(plane.view(torch.float16), W, H, peers, n, st.view(torch.float16))
+ctx.side_join()
+ctx.sync()
+assert torch.equal(hist.cpu(), torch.arange(256, dtype=torch.int32) * 3)
+assert np.array_equal(plane.cpu().numpy(), expect(mine))
+ctx.close()
+print("two-rank ok")
+"""
+
+
+@pytest.mark.timeout(400)
+def test_two_ranks_on_one_gpu_through_real_rccl(tmp_path):
+    """What no one-rank communicator can show: ncclSend / ncclRecv between DISTINCT ranks and the
+    ncclCommSplit communicator's all-reduce under concurrency, through the C ABI.  Two fresh child processes, both on
+    device 0, one 2-rank RCCL communicator; hard timeouts.  If RCCL on this pool refuses two ranks per device the test
+    skips with RCCL's reason (and has then checked that a refused pbr_comm_init leaves the context in single-GPU mode)."""
+    id_file = str(tmp_path / "rccl_unique_id")
+    env = dict(os.environ, NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen(["timeout", "-k", "10", "150", sys.executable, "-c", _TWO_RANKS % ROOT, str(r), id_file],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in (0, 1)]
+    outs = [p.communicate(timeout=200) for p in procs]
+    codes = [p.returncode for p in procs]
+    if 77 in codes or any("REFUSED:" in o[0] for o in outs):
+        reason = next((line for o in outs for line in o[0].splitlines() if line.startswith("REFUSED:")), "REFUSED")
+        warn = next((line for o in outs for line in o[1].splitlines() if "WARN" in line or "uplicate" in line), "")
+        pytest.skip(f"RCCL refuses two ranks of one communicator on one device here: {reason} {warn}".strip())
+    assert codes == [0, 0] and all("two-rank ok" in o[0] for o in outs), (codes, [o[0][-1500:] for o in outs], [o[1][-3000:] for o in outs])
+
+
 _TAIL_OVERLAP = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)

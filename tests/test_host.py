@@ -6,6 +6,7 @@ import re
 import numpy as np
 import pytest
 
+import common
 from direct12pbrrenderer_amd import _lib, scene, structs, synth
 from direct12pbrrenderer_amd.pipeline import TileSpec, grid_for_world, tile_for_rank
 
@@ -158,7 +159,7 @@ def test_tile_specs_cover_the_frame_once():
 # ------------------------------------------------------------------------- CPU light cull
 def _host_lib():
     import ctypes as C
-    L = C.CDLL(os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_host.so"))
+    L = C.CDLL(common.host_lib_path())
     L.pbrh_cull_lights.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     return L
 
@@ -212,6 +213,57 @@ def test_light_cull_matches_restatement_on_random_scenes():
         assert cnt == len(want) and got == want
         assert 0 < cnt <= n and got != sorted(got)          # octree order, not scene order
         assert cnt < n or spread < 10                       # the wide scenes really lose lights to the frustum
+
+
+def test_reference_scene_lights_reach_the_light_buffer_verbatim():
+    """SURVEY 8f row 4, last clause: the 8 lights of the reference's Asset/Scene/main.json (fixture: tests/golden/scene_lights.npz)
+    -> scene-file reader -> SceneLight::CaclAttenuationCoefficients (Scene.cpp:132-165) -> Scene::CullLight (Scene.h:229-237)
+    -> the PointLight[] ClusteredPass commits (DeferredPipeline.cpp:224-241)."""
+    import ctypes as C
+    import common
+    import light_cull_ref
+    L = _host_lib()
+    L.pbrh_parse_scene_lights.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.pbrh_light_buffer.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    recs = common.reference_scene_lights()
+    n = len(recs["radius"])
+    assert n == 8 and list(recs["name"]) == [f"light_{i}" for i in range(1, 9)]
+    assert np.all(recs["rotation"] == 0) and np.all(recs["scale"] == 1)
+    # ---- the file: a document in the serializer's shape round-trips through the C++ reader bit for bit
+    text = common.scene_json_text(recs).encode()
+    got = np.zeros((n, 8), np.float32)
+    err = C.create_string_buffer(256)
+    assert L.pbrh_parse_scene_lights(text, len(text), got.ctypes.data, n, err, 256) == n, err.value
+    want = np.concatenate([recs["translation"], recs["color"], recs["radius"][:, None], recs["intensity"][:, None]], axis=1).astype(np.float32)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[0], np.float32([-4.2, 1.0, 3.5, 0.9, 0.1, 0.3, 2.0, 10.0]))       # light_1, SURVEY 8d
+    assert L.pbrh_parse_scene_lights(text, len(text), None, 0, err, 256) == n                   # count only
+    assert L.pbrh_parse_scene_lights(b'{"mSceneModel": []}', 19, None, 0, err, 256) == 0        # a scene without lights
+    for bad, why in ((text[:-2], b"unterminated"), (text.replace(b'"mRadius": 2.0', b'"mRadius": "2"', 1), b"mRadius"),
+                     (text.replace(b'"@SceneObject"', b'"SceneObject"', 1), b"@SceneObject"), (b"[1, 2]", b"not an object"),
+                     (text.replace(b'"mIntensity": 10.0', b'"mIntensity": 1e', 1), b"exponent"), (text + b"x", b"trailing")):
+        assert L.pbrh_parse_scene_lights(bad, len(bad), None, 0, err, 256) == -1 and why in err.value, (why, err.value)
+    # ---- attenuation: radius 2 falls into the 7-unit preset (step function, quirk Q18) = SURVEY 8d's (1, 0.7, 1.8)
+    buf = np.zeros(16, structs.LIGHT_DTYPE)
+    for (w, h, cam) in ((1440, 960, (0.0, 3.0, 10.0, np.pi)), (640, 360, (0.0, 3.0, 10.0, np.pi)), (1280, 720, (3.0, 1.0, -4.0, 0.4))):
+        cp = np.float32(cam)
+        cnt = L.pbrh_light_buffer(w, h, cp.ctypes.data, got.ctypes.data, n, buf.ctypes.data, len(buf))
+        c = scene.Camera(0.333 * 3.14159265359, w, h, 0.1, 1000.0)
+        c.move(cam[:3])
+        c.rotate(0.0, cam[3], 0.0)
+        order = light_cull_ref.cull_lights(c, recs["translation"], recs["radius"], recs["intensity"])
+        assert cnt == len(order) and cnt >= 1
+        out = buf[:cnt]
+        assert np.array_equal(out["Position"], recs["translation"][order]) and np.array_equal(out["Color"], recs["color"][order])
+        assert np.all(out["Intensity"] == 10.0) and np.all(out["Radius"] == 2.0)
+        assert np.all(out["C0"] == np.float32(1.0)) and np.all(out["C1"] == np.float32(0.7)) and np.all(out["C2"] == np.float32(1.8))
+        # the same records through the Python mirror the bench / parity tests build their light buffers with
+        mirror = scene.make_lights(recs["translation"][order], recs["color"][order], 2.0, 10.0)
+        assert mirror.tobytes() == out.tobytes()
+    # the reference camera (App.cpp:99-101) sees all eight: culling radius 2 * 1.81418 * sqrt(10) = 11.5 around a 13-unit-wide ring
+    cp = np.float32([0.0, 3.0, 10.0, np.pi])
+    assert L.pbrh_light_buffer(1440, 960, cp.ctypes.data, got.ctypes.data, n, buf.ctypes.data, len(buf)) == 8
+    assert L.pbrh_light_buffer(1440, 960, cp.ctypes.data, got.ctypes.data, n, buf.ctypes.data, 4) == -1    # a buffer too small is an error
 
 
 # ------------------------------------------------------------------------- SURVEY 8f row 3: .hdr ingestion

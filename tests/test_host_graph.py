@@ -8,10 +8,10 @@ import pytest
 
 import common
 from direct12pbrrenderer_amd import synth
-from direct12pbrrenderer_amd.structs import Global, bloom_chain_texels
+from direct12pbrrenderer_amd.structs import Global, bloom_chain_texels, cube_texels
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST_LIB = os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_host.so")
+HOST_LIB = common.host_lib_path()
 
 # the order FGExecutionParser::Parse (FrameGraph.cpp:191-250) derives
 REFERENCE_ORDER = "PreFilterEnvMap>PrecomputeBRDF>Clustered>GBuffer>Skybox>DeferredShading>Bloom>AutoExposure>ToneMapping>Present"
@@ -56,6 +56,8 @@ def host():
     L.pbrh_halo_copy_from.argtypes = [C.c_void_p, C.c_void_p]
     L.pbrh_set_frames_in_flight.argtypes = [C.c_void_p, C.c_int]
     L.pbrh_set_tail_overlap.argtypes = [C.c_void_p, C.c_int]
+    L.pbrh_load_scene_lights.argtypes = [C.c_void_p, C.c_char_p]
+    L.pbrh_light_buffer.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     return L
 
 
@@ -208,6 +210,80 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
         assert np.isfinite(hdr3.astype(np.float32)[on]).mean() > 0.99 and not np.array_equal(hdr3, hdr1)
     finally:
         host.pbrh_destroy(r)
+
+
+@pytest.mark.gpu
+def test_host_graph_renders_the_reference_scene_lights(host, orc, tmp_path):
+    """the 8 lights of the reference's Asset/Scene/main.json (tests/golden/scene_lights.npz), read from a scene file
+    by the C++ host (pbrh_load_scene_lights -> SceneLight presets -> Scene::CullLight -> ClusteredPass), light a 640x360 frame;
+    the HDR target after shade + bloom, the adapted luminance and the LDR image are compared with the oracle fed the PointLight[]
+    records the CPU test pins (tests/test_host.py::test_reference_scene_lights_reach_the_light_buffer_verbatim)."""
+    from direct12pbrrenderer_amd import scene
+    from direct12pbrrenderer_amd.structs import LIGHT_DTYPE, Tile
+    W, H, ENV, LUT = 640, 360, 32, 64
+    recs = common.reference_scene_lights()
+    path = tmp_path / "main.json"
+    path.write_text(common.scene_json_text(recs))
+    err = C.create_string_buffer(256)
+    r = host.pbrh_create(0, W, H, ENV, LUT, err, 256)
+    assert r, err.value
+    try:
+        sky_np = synth.env_cube(ENV)
+        assert host.pbrh_set_skybox(r, sky_np[:4 * 6 * ENV * ENV].ctypes.data, ENV) == 0, host.pbrh_last_error(r)
+        assert host.pbrh_load_scene_lights(r, str(path).encode()) == 0, host.pbrh_last_error(r)
+        assert host.pbrh_load_scene_lights(r, str(tmp_path / "missing.json").encode()) == -1 and b"cannot open" in host.pbrh_last_error(r)
+        gb = synth.gbuffer_tile(0, 0, W, H, W, H, coverage_mask=True)
+        assert host.pbrh_set_gbuffer(r, *[np.ascontiguousarray(gb[k]).ctypes.data for k in ("A", "B", "C", "depth", "stencil")]) == 0
+        assert host.pbrh_set_initial_luminance(r, 0.18) == 0
+        assert host.pbrh_render(r, 1.0 / 60.0) == 0, host.pbrh_last_error(r)
+
+        def read(name, shape, dtype):
+            a = np.zeros(shape, dtype=dtype)
+            n = host.pbrh_read(r, name.encode(), a.ctypes.data, a.nbytes)
+            assert n == a.nbytes, (name, n, host.pbrh_last_error(r))
+            return a
+        hdr = read("DeferredShadingRT", (H, W, 4), np.float16)
+        ldr = read("ToneMappedTexture", (H, W), np.uint32)
+        avg = read("AverageLuminance", (1,), np.float32)[0]
+        lights_dev = read("ClusteredLights", (1024,), LIGHT_DTYPE)
+        env = read("PrefilterEnvMap", (cube_texels(ENV, 5), 4), np.float16)
+        lut = read("PrecomputeBRDF", (LUT, LUT, 2), np.float16)
+        g = Global()
+        assert host.pbrh_get_global(r, C.byref(g)) == 0
+    finally:
+        host.pbrh_destroy(r)
+    # the light buffer on the device = the records the CPU path derives (octree order, 7-unit preset)
+    packed = np.ascontiguousarray(np.concatenate([recs["translation"], recs["color"], recs["radius"][:, None], recs["intensity"][:, None]], axis=1), np.float32)
+    lights = np.zeros(16, LIGHT_DTYPE)
+    cam4 = np.float32([0.0, 3.0, 10.0, 3.14159265359])
+    assert host.pbrh_light_buffer(W, H, cam4.ctypes.data, packed.ctypes.data, 8, lights.ctypes.data, 16) == 8
+    lights = lights[:8]
+    assert lights_dev[:8].tobytes() == lights.tobytes() and not lights_dev[8:].tobytes().strip(b"\0")
+    assert sorted(map(tuple, lights["Position"])) == sorted(map(tuple, recs["translation"]))
+    # oracle frame on the device's IBL tables (their own parity: tests/test_gpu_parity.py)
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)
+    assert cl["NumLights"].max() >= 1                                   # the scene's lights do reach clusters of this view
+    tile = Tile(0, 0, W, H, W, H)
+    want, _ = orc.deferred_shade(g, tile, gb, lut, env, ENV, 5, cl, lights)
+    no_lights, _ = orc.deferred_shade(g, tile, gb, lut, env, ENV, 5, cl, lights[:0])
+    lit = np.abs(want.astype(np.float32) - no_lights.astype(np.float32))[..., :3].max(axis=-1) > 1e-3
+    assert lit.mean() > 0.02                                            # ... and light a visible share of the pixels
+    sky_full = sky_np.copy()
+    orc.cube_gen_mips(sky_full, ENV, int(np.log2(ENV)) + 1)
+    orc.skybox(g, tile, sky_full, ENV, int(np.log2(ENV)) + 1, gb["stencil"], want)
+    orc.bloom(want)
+    hist = orc.lum_histogram(want)
+    avg_want = orc.lum_average(hist, W * H, 1.0 / 60.0, 0.18)
+    ldr_want = orc.tonemap(want, avg_want)
+    scale = np.abs(want.astype(np.float32)[..., :3]).max()
+    d = common.half_ulp_diff(hdr[..., :3], want[..., :3])
+    assert (d > 2).mean() <= 1e-3, (d.max(), (d > 2).mean())
+    assert np.abs(hdr.astype(np.float32) - want.astype(np.float32))[..., :3].max() <= 5e-3 * scale
+    assert abs(float(avg) - avg_want) <= 1e-4 * abs(avg_want) + 1e-7
+    sh = np.array([0, 8, 16], dtype=np.uint32)
+    dl = np.abs(((ldr[..., None] >> sh) & 255).astype(np.int32) - ((ldr_want[..., None] >> sh) & 255).astype(np.int32))
+    assert (dl > 1).mean() < 1e-3
 
 
 @pytest.mark.gpu

@@ -5,6 +5,8 @@ import re
 import subprocess
 import sys
 
+import common
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -57,7 +59,7 @@ def test_host_library_exports_every_declared_symbol():
     """libpbr_host.so (the C++ pass graph) exports what direct12pbrrenderer_amd/host/pbr_host.h declares."""
     import ctypes
     import torch  # noqa: F401  (its ROCm runtime first: see _lib.load)
-    lib = ctypes.CDLL(os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_host.so"))
+    lib = ctypes.CDLL(common.host_lib_path())
     header = open(os.path.join(ROOT, "direct12pbrrenderer_amd", "host", "pbr_host.h")).read()
     declared = set(re.findall(r"\b(pbrh_[a-z0-9_]+)\s*\(", header))
     assert len(declared) >= 25
@@ -88,7 +90,7 @@ def test_host_tile_layout_matches_the_python_tiling_and_halo_plan():
     import numpy as np
     import torch  # noqa: F401
     from direct12pbrrenderer_amd.pipeline import halo_plan, tile_of_frame
-    lib = ctypes.CDLL(os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_host.so"))
+    lib = ctypes.CDLL(common.host_lib_path())
     lib.pbrh_tile_layout.argtypes = [ctypes.c_uint32] * 5 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     for fw, fh, cols, rows in ((7680, 4320, 4, 2), (7680, 4320, 2, 1), (7680, 4320, 2, 2), (3072, 576, 3, 1), (1024, 2048, 1, 4), (3840, 2160, 1, 1)):
         world = cols * rows
