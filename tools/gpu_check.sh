@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU-box check of one state of the tree (run through gpurun): GPU parity tests, the bench line (with its host_graph block),
-# the 2-rank rehearsal of bench.py on the one GPU (weak-scaling headline + cfg5 sub-record).  usage: bash tools/r03_gpu_check.sh <tag> [quick]
+# the 2-rank rehearsal of bench.py on the one GPU (weak-scaling headline + cfg5 sub-record).  usage: bash tools/gpu_check.sh <tag> [quick]
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 if [ "$2" = "quick" ]; then
