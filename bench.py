@@ -57,6 +57,7 @@ MEASURED_CLOCK_HZ = 2.1e9
 # algorithmic bytes per pixel: unique bytes a reference pass must read + write once
 BYTES_PER_PX = {"shade": 25.0, "bloom": 75.75, "histogram": 8.0, "tonemap": 12.0}
 ENV_SIZE, LUT_RES, N_LIGHTS = 512, 512, 256
+ROUGH_MIN = 48                  # synth.gbuffer_tile default; see config.workload
 CFG5_FRAME = (7680, 4320)       # BASELINE.json configs[4]
 CFG5_GRID = {8: (4, 2)}         # (cols, rows): "tiled 2x4" = 2 rows of 4 tiles; other N: the most square grid
 
@@ -86,6 +87,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--no-host-graph", action="store_true", help="skip the C++ pass-graph leg (host_graph block)")
+    p.add_argument("--no-shade-paths", action="store_true", help="skip the shade_ms_by_path A/B (N = 1)")
     p.add_argument("--deadline", type=float, default=240.0, help="seconds a collective phase may take before the rank gives up (N > 1)")
     return p.parse_args()
 
@@ -136,16 +138,18 @@ class Watchdog:
                     os._exit(code)
 
     def phase(self, seconds, what):
+        """Context manager arming a deadline.  Phases may nest: leaving an inner one re-arms the enclosing one's deadline."""
         wd = self
 
         class _P:
             def __enter__(self_inner):
                 with wd.lock:
+                    self_inner.prev = (wd.deadline, wd.what)
                     wd.deadline, wd.what = time.monotonic() + seconds, what
 
             def __exit__(self_inner, *exc):
                 with wd.lock:
-                    wd.deadline = None
+                    wd.deadline, wd.what = self_inner.prev
                 return False
         return _P()
 
@@ -256,19 +260,20 @@ def mean_lights_per_pixel(g, gb_np, spec, clusters_dev):
     return float(np.minimum(cl["NumLights"], 32)[idx].mean())
 
 
-def cpu_baseline(g, lights, lut_np, env_np, width, height, budget_s=2.5, reps=5):
-    """The oracle ("port") on a bounded band of the single-GPU frame, all host threads: a 64-row probe sizes the band
-    so one repetition costs about `budget_s` seconds (<= the whole frame); inputs are synthesised ONCE outside the
-    clock; the timed region is the oracle calls only (cluster build + cull, shade, bloom, histogram, average, tone-map);
-    value = median of `reps` repetitions after one warm-up."""
+def cpu_baseline(g, lights, lut_np, env_np, width, height, rows=1024, reps=5, parity_probe=None):
+    """The oracle ("port") on a FIXED band of the single-GPU frame, all host threads: the `rows` centre rows of the frame (the same
+    sample on every box and in every round, whatever the host's speed — round 3 sized the band with a 64-row probe and the figure
+    wandered 4.3 -> 6.9 -> 5.1); inputs are synthesised ONCE outside the clock; the timed region is the oracle calls only (cluster
+    build + cull, shade, bloom, histogram, average, tone-map); value = median of `reps` repetitions after one warm-up.
+    parity_probe(orc): while the checker is loaded, the caller's GPU-vs-truth comparison (the `parity` block) runs here — this
+    leg is the only place bench.py touches oracle/."""
     from oracle import binding as orc
 
-    def band(rows):
-        rows = max(16, min(height, rows) // 16 * 16)
-        y0 = (height - rows) // 2
-        return rows, y0, synth.gbuffer_tile(0, y0, width, rows, width, height)
+    rows = max(16, min(height, rows) // 16 * 16)
+    y0 = (height - rows) // 2 // 8 * 8
+    gb = synth.gbuffer_tile(0, y0, width, rows, width, height)
 
-    def run(rows, y0, gb):
+    def run():
         t0 = time.perf_counter()
         cl = orc.cluster_build(g)
         orc.cluster_cull(g, lights, cl)
@@ -279,16 +284,56 @@ def cpu_baseline(g, lights, lut_np, env_np, width, height, budget_s=2.5, reps=5)
         orc.tonemap(hdr, avg)
         return time.perf_counter() - t0
 
-    rows, y0, gb = band(64)
-    dt = run(rows, y0, gb)
-    rows, y0, gb = band(int(rows * budget_s / max(dt, 1e-3)))
-    run(rows, y0, gb)
-    times = sorted(run(rows, y0, gb) for _ in range(reps))
+    run()
+    times = sorted(run() for _ in range(reps))
     dt = times[len(times) // 2]
-    return {"value": round(width * rows / dt / 1e6, 4), "unit": "Mpixel/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{width}x{rows} band (rows {y0}..{y0 + rows - 1}) of the {width}x{height} frame: cluster build+cull, shade(256 lights+IBL), "
+    base = {"value": round(width * rows / dt / 1e6, 4), "unit": "Mpixel/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{width}x{rows} band (rows {y0}..{y0 + rows - 1}, fixed) of the {width}x{height} frame: cluster build+cull, shade(256 lights+IBL), "
                       f"bloom, histogram, average, tonemap — oracle/pbr_oracle.cpp, OpenMP on {orc.num_threads()} threads, median of {reps} x {dt:.2f} s "
-                      f"(inputs synthesised outside the clock)"}
+                      f"(min {times[0]:.2f}, max {times[-1]:.2f}; inputs synthesised outside the clock)"}
+    parity = None
+    if parity_probe is not None:
+        try:
+            parity = parity_probe(orc)
+        except Exception as e:   # noqa: BLE001 — reporting only
+            parity = {"error": f"{type(e).__name__}: {e}"}
+    return base, parity
+
+
+def shade_parity_probe(ctx, g, lights, lut_dev, env_dev, lut_np, env_np, width, height, rows=32):
+    """The `parity` block: the GPU shade BEFORE its fp16 store (pbr_deferred_shade_f32, same kernel body) on a width x rows band of the
+    bench frame against the DOUBLE-precision evaluation of the reference's formulas (oracle/pbr_oracle_f64.cpp), as plain relative
+    L-inf — north_star's "<= 1e-4" with nothing allowed on top — next to the same figure for the fp32 CPU restatement of the shader
+    (the error both share is the conditioning of GGX at highlights).  Returns a closure for cpu_baseline."""
+    def probe(orc):
+        y0 = (height - rows) // 2 // 8 * 8
+        tile = Tile(0, y0, width, rows, width, height)
+        gb = synth.gbuffer_tile(0, y0, width, rows, width, height)
+        cl = orc.cluster_build(g)
+        orc.cluster_cull(g, lights, cl)
+        _, o32 = orc.deferred_shade(g, tile, gb, lut_np, env_np, ENV_SIZE, ENV_MIPS, cl, lights, want_f32=True)
+        lo, hi, fl = orc.deferred_shade_f64(g, tile, gb, lut_np, env_np, ENV_SIZE, ENV_MIPS, cl, lights)
+        gbd = {k: ctx.upload(v) for k, v in gb.items()}
+        out = ctx.zeros((rows, width, 4), torch.float32)
+        envp = ctx.env_pad(env_dev, ENV_SIZE, ENV_MIPS)
+        ctx.deferred_shade_f32(g, tile, gbd, width, lut_dev, LUT_RES, envp, ENV_SIZE, ENV_MIPS, ctx.upload(cl), ctx.upload(lights), len(lights), out, width)
+        ctx.sync()
+        got = out.cpu().numpy()
+        ok = fl == 0
+        scale = float(np.abs(hi[ok]).max())
+        dg = orc.truth_distance(got, lo, hi)[ok].max(axis=-1) / scale
+        do = orc.truth_distance(o32, lo, hi)[ok].max(axis=-1) / scale
+        worst = int(np.argmax(dg))
+        return {"what": f"fp32 shade (pbr_deferred_shade_f32) vs f64 truth on the {width}x{rows} band at row {y0} of the bench frame; relative to scale = max |truth|",
+                "bound": "north_star: <= 1e-4 relative L-inf (plain, nothing allowed on top)", "pixels": int(ok.sum()),
+                "pixels_not_comparable": int((~ok).sum()), "scale": round(scale, 3),
+                "gpu_pixels_above_1e-4": int((dg > 1e-4).sum()), "gpu_worst": float(f"{dg.max():.3e}"), "gpu_q99.99": float(f"{np.quantile(dg, 0.9999):.3e}"),
+                "cpu_fp32_restatement_pixels_above_1e-4": int((do > 1e-4).sum()), "cpu_fp32_restatement_worst": float(f"{do.max():.3e}"),
+                "cpu_fp32_restatement_at_gpu_worst_pixel": float(f"{do[worst]:.3e}"),
+                "criterion_failures": int((dg > 1e-4 + 4.0 * do).sum()),
+                "note": "pixels above 1e-4 are GGX highlights at roughness ~0.2 where the fp32 rounding of N.H is amplified by 4/t; the fp32 restatement of "
+                        "the shader misses the bound at the same pixels by the same amount (tests assert |gpu - truth| <= 1e-4 scale + 4 |restatement - truth|)"}
+    return probe
 
 
 def weak_tile(world, cols, rows, base_w, base_h):
@@ -537,6 +582,57 @@ def run_workload(job, name, scaling, make_spec, full_w, full_h, cols, rows, step
     return res
 
 
+def two_preset_lights(cam):
+    """The bench lights with every second one re-cast as radius 1 / intensity 40: the same positions, colours and CULLING radius
+    (radius * 1.814 * sqrt(intensity): 2 sqrt(10) = 1 sqrt(40)), hence the same cluster lists and trip counts — but a second attenuation preset
+    ((1, 4.5, 75) for radius <= 1, Scene.cpp:132-165), which switches the shade's shared-polynomial path off."""
+    a = synth.lights_in_view_box(N_LIGHTS, cam)
+    b = synth.lights_in_view_box(N_LIGHTS, cam, radius=1.0, intensity=40.0)
+    a[1::2] = b[1::2]
+    return a
+
+
+def shade_paths_ab(job, res, frames=30):
+    """`shade_ms_by_path`: the in-frame shade time (HIP events around the launch inside whole rendered frames) and the frame time of the bench
+    workload as shipped and with the inputs that take the shade's other light-walk instantiations (shade.hip: walk(QSAFE, TSAFE, ATT)):
+    SURVEY 8d's full roughness range (a wave of 64 independent pixels is then never all >= 0.157, so the GGX floor max(pi t^2, 1e-6) is
+    evaluated: TSAFE off) and two attenuation presets (ATT off).  Outside the timed region; N = 1 only.  The full-range frames hold fp16 inf /
+    NaN after bloom (the reason for the floor on roughness) — their time is what is reported, not their image."""
+    ctx, spec, g = job.ctx, res["spec"], res["g"]
+    cam = scene.Camera.reference_default(spec.full_w, spec.full_h)
+    out = {}
+    variants = [("as_shipped", ROUGH_MIN, False), ("roughness_0_255", 0, False), ("two_attenuation_presets", ROUGH_MIN, True),
+                ("roughness_0_255_and_two_presets", 0, True)]
+    for name, rough_min, two in variants:
+        lights = two_preset_lights(cam) if two else res["lights"]
+        fr = DeferredFrame(ctx, spec, g, lights, job.lut, LUT_RES, job.env, ENV_SIZE, ENV_MIPS)
+        gb_np = res["gb_np"] if rough_min == ROUGH_MIN else synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h, rough_min=rough_min)
+        fr.upload_gbuffer(gb_np)
+        fr.set_prev_luminance(0.18)
+        for _ in range(60):
+            fr.render()
+        torch.cuda.synchronize()
+        ev = []
+        t0 = time.perf_counter()
+        for i in range(frames):
+            fr.render(ev if i % 3 == 0 else None)
+        torch.cuda.synchronize()
+        frame_ms = (time.perf_counter() - t0) / frames * 1e3
+        shade_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        out[name] = {"shade_ms": round(shade_ms, 4), "frame_ms": round(frame_ms, 4),
+                     "mean_lights_per_pixel": round(mean_lights_per_pixel(g, gb_np, spec, fr.clusters), 3)}
+        del fr, gb_np
+        torch.cuda.empty_cache()
+    base = out["as_shipped"]["shade_ms"]
+    for v in out.values():
+        v["shade_vs_as_shipped"] = round(v["shade_ms"] / base, 4)
+    out["note"] = ("same frame size, lights' positions / colours / culling radii and cluster lists in all four (mean_lights_per_pixel); only the walk "
+                   "instantiation differs: as_shipped = walk(QSAFE, TSAFE, ATT) in every wave; roughness_0_255 = TSAFE off (+1 packed mul, +2 v_max per "
+                   "light pair); two presets = ATT off (per-light coefficients: 19 instead of 13 LDS dwords per pair).  The roughness_0_255 frames contain "
+                   "fp16 inf (GGX peak > 65504 below roughness ~0.17) — timing only")
+    return out
+
+
 def workload_config(job, r, settle):
     spec, world, rows, cols = r["spec"], job.world, r["rows"], r["cols"]
     if world == 1:
@@ -546,7 +642,11 @@ def workload_config(job, r, settle):
                     f"{spec.w}x{spec.h} tiles, one per GPU")
     else:
         workload = f"strong scaling: {spec.full_w}x{spec.full_h} frame as {rows} rows x {cols} cols of {spec.w}x{spec.h} tiles, one per GPU"
-    workload += f"; {N_LIGHTS} clustered lights + IBL (env {ENV_SIZE}^2 x{ENV_MIPS} mips, LUT {LUT_RES}^2, SH9), auto-exposure + ACES + 9-tap bloom"
+    workload += (f"; {N_LIGHTS} clustered lights + IBL (env {ENV_SIZE}^2 x{ENV_MIPS} mips, LUT {LUT_RES}^2, SH9), auto-exposure + ACES + 9-tap bloom"
+                 f"; synthetic G-buffer per SURVEY 8d EXCEPT roughness u8 uniform on [{ROUGH_MIN},255] (8d: [0,255]; below ~0.17 the GGX peak of an "
+                 f"intensity-10 light overflows fp16 and one inf turns the bloom pyramid into NaNs), every pixel an independent surface sample, stencil 1 "
+                 f"everywhere; all {N_LIGHTS} lights radius 2 / intensity 10 => ONE attenuation preset (1, 0.7, 1.8) — with these two properties every wave of "
+                 f"the shade takes its all-fast-paths walk (GGX floor off, shared attenuation polynomial): see shade_ms_by_path for the other paths")
     fr = r["frame_obj"]
     cfg = {"workload": workload, "frame": [spec.full_w, spec.full_h], "layout_rows_x_cols": f"{rows}x{cols}",
            "tile": [spec.x0, spec.y0, spec.w, spec.h], "shaded_rect": [spec.sx0, spec.sy0, spec.sw, spec.sh],
@@ -680,7 +780,7 @@ def main():
             return 3
         out.setdefault("config", {}).setdefault("notes", []).append(f"gave up on '{what}' after {a.deadline:.0f} s; the record holds what was measured before")
         emit(out)
-        return 0
+        return 4    # the (partial) record is on stdout, but a run whose collective hung must not look like a clean one
 
     wd = Watchdog()
     wd.on_fire = on_deadline
@@ -768,15 +868,24 @@ def main():
         shade_ms_in_frame = sum(e0.elapsed_time(e1) for e0, e1 in shade_events) / max(len(shade_events), 1)
         kern["shade(in frame)"] = {"ms": round(shade_ms_in_frame, 4), "GB/s": round(BYTES_PER_PX["shade"] * shaded_px / (shade_ms_in_frame * 1e-3) / 1e9, 1)}
         achieved = kern["shade(in frame)"]["GB/s"]
-        out["roofline"] = {"bound": "hbm", "kernel": "k_deferred_shade",
+        frame_bytes = sum(BYTES_PER_PX.values()) * spec.w * spec.h
+        frame_gbps = frame_bytes / (res["ms_per_step"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "valu", "kernel": "k_deferred_shade",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": pmc_traffic("k_deferred_shade", shaded_px),
                            "hbm_measured_GBps": round(hbm_meas, 1), "frac_of_measured": round(achieved / hbm_meas, 5),
+                           # BASELINE's metric is "Mpixel/s ...; % HBM roofline" of the FRAME: all stages' algorithmic bytes over the timed step
+                           "frame": {"bytes": int(frame_bytes), "bytes_per_pixel": sum(BYTES_PER_PX.values()), "ms": round(res["ms_per_step"], 4),
+                                     "GBps": round(frame_gbps, 1), "frac": round(frame_gbps / HBM_PEAK_GBS, 4), "frac_of_measured": round(frame_gbps / hbm_meas, 4),
+                                     "note": "SURVEY 8d frame total (shade 25 + bloom 75.75 + histogram 8 + tone-map 12 B/px) x this rank's interior pixels / "
+                                             "ms_per_step of the timed region"},
                            "stage_ms": {k: v["ms"] for k, v in kern.items()},
                            "stage_GBps": {k: v["GB/s"] for k, v in kern.items()},
                            "stage_frac_of_measured": {k: round(v["GB/s"] / hbm_meas, 4) for k, v in kern.items() if v["GB/s"]},
-                           "note": "algorithmic bytes (SURVEY 8d) / HIP-event duration; hbm_measured_GBps = pbr_membench_read streaming 2 GiB on this device; "
-                                   "the shade with 256 clustered lights is FP32-VALU-bound (SURVEY D6): its HBM fraction is structurally low; "
+                           "note": "dominant kernel = the shade, which with 256 clustered lights is bound by FP32 VALU ISSUE (bound: valu; the `valu` block "
+                                   "below prices it), so achieved / peak / frac — its ALGORITHMIC bytes (SURVEY 8d: 25 B/px) over its HIP-event launch duration "
+                                   "against HBM, as the schema asks — are structurally low; `frame` is the whole step against HBM; "
+                                   "hbm_measured_GBps = pbr_membench_read streaming 2 GiB on this device; "
                                    "stage_GBps of the fused bloom is EFFECTIVE (the 16 reference passes' bytes / the fused launches' time), not traffic; "
                                    "traffic (when present) is the committed rocprofv3 PMC figure for this workload and this version of shade.hip, "
                                    "IBL gathers served by L2/MALL included"}
@@ -816,6 +925,12 @@ def main():
                 valu["TFLOPs_upper_bound"] = round(tf, 1)
                 valu["frac_of_fp32_peak_upper_bound"] = round(tf / FP32_VALU_PEAK_TFLOPS, 3)
             out["roofline"]["valu"] = valu
+
+    if world == 1 and not a.no_kernel_timing and not a.no_shade_paths:
+        try:
+            out["shade_ms_by_path"] = shade_paths_ab(job, res)
+        except Exception as e:   # noqa: BLE001 — reporting only
+            out["shade_ms_by_path"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- the drop-in path: the same workload driven by the C++ pass graph
     # (optional legs from here on: an exception on this rank is recorded, not raised — the contract line above is complete, and a
@@ -882,8 +997,12 @@ def main():
 
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(g, lights, job.lut.cpu().view(torch.int16).numpy().view(np.float16),
-                                               job.env.cpu().view(torch.int16).numpy().view(np.float16), a.width, a.height)
+            lut_np = job.lut.cpu().view(torch.int16).numpy().view(np.float16)
+            env_np = job.env.cpu().view(torch.int16).numpy().view(np.float16)
+            probe = shade_parity_probe(ctx, g, lights, job.lut, job.env, lut_np, env_np, a.width, a.height)
+            out["cpu_baseline"], parity = cpu_baseline(g, lights, lut_np, env_np, a.width, a.height, parity_probe=probe)
+            if parity is not None:
+                out["parity"] = parity
         except Exception as e:   # the baseline is reporting only; never fail the GPU measurement on it
             out["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     with wd.phase(a.deadline, "teardown"):

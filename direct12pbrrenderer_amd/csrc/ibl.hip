@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void k_prefilter_env(const float* __restrict__
     prefilter_block(tab, sky, sky_size, sky_mips, size, s, roughness, out, blockIdx.x);
 }
 
+#ifdef PBR_DEBUG_KNOBS   // measured alternative of round 1 (PBR_PREFILTER_SEQ=1): only the knobs build carries it
 // All mips in ONE launch.  A thread walks its 1 024 samples one after the other (the reference's running sum), so a
 // dispatch lasts as long as that serial chain whatever the mip's size — five dispatches in a row cost five chains
 // with a mostly idle chip (mip 4 is 96 waves).  Run together the mips overlap: blocks are ordered mip 1, 2, ..,
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void k_prefilter_env_all(const float* __restri
     const float roughness = mips > 1 ? (float)mip / (float)(mips - 1) : 0.0f;   // DeferredPipeline.cpp:99
     prefilter_block(tab, sky, sky_size, sky_mips, size, size >> mip, roughness, out + 4 * cube_mip_offset(size, mip), b);
 }
+#endif
 
 // ---------------------------------------------------------------------------- wave-parallel prefilter (pbr_prefilter_env)
 // The same integral, mapped the way the hardware likes it:
@@ -311,17 +313,16 @@ __global__ __launch_bounds__(256) void k_prefilter_fast(const float4* __restrict
 }
 #endif
 
+#ifdef PBR_DEBUG_KNOBS
 // The same table-driven, branch-free inner loop with the OTHER mapping: one lane per output texel, the 64 lanes of a
 // wave are 64 neighbouring texels and all of them take sample j at the same time.  Neighbouring texels reflect the same
 // tangent-space direction into neighbouring source positions, so a wave's 8 x 64 texel fetches fall into a few dozen
 // cache lines (measured: 2.4x faster than the wave-per-texel mapping, whose 64 lanes scatter over the whole lobe and
 // pull ~256 lines per trip through a 32 KB L1).  The sum runs in sample order like the shader's.  This is what
 // pbr_prefilter_env launches; k_prefilter_fast stays selectable (PBR_PREFILTER_WAVE=1) as the measured alternative.
-// run_if_lossy: nullptr = always; else the kernel runs only when *run_if_lossy != 0 (pbr_prefilter_env launches this kernel AND
-// k_prefilter_foot; the flag written by k_cube_pad_chain decides on the device which of the two does the work)
+// Round-2 kernel, superseded by k_prefilter_foot<false>: only the knobs build carries it (PBR_PREFILTER_F32=1), as the measured A/B partner.
 __global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict__ sky_padded, const float4* __restrict__ tables,
-                                                         PfLaunch pl, pbr_half* __restrict__ out, const uint32_t* __restrict__ run_if_lossy) {
-    if (run_if_lossy && *run_if_lossy == 0u) return;
+                                                         PfLaunch pl, pbr_half* __restrict__ out) {
     __shared__ float4 tab[PBR_SAMPLE_COUNT];
     uint32_t mip = 1;
     while (mip + 1 < pl.mips && blockIdx.x >= pl.first_block[mip + 1]) mip++;
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256) void k_prefilter_tex(const float4* __restrict_
     const float w = pl.wsum[mip];   // 0 samples -> 0/0 = NaN like the reference
     store_h4(out + 4 * (cube_mip_offset(pl.size, mip) + (size_t)t), f4(cr / w, cg / w, cb / w, 1.0f));
 }
+#endif
 
 // ---- the same table-driven, texel-per-lane loop on a HALF-precision padded copy of the source chain (what pbr_prefilter_env
 // launches for mips >= 1).  Counters of k_prefilter_tex (profiles/r03_*): VALU busy ~100 % (168 instructions per sample) AND
@@ -489,7 +491,16 @@ __global__ __launch_bounds__(PF_FOOT_BLOCK) __attribute__((amdgpu_waves_per_eu(8
     __syncthreads();
     const uint32_t s = pl.size >> mip;
     const uint32_t n = 6u * s * s;
-    const uint32_t t = (blockIdx.x - pl.first_block[mip]) * PF_FOOT_BLOCK + threadIdx.x;
+    // XCD-aware block -> texel mapping.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with its own
+    // 4 MB L2: with the plain mapping every XCD samples for texels all over the cube, i.e. needs the WHOLE source chain in its L2 —
+    // the fp32 chain (33.6 MB) then thrashes (round 3: FETCH 3.1 GB for a 50 MB compulsory footprint, TCC hit 85 %).  Here the
+    // blocks that share blockIdx % 8 — one XCD — take one CONTIGUOUS eighth of the mip's texels, so an XCD's working set is the
+    // source region behind ~3/4 of a cube face.  (Any consistent function of blockIdx % 8 keeps the grouping; which physical XCD
+    // serves a group does not matter.)
+    const uint32_t lb = blockIdx.x - pl.first_block[mip], nb = pl.first_block[mip + 1] - pl.first_block[mip];
+    const uint32_t xcd = lb & 7u, chunk = nb >> 3, rem = nb & 7u;
+    const uint32_t block = xcd * chunk + min(xcd, rem) + (lb >> 3);   // group x holds chunk + (x < rem) blocks; lb >> 3 < that count by construction
+    const uint32_t t = block * PF_FOOT_BLOCK + threadIdx.x;
     if (t >= n) return;
     const uint32_t x = t % s, y = (t / s) % s, face_o = t / (s * s);
     const float u = (float)x / (float)s, v = (float)y / (float)s;   // texel corner (Q8)
@@ -581,9 +592,7 @@ __global__ __launch_bounds__(256) void k_cube_pad_chain(const float4* __restrict
 
 // roughness 0: H = L = N for every sample, weight 1: the filtered value IS the bilinear fetch at the texel-corner
 // direction (the reference's 1 024-fold running sum of one value differs from it by < 1e-4 relative, far inside the fp16 ULP)
-// (the call's last kernel: it also lowers the "half copy is lossy" flag again for the next call)
-__global__ __launch_bounds__(256) void k_prefilter_mip0(const float4* __restrict__ sky_padded, PfLaunch pl, pbr_half* __restrict__ out, uint32_t* __restrict__ lossy) {
-    if (lossy && blockIdx.x == 0 && threadIdx.x == 0) *lossy = 0u;
+__global__ __launch_bounds__(256) void k_prefilter_mip0(const float4* __restrict__ sky_padded, PfLaunch pl, pbr_half* __restrict__ out) {
     const uint32_t s = pl.size;
     const size_t n = (size_t)6 * s * s;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -808,25 +817,33 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     PBR_REQUIRE(ctx, size >= 1 && mips >= 1 && mips <= 16 && (size >> (mips - 1)) >= 1, "pbr_prefilter_env: bad output size/mips");
     PBR_REQUIRE(ctx, sky && sky->data && sky->size >= 1 && sky->mips >= 1 && (sky->size >> (sky->mips - 1)) >= 1, "pbr_prefilter_env: bad sky cube");
     PBR_REQUIRE(ctx, size <= 8192, "pbr_prefilter_env: bad output size/mips");
+#ifdef PBR_DEBUG_KNOBS
     static const bool sequential = pbr::knob_set("PBR_PREFILTER_SEQ");   // A/B switch: the thread-per-texel kernel, all mips in one launch
-    if (sequential || sky->mips > 16) {
+    if (sequential) {
         size_t blocks = 0;
         for (uint32_t m = 0; m < mips; m++) blocks += ((size_t)6 * (size >> m) * (size >> m) + 255) / 256;
         PBR_REQUIRE(ctx, blocks <= 0x7FFFFFFFull, "pbr_prefilter_env: cube too large");
         hipLaunchKernelGGL(k_prefilter_env_all, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sky->data, sky->size, sky->mips, size, mips, out);
         return launched(ctx, "k_prefilter_env_all");
     }
-    // ---- wave-parallel path: padded source chain (stream-ordered scratch) + per-mip sample tables (kept on the device)
+#endif
+    // ---- padded source chain (stream-ordered scratch) + per-mip sample tables (kept on the device)
     PfLaunch pl{};
     pl.mips = mips; pl.size = size; pl.sky_size = sky->size; pl.sky_mips = sky->mips;
+    PBR_REQUIRE(ctx, sky->mips <= 16, "pbr_prefilter_env: bad sky cube");
     for (uint32_t l = 0; l < sky->mips; l++) pl.src_off[l] = (uint32_t)cube_border_mip_offset(sky->size, l);
     const size_t padded_texels = cube_border_mip_offset(sky->size, sky->mips);
-    PBR_REQUIRE(ctx, padded_texels <= 0xFFFFFFFFull, "pbr_prefilter_env: sky cube too large");
-    static const bool wave_per_texel = pbr::knob_set("PBR_PREFILTER_WAVE");   // A/B switch: the other mapping
-    // which kernel samples mips >= 1: the half / fp32 padded chains through k_prefilter_foot (default) or the round-2 kernel on the
-    // padded fp32 chain (knobs build: PBR_PREFILTER_F32=1, kept as the measured alternative); k_prefilter_foot takes 32-bit byte offsets
-    static const bool force_f32 = pbr::knob_set("PBR_PREFILTER_F32");
-    const bool use_foot = !force_f32 && !wave_per_texel && padded_texels * 16u < (1ull << 32) && mips > 1;
+    // the kernels address the padded chains with 32-bit byte offsets: sky cubes up to 4096^2 with a full mip chain (2.1 GiB padded);
+    // larger ones go through pbr_prefilter_env_mip, one reference dispatch at a time
+    PBR_REQUIRE(ctx, padded_texels * 16u < (1ull << 32), "pbr_prefilter_env: sky cube too large (padded fp32 chain must stay below 4 GiB; use pbr_prefilter_env_mip)");
+    // which kernel samples mips >= 1: k_prefilter_foot on the half / fp32 padded chains.  Knobs build only: PBR_PREFILTER_WAVE=1 (the
+    // wave-per-texel mapping) and PBR_PREFILTER_F32=1 (the round-2 kernel on the padded fp32 chain) stay selectable as A/B partners
+    bool wave_per_texel = false, force_f32 = false;
+#ifdef PBR_DEBUG_KNOBS
+    static const bool k_wave = pbr::knob_set("PBR_PREFILTER_WAVE"), k_f32 = pbr::knob_set("PBR_PREFILTER_F32");
+    wave_per_texel = k_wave; force_f32 = k_f32 && !k_wave;
+#endif
+    const bool use_foot = !force_f32 && !wave_per_texel;
     const uint32_t per_block = wave_per_texel ? (uint32_t)PF_TEXELS_PER_BLOCK : use_foot ? PF_FOOT_BLOCK : 256u;
     // The sample tables depend on (size, mips, sky mips) only: built on the host and uploaded when that key changes, then reused
     // (a renderer prefilters the same shapes again and again; the build is ~0.1 ms of libm and the upload a blocking copy).  A new key
@@ -840,16 +857,12 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
         }
         if (ctx->pf_dev) { (void)hipFree(ctx->pf_dev); ctx->pf_dev = nullptr; }
         PBR_HIP(ctx, hipSetDevice(ctx->device));
-        PBR_HIP(ctx, hipMalloc(&ctx->pf_dev, table_bytes + 16));
-        hipError_t e = hipMemcpy(ctx->pf_dev, ctx->host_tmp.data(), table_bytes, hipMemcpyHostToDevice);   // blocking: host_tmp may be reused at once
-        // the flag: zeroed IN STREAM ORDER (hipMemset on the null stream is not ordered against a non-blocking stream's kernels), then
-        // lowered again by each call's last kernel
-        if (e == hipSuccess) e = hipMemsetAsync(reinterpret_cast<char*>(ctx->pf_dev) + table_bytes, 0, 16, ctx->stream);
+        PBR_HIP(ctx, hipMalloc(&ctx->pf_dev, table_bytes));
+        const hipError_t e = hipMemcpy(ctx->pf_dev, ctx->host_tmp.data(), table_bytes, hipMemcpyHostToDevice);   // blocking: host_tmp may be reused at once
         if (e != hipSuccess) { (void)hipFree(ctx->pf_dev); ctx->pf_dev = nullptr; return hip_fail(ctx, e, "prefilter tables"); }
         ctx->pf_key[0] = size; ctx->pf_key[1] = mips; ctx->pf_key[2] = sky->mips;
     }
     const float4* tables = reinterpret_cast<const float4*>(ctx->pf_dev);
-    uint32_t* lossy = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->pf_dev) + table_bytes);   // 1 = the half copy is not exact
     uint32_t blocks = 0;
     for (uint32_t m = 1; m < mips; m++) {
         pl.count[m] = ctx->pf_count[m];
@@ -860,10 +873,19 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     }
     pl.first_block[mips] = blocks;
     const size_t foot_texels = padded_texels + 1;   // the half4 copy has the padded fp32 chain's layout (+ 1: the last row pair reads 8 bytes past a texel)
-    float4* padded = nullptr;
-    PBR_HIP(ctx, hipMallocAsync((void**)&padded, padded_texels * 16 + (use_foot ? foot_texels * 8 : 0), ctx->stream));
+    // one stream-ordered block per call: [16 bytes: the "half copy is lossy" word][padded fp32 chain][padded half chain].  The flag
+    // belongs to the CALL (round 3 kept one per context behind the cached tables: two calls of one context on different streams
+    // could race on it — ADVICE r03); it is zeroed in stream order in front of the kernel that raises it.
+    char* block = nullptr;
+    PBR_HIP(ctx, hipMallocAsync((void**)&block, 16 + padded_texels * 16 + (use_foot ? foot_texels * 8 : 0), ctx->stream));
+    uint32_t* lossy = reinterpret_cast<uint32_t*>(block);   // 1 = the half copy is not exact
+    float4* padded = reinterpret_cast<float4*>(block + 16);
     pbr_half* foot = use_foot ? reinterpret_cast<pbr_half*>(padded + padded_texels) : nullptr;
     pbr_status r = PBR_OK;
+    {
+        const hipError_t e = hipMemsetAsync(lossy, 0, 16, ctx->stream);
+        if (e != hipSuccess) r = hip_fail(ctx, e, "pbr_prefilter_env: flag reset");
+    }
     PfLevels fo{};
     PfPad pp{};
     pp.size = sky->size; pp.mips = sky->mips;
@@ -877,7 +899,7 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
         pad_blocks += ((uint64_t)6 * (sl + 2) * (sl + 2) + 255) / 256;
     }
     pp.first_block[sky->mips] = (uint32_t)pad_blocks;
-    if (pad_blocks > 0x7FFFFFFFull) r = pbr::fail(ctx, PBR_ERR_INVALID, "pbr_prefilter_env: sky cube too large");
+    if (r == PBR_OK && pad_blocks > 0x7FFFFFFFull) r = pbr::fail(ctx, PBR_ERR_INVALID, "pbr_prefilter_env: sky cube too large");
     if (r == PBR_OK) {
         hipLaunchKernelGGL(k_cube_pad_chain, dim3((unsigned)pad_blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(sky->data), padded, foot, pp, lossy);
         r = launched(ctx, "k_cube_pad_chain");
@@ -885,21 +907,22 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     if (r == PBR_OK && blocks) {
 #ifdef PBR_DEBUG_KNOBS
         if (wave_per_texel) hipLaunchKernelGGL(k_prefilter_fast, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
+        else if (force_f32) hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out);
         else
 #endif
-        if (use_foot) {   // both instances; the flag k_cube_pad_chain wrote picks the one that works, the other returns at once
+        {   // both instances; the flag k_cube_pad_chain wrote picks the one that works, the other returns at once
             hipLaunchKernelGGL(k_prefilter_foot<true>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)foot, fo, tables, pl, out, lossy);
             r = launched(ctx, "k_prefilter_foot<half>");
             if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_foot<false>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)padded, fo, tables, pl, out, lossy);
-        } else hipLaunchKernelGGL(k_prefilter_tex, dim3(blocks), dim3(256), 0, ctx->stream, padded, tables, pl, out, (const uint32_t*)nullptr);
+        }
         if (r == PBR_OK) r = launched(ctx, "k_prefilter_*");
     }
     if (r == PBR_OK) {
         const size_t n0 = (size_t)6 * size * size;
-        hipLaunchKernelGGL(k_prefilter_mip0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, padded, pl, out, use_foot ? lossy : (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_prefilter_mip0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, ctx->stream, padded, pl, out);
         r = launched(ctx, "k_prefilter_mip0");
     }
-    (void)hipFreeAsync(padded, ctx->stream);
+    (void)hipFreeAsync(block, ctx->stream);
     return r;
 }
 

@@ -15,7 +15,7 @@ struct pbr_ctx {
     size_t scratch_bytes = 0;
     std::string err;
     std::vector<float> host_tmp;      // host staging (prefilter sample tables)
-    // pbr_prefilter_env: the sample tables of the last (size, mips, sky mips) + the 16-byte "half copy is lossy" word behind them
+    // pbr_prefilter_env: the sample tables of the last (size, mips, sky mips), kept on the device between calls
     void* pf_dev = nullptr;
     uint32_t pf_key[3] = {0, 0, 0};
     uint32_t pf_count[16] = {};

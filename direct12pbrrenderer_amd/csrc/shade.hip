@@ -335,6 +335,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             };
             if (q_safe & 1) {
                 if (t_ok) { if (q_safe & 2) walk(std::true_type{}, std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::true_type{}, std::false_type{}); }
+                else if (q_safe & 2) walk(std::true_type{}, std::false_type{}, std::true_type{});   // a rough-enough wave is a property of the PIXELS, one polynomial of the SCENE: independent
                 else walk(std::true_type{}, std::false_type{}, std::false_type{});
             } else walk(std::false_type{}, std::false_type{}, std::false_type{});
         } else {

@@ -266,7 +266,7 @@ def test_host_graph_renders_the_reference_scene_lights(host, orc, tmp_path):
     assert cl["NumLights"].max() >= 1                                   # the scene's lights do reach clusters of this view
     tile = Tile(0, 0, W, H, W, H)
     want, _ = orc.deferred_shade(g, tile, gb, lut, env, ENV, 5, cl, lights)
-    no_lights, _ = orc.deferred_shade(g, tile, gb, lut, env, ENV, 5, cl, lights[:0])
+    no_lights, _ = orc.deferred_shade(g, tile, gb, lut, env, ENV, 5, orc.cluster_cull(g, lights[:0], orc.cluster_build(g)), lights[:0])
     lit = np.abs(want.astype(np.float32) - no_lights.astype(np.float32))[..., :3].max(axis=-1) > 1e-3
     assert lit.mean() > 0.02                                            # ... and light a visible share of the pixels
     sky_full = sky_np.copy()
