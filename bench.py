@@ -870,7 +870,7 @@ def main():
         achieved = kern["shade(in frame)"]["GB/s"]
         frame_bytes = sum(BYTES_PER_PX.values()) * spec.w * spec.h
         frame_gbps = frame_bytes / (res["ms_per_step"] * 1e-3) / 1e9
-        out["roofline"] = {"bound": "valu", "kernel": "k_deferred_shade",
+        out["roofline"] = {"bound": "hbm", "kernel": "k_deferred_shade", "kernel_limited_by": "valu",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                            "traffic": pmc_traffic("k_deferred_shade", shaded_px),
                            "hbm_measured_GBps": round(hbm_meas, 1), "frac_of_measured": round(achieved / hbm_meas, 5),
@@ -882,9 +882,10 @@ def main():
                            "stage_ms": {k: v["ms"] for k, v in kern.items()},
                            "stage_GBps": {k: v["GB/s"] for k, v in kern.items()},
                            "stage_frac_of_measured": {k: round(v["GB/s"] / hbm_meas, 4) for k, v in kern.items() if v["GB/s"]},
-                           "note": "dominant kernel = the shade, which with 256 clustered lights is bound by FP32 VALU ISSUE (bound: valu; the `valu` block "
-                                   "below prices it), so achieved / peak / frac — its ALGORITHMIC bytes (SURVEY 8d: 25 B/px) over its HIP-event launch duration "
-                                   "against HBM, as the schema asks — are structurally low; `frame` is the whole step against HBM; "
+                           "note": "dominant kernel = the shade, which with 256 clustered lights is bound by FP32 VALU ISSUE (kernel_limited_by: valu; the `valu` "
+                                   "block — same bound / achieved / peak / unit / frac shape — prices it), so this block's achieved / peak / frac — the kernel's "
+                                   "ALGORITHMIC bytes (SURVEY 8d: 25 B/px) over its HIP-event launch duration against HBM, which is what the schema's "
+                                   "bound: hbm | mfma offers for a kernel without MFMA — are structurally low; `frame` is the whole step against HBM; "
                                    "hbm_measured_GBps = pbr_membench_read streaming 2 GiB on this device; "
                                    "stage_GBps of the fused bloom is EFFECTIVE (the 16 reference passes' bytes / the fused launches' time), not traffic; "
                                    "traffic (when present) is the committed rocprofv3 PMC figure for this workload and this version of shade.hip, "
@@ -901,7 +902,9 @@ def main():
             #    those costs: the time the VALU needs to ISSUE the kernel's instructions, as a share of the launch.
             nv = sq["SQ_INSTS_VALU"]
             rate = nv / (shade_ms_in_frame * 1e-3)
-            valu = {"wave_insts_per_launch": nv, "achieved_Ginst_s": round(rate / 1e9, 1),
+            valu = {"bound": "valu", "achieved": round(rate / 1e9, 1), "peak": round(N_SIMD * CLOCK_HZ / 2.0 / 1e9, 1), "unit": "Ginst/s (wave64 VALU instructions)",
+                    "frac": round(rate / (N_SIMD * CLOCK_HZ / 2.0), 3),
+                    "wave_insts_per_launch": nv, "achieved_Ginst_s": round(rate / 1e9, 1),
                     "spec_peak_Ginst_s": round(N_SIMD * CLOCK_HZ / 2.0 / 1e9, 1), "frac_of_spec": round(rate / (N_SIMD * CLOCK_HZ / 2.0), 3),
                     "measured_plain_peak_Ginst_s": round(N_SIMD * MEASURED_CLOCK_HZ / MEASURED_CYCLES["plain"] / 1e9, 1),
                     "frac_of_measured_plain": round(rate / (N_SIMD * MEASURED_CLOCK_HZ / MEASURED_CYCLES["plain"]), 3),

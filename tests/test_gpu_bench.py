@@ -26,3 +26,11 @@ def test_bench_prints_one_json_line(extra, n):
     assert KEYS <= set(rec) and rec["n_gpus"] == n and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0
     assert rec["config"]["clock_settle_frames"] == 5 and "workload" in rec["config"]
     assert rec["roofline"]["bound"] in ("hbm", "mfma") and rec["roofline"]["achieved"] > 0
+    assert "roughness" in rec["config"]["workload"] and "attenuation preset" in rec["config"]["workload"]     # the headline says what it timed
+    fr = rec["roofline"]["frame"]
+    assert rec["roofline"]["kernel_limited_by"] == "valu" and fr["bytes"] > 0 and 0 < fr["frac"] < 1 and abs(fr["GBps"] * rec["ms_per_step"] * 1e6 - fr["bytes"]) < 1e-2 * fr["bytes"]
+    if n == 1:
+        ab = rec["shade_ms_by_path"]
+        assert set(ab) >= {"as_shipped", "roughness_0_255", "two_attenuation_presets", "roughness_0_255_and_two_presets"}, ab
+        lp = {k: v["mean_lights_per_pixel"] for k, v in ab.items() if isinstance(v, dict)}
+        assert max(lp.values()) - min(lp.values()) < 0.02, lp      # the variants differ in the walk instantiation, not in the work
