@@ -54,6 +54,7 @@ SIGNATURES = {
     "pbr_blur_h": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32]),
     "pbr_blur_v": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32]),
     "pbr_bloom_upsample_add": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp]),
+    "pbr_bloom_up_level": (_int, [_vp, _vp, _vp, _u32, _u32, _vp, _u32, _u32]),
     "pbr_bloom_merge": (_int, [_vp, _vp, _u32, _vp, _u32, _u32]),
     "pbr_bloom": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _f32, _f32]),
     "pbr_bloom_prefilter_rect": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _u32, _u32, _u32, C.POINTER(_u32 * 4), _f32, _f32]),

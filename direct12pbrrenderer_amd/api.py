@@ -211,6 +211,10 @@ class PbrContext:
     def blur_v(self, src, iw, ih, out, ow, oh):
         self._check(self.lib.pbr_blur_v(self.h, _ptr(src), iw, ih, _ptr(out), ow, oh))
 
+    def bloom_up_level(self, upper, lower, lw, lh, out, ow, oh):
+        """out = V(H(upper) + H(lower at out's size)) — one fused upsample level (upper may be None)"""
+        self._check(self.lib.pbr_bloom_up_level(self.h, _ptr(upper) if upper is not None else None, _ptr(lower), lw, lh, _ptr(out), ow, oh))
+
     def bloom_upsample_add(self, upper, uw, uh, lower, lw, lh, out):
         self._check(self.lib.pbr_bloom_upsample_add(self.h, _ptr(upper), uw, uh, _ptr(lower), lw, lh, _ptr(out)))
 

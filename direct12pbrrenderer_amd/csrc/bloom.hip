@@ -844,6 +844,209 @@ __global__ __launch_bounds__(512, TH == 16 ? 6 : 4) void k_blur_up_wide(const pb
     }
 }
 
+// ---------------------------------------------------------------- 2x-up levels, POLYPHASE form (round 4)
+// k_blur_up_wide evaluates what the shader evaluates: every one of the nine taps of a fine-grid output is a bilinear 2x-up
+// sample of the coarse level (weights 1/4 | 3/4 in x and in y), 9 taps x (TH + 8) fine rows.  The upsample and the blur are both
+// linear and the upsample's weights are periodic, so the H blur of the upsampled row is two FIXED six-tap filters on the COARSE
+// row — even outputs 2p tap c[p-3 .. p+2], odd outputs 2p+1 tap c[p-2 .. p+3] (coefficients below) — and the y half of the
+// bilinear sample commutes with the H blur: filter the ~TH/2 + 6 coarse rows once, THEN blend neighbouring filtered rows with
+// 1/4 | 3/4 into the fine rows.  Per fine output and channel that is ~6 x 22/40 + 2 multiply-adds for the H pass instead of
+// 9 + the four of the bilinear sample, a lane loads ONE coarse texel per coarse row (k_blur_up_wide: three per row for its
+// column pair) and reads seven 8-byte LDS entries per coarse row instead of fifteen per fine row.
+// Not the shader's operation order, hence not bit-identical to the oracle: the fp32 value in front of the H pass's fp16 store
+// differs by a few fp32 ulps, i.e. the stored fp16 texel differs by one fp16 ULP on ~5e-5 of the texels (SURVEY 8c allows <= 1
+// fp16 ULP per bloom stage; tests/test_gpu_parity.py holds every stage to that and the whole chain to <= 2).  The sum is rounded to
+// fp16 exactly where bloom_upsample_add / blur_horizontal store it, the V pass and the tail are k_blur_up_wide's, unchanged.
+// Clamp addressing: a tap outside the coarse level reads the edge texel — the same linear map as the shader's clamp of the
+// sample position (every fine position outside the level samples the pure edge texel either way).
+namespace poly {
+constexpr double G[9] = {0.0148, 0.0459, 0.1050, 0.1941, 0.2803, 0.1941, 0.1050, 0.0459, 0.0148};   // blur.hlsli:17
+constexpr double g(int k) { return (k < -4 || k > 4) ? 0.0 : G[k + 4]; }
+// coefficient of c[p + j] in the EVEN output 2p: sum_k g(k) * [weight of c[p + j] in the 2x-up sample at fine position 2p + k];
+// the odd output 2p + 1 takes c[p + j] with E(-j)   (j = -3 .. 2 resp. -2 .. 3; both sets sum to 0.9999 like the nine weights)
+constexpr float E(int j) { return (float)(0.75 * g(2 * j) + 0.25 * g(2 * j + 2) + 0.75 * g(2 * j + 1) + 0.25 * g(2 * j - 1)); }
+}  // namespace poly
+
+template <bool DUAL, int TAIL, int TH>
+__global__ __launch_bounds__(512, 4) void k_blur_up_poly(const pbr_half* __restrict__ in, int iw, int ih,
+                                                          const pbr_half* __restrict__ in2,   // DUAL: ow x oh, same-size
+                                                          pbr_half* __restrict__ out, int ow, int oh, int out_pitch,
+                                                          int tiles_x, int n_tiles,
+                                                          TailRect tr, float min_log, float inv_range,
+                                                          uint32_t* __restrict__ hist) {
+    constexpr int TW = 128, NP = TW / 2 + 4, NC = TW / 2 + 6, SR = TH + 8, NT = 512, NW = NT / 64;
+    constexpr int NPAIR = TH / 2 + 5;                 // coarse row pairs (m, m + 1) whose two blends (fine rows 2m + 1, 2m + 2) the tile's SR rows need
+    constexpr int PPW = (NPAIR + NW - 1) / NW;        // pairs per wave; wave w: pairs w * PPW .. (the last waves may hold fewer, or none)
+    constexpr int PER_O = TH / 4;                     // V outputs per thread: column t & 127, rows (t >> 7) * PER_O ..
+    static_assert(TH % 4 == 0 && (PPW + 1) * 6 <= 64 && 2 * PPW * 4 <= 64, "one halo entry per lane");
+    __shared__ H4 sLineC[NW][NC + 2];                 // one coarse row per wave at a time: entry e = coarse column x0 / 2 - 3 + e
+    __shared__ float2 sLineU[DUAL ? NW : 1][3][NP];   // DUAL: the same-size input's fine row as column pairs (k_blur_up_wide's line)
+    __shared__ H4 sT[SR][TW];
+    __shared__ uint32_t sh_hist[TAIL == 2 ? NW : 1][TAIL == 2 ? PBR_HISTOGRAM_BINS : 1];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int vc = t & 127, vg = __builtin_amdgcn_readfirstlane(t >> 7);
+    if (TAIL == 2) {
+        for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += NT) (&sh_hist[0][0])[i] = 0u;
+    }
+    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[0].w);
+    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[0].w);
+    const h16 alpha_t = to_half_rn(alpha_h);
+    const float alpha_v = gauss9_const((float)alpha_t);
+    const float a0w = (float)to_half_rn(alpha_v);
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int x0 = (TAIL != 0 ? tr.tx0 + tile % tiles_x : tile % tiles_x) * TW, y0 = (TAIL != 0 ? tr.ty0 + tile / tiles_x : tile / tiles_x) * TH;
+    const int xv = x0 + vc, rbase = vg * PER_O;
+    H4 hdr_in[PER_O];
+    const bool in_mx = TAIL != 0 && xv >= tr.mx0 && xv < tr.mx1;
+    char* const hdr_row0 = reinterpret_cast<char*>(out) + (ptrdiff_t)(y0 + rbase - tr.by) * out_pitch * 8;
+    const uint32_t hdr_x = (uint32_t)(xv - tr.bx) * 8u;
+    const size_t hdr_pitch = (size_t)out_pitch * 8u;
+    // ---- H pass.  Wave w owns the coarse row pairs i = w * PPW .. + PPW - 1 (i < NPAIR): coarse rows cb + i and cb + i + 1, cb = y0 / 2 - 3;
+    // pair i blends into the tile's fp16 rows 2i - 1 (fine row y0 - 5 + 2i, odd) and 2i (even); rows -1 and SR do not exist.
+    {
+        const int i_first = wv * PPW;
+        const int n_pairs = min(PPW, NPAIR - i_first);                        // wave-uniform; <= 0: nothing to do for this wave
+        const int cb = (y0 >> 1) - 3 + i_first;                               // first coarse row of the wave
+        const uint32_t ccol = (uint32_t)clampi((x0 >> 1) - 3 + lane, 0, iw - 1) * 8u;
+        H4 cr[PPW + 1], chalo{};                                              // the wave's coarse rows at this lane's column; one halo entry
+        const int hk = lane / 6, hq = 64 + lane % 6;                          // halo: lane -> (row lane / 6, entry 64 + lane % 6), lanes 0 .. 6 (PPW + 1) - 1
+        const bool has_halo = lane < 6 * (PPW + 1);
+        H4 upE[DUAL ? 2 * PPW : 1], upO[DUAL ? 2 * PPW : 1], hupE{}, hupO{};
+        const int uk = lane >> 2, uq = 64 + (lane & 3);                       // DUAL halo: lane -> (fine row lane / 4 of the wave's 2 PPW, pair entry 64 + lane % 4)
+        const bool has_uhalo = DUAL && lane < 8 * PPW;
+        if (n_pairs > 0) {
+#pragma unroll
+            for (int k = 0; k <= PPW; k++) {
+                const char* row = reinterpret_cast<const char*>(in) + (size_t)clampi(cb + k, 0, ih - 1) * iw * 8u;   // wave-uniform: a scalar base
+                cr[k] = ld_h4(row, ccol);
+            }
+            if (has_halo) {
+                const char* row = reinterpret_cast<const char*>(in) + (size_t)clampi(cb + hk, 0, ih - 1) * iw * 8u;
+                chalo = ld_h4(row, (uint32_t)clampi((x0 >> 1) - 3 + hq, 0, iw - 1) * 8u);
+            }
+            if (DUAL) {
+                const int sxe = clampi(x0 - 4 + 2 * lane, 0, ow - 1), sxo = clampi(x0 - 3 + 2 * lane, 0, ow - 1);
+#pragma unroll
+                for (int k = 0; k < 2 * PPW; k++) {   // fine rows of the wave: tile row 2 i_first - 1 + k
+                    const char* row = reinterpret_cast<const char*>(in2) + (size_t)clampi(y0 - 4 + 2 * i_first - 1 + k, 0, oh - 1) * ow * 8u;
+                    upE[k] = ld_h4(row, (uint32_t)sxe * 8u); upO[k] = ld_h4(row, (uint32_t)sxo * 8u);
+                }
+                if (has_uhalo) {
+                    const uint32_t row = (uint32_t)(clampi(y0 - 4 + 2 * i_first - 1 + uk, 0, oh - 1) * ow) * 8u;
+                    hupE = ld_h4(in2, row + (uint32_t)clampi(x0 - 4 + 2 * uq, 0, ow - 1) * 8u); hupO = ld_h4(in2, row + (uint32_t)clampi(x0 - 3 + 2 * uq, 0, ow - 1) * 8u);
+                }
+            }
+        }
+        // the HDR texels of the merge: issued AFTER the level's texels (loads return in order), consumed after the H pass
+        if (TAIL != 0) {
+#pragma unroll
+            for (int k = 0; k < PER_O; k++) {
+                const int y = y0 + rbase + k;
+                if (in_mx && y >= tr.my0 && y < tr.my1) hdr_in[k] = ld_h4(hdr_row0 + k * hdr_pitch, hdr_x);
+            }
+        }
+        if (n_pairs > 0) {
+            H4* line = sLineC[wv];
+            float2 (*lineU)[NP] = sLineU[DUAL ? wv : 0];
+            V3 pE = v3(0.0f, 0.0f, 0.0f), pO = pE;   // the previous coarse row, H-filtered: even / odd fine column of the lane
+#pragma unroll
+            for (int k = 0; k <= PPW; k++) {
+                if (k > n_pairs) break;              // wave-uniform
+                line[lane] = cr[k];
+                if (has_halo && hk == k) line[hq] = chalo;
+                wave_sync();
+                V3 e[7];
+#pragma unroll
+                for (int j = 0; j < 7; j++) e[j] = h3f(line[lane + j]);
+                wave_sync();
+                // even output 2p: c[p-3 .. p+2] = e[0 .. 5] with E(-3 .. 2); odd output 2p + 1: c[p-2 .. p+3] = e[1 .. 6] with E(2 .. -3)
+                constexpr float PE[6] = {poly::E(-3), poly::E(-2), poly::E(-1), poly::E(0), poly::E(1), poly::E(2)};
+                V3 cE = v3(0.0f, 0.0f, 0.0f), cO = cE;
+#pragma unroll
+                for (int j = 0; j < 6; j++) { cE = fma3(e[j], PE[j], cE); cO = fma3(e[j + 1], PE[5 - j], cO); }
+                if (k > 0) {
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int r = 2 * (i_first + k - 1) - 1 + half;      // tile row of this blend (wave-uniform)
+                        if (r < 0 || r >= SR) continue;
+                        // fine row 2m + 1: (m, m + 1) with second-tap weight 1/4; fine row 2m + 2: 3/4 (tap1d<M_UP>; the sampler's lerp form)
+                        const float fy = half ? 0.75f : 0.25f, wy0 = 1.0f - fy;
+                        V3 bE = fma3(cE, fy, pE * wy0), bO = fma3(cO, fy, pO * wy0);
+                        if (DUAL) {   // bloom_upsample_add: lower first, then upper — the same-size input's nine taps on this fine row
+                            const int u = 2 * (k - 1) + half;
+                            lineU[0][lane] = make_float2((float)upE[u].x, (float)upO[u].x); lineU[1][lane] = make_float2((float)upE[u].y, (float)upO[u].y);
+                            lineU[2][lane] = make_float2((float)upE[u].z, (float)upO[u].z);
+                            if (has_uhalo && uk == u) {
+                                lineU[0][uq] = make_float2((float)hupE.x, (float)hupO.x); lineU[1][uq] = make_float2((float)hupE.y, (float)hupO.y);
+                                lineU[2][uq] = make_float2((float)hupE.z, (float)hupO.z);
+                            }
+                            wave_sync();
+                            V3 uE, uO;
+                            gauss9_pair(lineU[0] + lane, uE.x, uO.x); gauss9_pair(lineU[1] + lane, uE.y, uO.y); gauss9_pair(lineU[2] + lane, uE.z, uO.z);
+                            wave_sync();
+                            bE = bE + uE; bO = bO + uO;
+                        }
+                        struct alignas(16) H8 { H4 a, b; } th;   // the H pass's fp16 store, both columns of the lane
+                        th.a.x = to_half_rn(bE.x); th.a.y = to_half_rn(bE.y); th.a.z = to_half_rn(bE.z); th.a.w = alpha_t;
+                        th.b.x = to_half_rn(bO.x); th.b.y = to_half_rn(bO.y); th.b.z = to_half_rn(bO.z); th.b.w = alpha_t;
+                        *reinterpret_cast<H8*>(&sT[r][2 * lane]) = th;
+                    }
+                }
+                pE = cE; pO = cO;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- V-gauss over a sliding window of the fp16 tile + tail (k_blur_up_wide's)
+    {
+        H4 win[PER_O + 8];
+#pragma unroll
+        for (int i = 0; i < PER_O + 8; i++) win[i] = sT[rbase + i][vc];
+#pragma unroll
+        for (int k = 0; k < PER_O; k++) {
+            const int y = y0 + rbase + k;
+            if (xv >= ow || y >= oh) continue;
+            V3 a3 = v3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int i = 0; i < 9; i++) a3 = fma3(h3f(win[k + i]), c_gauss[i], a3);
+            const F4 a = f4(a3.x, a3.y, a3.z, alpha_v);
+            if (TAIL == 0) {
+                store_h4(out + 4 * ((size_t)y * out_pitch + xv), a);
+            } else {
+                if (!(in_mx && y >= tr.my0 && y < tr.my1)) continue;
+                const half2v a01 = round_h2(a3.x, a3.y);
+                const h16 a2 = to_half_rn(a3.z);
+                const F4 s = h4f(hdr_in[k]);
+                struct alignas(8) O4 { half2v lo, hi; } o;
+                o.lo = round_h2(s.x + (float)a01.x, s.y + (float)a01.y);
+                o.hi = round_h2(s.z + (float)a2, s.w + a0w);
+                *reinterpret_cast<O4*>(hdr_row0 + k * hdr_pitch + hdr_x) = o;
+                if (TAIL == 2) {
+                    if (xv >= tr.hx0 && xv < tr.hx1 && y >= tr.hy0 && y < tr.hy1)
+                        atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.lo.x, (float)o.lo.y, (float)o.hi.x, min_log, inv_range)], 1u);
+                }
+            }
+        }
+    }
+    if (tile + (int)gridDim.x < n_tiles) __syncthreads();   // the next tile overwrites sT
+    }
+    if (TAIL == 2) {
+        __syncthreads();
+        for (int i = t; i < PBR_HISTOGRAM_BINS; i += NT) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) sum += sh_hist[w2][i];
+            if (sum) atomicAdd(&hist[i], sum);
+        }
+    }
+}
+
 // rows a k_blur_h block pipelines: as many as keep >= ~2048 blocks (8 per CU) in the grid
 static int blur_h_rows(uint32_t ow, uint32_t oh) {
     const uint64_t row_blocks = (uint64_t)((ow + 255) / 256) * oh;
@@ -883,18 +1086,24 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
         const int wtiles_x = (tr.mx1 + 127) / 128 - wtx0, wn = wtiles_x * ((tr.my1 + 31) / 32 - wty0);
         if (wide_forced >= 0 ? wide_forced == 1 : wn >= 400) {
             tr.tx0 = wtx0; tr.ty0 = wty0;
-#ifdef PBR_DEBUG_KNOBS
-            if (wide_th == 16) {
+#ifdef PBR_DEBUG_KNOBS   // the shader-order (bit-identical) kernel of round 3: A/B partner and checker, PBR_BLOOM_POLY=0
+            static const bool poly_off = pbr::knob_int("PBR_BLOOM_POLY", 1) == 0;
+            if (poly_off && wide_th == 16) {
                 tr.ty0 = tr.my0 / 16;
                 const int wn16 = wtiles_x * ((tr.my1 + 15) / 16 - tr.ty0);
                 hipLaunchKernelGGL((k_blur_up_wide<DUAL, TAIL, 16>), dim3(TAIL == 2 ? even_blocks(wn16) : wn16), dim3(512), 0, ctx->stream,
                                    in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, wtiles_x, wn16, tr, min_log, inv_range, hist);
                 return launched(ctx, "k_blur_up_wide<16>");
             }
+            if (poly_off) {
+                hipLaunchKernelGGL((k_blur_up_wide<DUAL, TAIL, 32>), dim3(TAIL == 2 ? even_blocks(wn) : wn), dim3(512), 0, ctx->stream,
+                                   in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, wtiles_x, wn, tr, min_log, inv_range, hist);
+                return launched(ctx, "k_blur_up_wide");
+            }
 #endif
-            hipLaunchKernelGGL((k_blur_up_wide<DUAL, TAIL, 32>), dim3(TAIL == 2 ? even_blocks(wn) : wn), dim3(512), 0, ctx->stream,
+            hipLaunchKernelGGL((k_blur_up_poly<DUAL, TAIL, 32>), dim3(TAIL == 2 ? even_blocks(wn) : wn), dim3(512), 0, ctx->stream,
                                in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, wtiles_x, wn, tr, min_log, inv_range, hist);
-            return launched(ctx, "k_blur_up_wide");
+            return launched(ctx, "k_blur_up_poly");
         }
     }
     // 64 x 32 tiles (512 threads) when the level is large enough to fill the chip that way, 64 x 16 below (PBR_BLOOM_TILE=16: on 4 waves)
@@ -1029,6 +1238,16 @@ pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pb
     dim3 grid((w + 255) / 256, h);
     hipLaunchKernelGGL(k_bloom_merge, grid, dim3(256), 0, ctx->stream, hdr, (int)pitch, in, (int)w, (int)h);
     return launched(ctx, "k_bloom_merge");
+}
+
+pbr_status pbr_bloom_up_level(pbr_ctx* ctx, const pbr_half* upper, const pbr_half* lower, uint32_t lw, uint32_t lh,
+                              pbr_half* out, uint32_t ow, uint32_t oh) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, lower && out && out != lower && out != upper, "pbr_bloom_up_level: null pointer / out aliases an input");
+    PBR_REQUIRE(ctx, lw >= 1 && lh >= 1 && ow == 2 * lw && oh == 2 * lh && exact_half(ow) && exact_half(oh), "pbr_bloom_up_level: out must be exactly twice lower, even, <= 8192");
+    if (force_staged()) return pbr::fail(ctx, PBR_ERR_UNSUPPORTED, "pbr_bloom_up_level: PBR_BLOOM_STAGED is set");
+    if (upper) return launch_hv<M_UP, true, 0>(ctx, lower, lw, lh, upper, out, ow, oh, ow, nullptr, 0.0f, 0.0f, nullptr);
+    return launch_hv<M_UP, false, 0>(ctx, lower, lw, lh, nullptr, out, ow, oh, ow, nullptr, 0.0f, 0.0f, nullptr);
 }
 
 static pbr_status bloom_final(pbr_ctx* ctx, const pbr_half* b0, pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,

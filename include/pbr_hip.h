@@ -293,8 +293,18 @@ pbr_status pbr_bloom_upsample_add(pbr_ctx* ctx, const pbr_half* upper, uint32_t 
 /* bloom_merge.hlsl:7-11: hdr += in (both w x h; hdr pitch in pixels). */
 pbr_status pbr_bloom_merge(pbr_ctx* ctx, pbr_half* hdr, uint32_t pitch, const pbr_half* in,
                            uint32_t w, uint32_t h);
-/* BloomPass::Execute (DeferredPipeline.cpp:400-570), all 16 dispatches: hdr is bit-identical to the sequence of
- * stage calls above.  chain_a / chain_b: pbr_bloom_chain_texels(w,h) half4 texels each (BloomMipchain /
+/* One upsample level of BloomPass::Execute as ONE call (DeferredPipeline.cpp:472-540: the `Upsample Horizontal Add` +
+ * `Blur Vertical` pair; with upper == NULL the `Upsample Merge` pair blur_horizontal + blur_vertical, :541-559, without the merge):
+ *   out = V( H(upper) + H(lower sampled at out's size) )        out, upper: ow x oh;  lower: lw x lh, ow == 2 lw, oh == 2 lh
+ * — the fused kernel pbr_bloom runs for such a level pair, exposed for stage-level tests and hosts that fuse the pair.  The H
+ * result is rounded to fp16 where the first dispatch stores it.  Levels of >= 400 tiles of 128 x 32 texels take the polyphase
+ * form of the 2x-up blur (csrc/bloom.hip: k_blur_up_poly): <= 1 fp16 ULP from the two staged calls (SURVEY 8c's bloom-stage
+ * tolerance), not bit-identical; smaller levels are bit-identical.  Sizes must be even and <= 8192; out must not alias an input. */
+pbr_status pbr_bloom_up_level(pbr_ctx* ctx, const pbr_half* upper, const pbr_half* lower, uint32_t lw, uint32_t lh,
+                              pbr_half* out, uint32_t ow, uint32_t oh);
+/* BloomPass::Execute (DeferredPipeline.cpp:400-570), all 16 dispatches.  hdr is bit-identical to the sequence of stage calls
+ * above for frames below ~1.6 Mpixel; from there on the large 2x-up levels run in polyphase form (pbr_bloom_up_level) and hdr
+ * is within 2 fp16 ULP of that sequence (>= 99.9 % of the texels identical).  chain_a / chain_b: pbr_bloom_chain_texels(w,h) half4 texels each (BloomMipchain /
  * BloomTempTexture) — SCRATCH: their contents after the call are unspecified.  (Wherever a level is exactly half
  * the one above and at most 8192 wide/high, the H and V pass of that level pair run as one kernel and the H result
  * is never written; elsewhere the staged kernels run.  Level 0 of chain_a — the V blur the merge consumes — is

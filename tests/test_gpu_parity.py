@@ -891,9 +891,19 @@ sys.path.insert(0, %r); sys.path.insert(0, %r)
 from oracle import binding as orc
 from direct12pbrrenderer_amd import synth
 from direct12pbrrenderer_amd.api import PbrContext
+import common
+EXACT = %r
 ctx = PbrContext(0)
 up = lambda a: ctx.upload(np.ascontiguousarray(a, dtype=np.float16).view(np.uint16)).view(torch.float16)
 down = lambda t: t.cpu().view(torch.int16).numpy().view(np.float16)
+def same(got, want, what):
+    # EXACT: the shader-order kernels, bit for bit.  Otherwise the polyphase 2x-up kernel ran somewhere in the chain: every texel
+    # within 2 fp16 ULP of the oracle's staged chain end to end, and all but a sliver identical
+    if EXACT:
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (what, int((got.view(np.uint16) != want.view(np.uint16)).sum()))
+    else:
+        d = common.half_ulp_diff(got[..., :3], want[..., :3])
+        assert d.max() <= 2 and (d > 0).mean() <= 2e-3 and (d > 1).mean() <= 1e-4, (what, int(d.max()), float((d > 0).mean()), float((d > 1).mean()))
 for (w, h) in %r:
     img = synth.hdr_noise_image(w, h, seed=w + h)
     want = img.copy()
@@ -902,13 +912,13 @@ for (w, h) in %r:
     hdr, hist = up(img), ctx.zeros((256,), torch.int32)
     ctx.bloom_histogram(hdr, w, h, w, ca, cb, (0, 0, w, h), hist)
     got = down(hdr)
-    assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), ("bloom+histogram", w, h, int((got.view(np.uint16) != want.view(np.uint16)).sum()))
+    same(got, want, ("bloom+histogram", w, h))
     ref = ctx.zeros((256,), torch.int32)
     ctx.lum_histogram(hdr, w, h, w, ref)
     assert np.array_equal(hist.cpu().numpy(), ref.cpu().numpy()), ("histogram", w, h)
     hdr2 = up(img)
     ctx.bloom(hdr2, w, h, w, ca, cb)
-    assert np.array_equal(down(hdr2).view(np.uint16), want.view(np.uint16)), ("bloom", w, h)
+    assert np.array_equal(down(hdr2).view(np.uint16), got.view(np.uint16)), ("bloom without histogram = bloom with", w, h)
     # a histogram rectangle that is not the frame
     hdr3, hist3, ref3 = up(img), ctx.zeros((256,), torch.int32), ctx.zeros((256,), torch.int32)
     rect = (w // 8, h // 16, w // 2 + 3, h // 2 + 1)
@@ -917,34 +927,49 @@ for (w, h) in %r:
     sub = down(hdr3)[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]]
     ctx.lum_histogram(up(sub), rect[2], rect[3], rect[2], ref3)
     assert np.array_equal(hist3.cpu().numpy(), ref3.cpu().numpy()), ("histogram rect", w, h)
+    # ONE upsample level as a stage (pbr_bloom_up_level) on the oracle's own inputs: <= 1 fp16 ULP (EXACT: 0) from the two staged dispatches
+    if w %% 4 == 0 and h %% 4 == 0:
+        lower = synth.hdr_noise_image(w // 2, h // 2, seed=3 * w + h)
+        for upper in (synth.hdr_noise_image(w, h, seed=w + 7 * h), None):
+            out = ctx.zeros((h, w, 4), torch.float16)
+            ctx.bloom_up_level(up(upper) if upper is not None else None, up(lower), w // 2, h // 2, out, w, h)
+            b = orc.bloom_upsample_add(upper, lower) if upper is not None else orc.blur_h(lower, w, h)
+            want_l = orc.blur_v(b, w, h)
+            d = common.half_ulp_diff(down(out), want_l)
+            assert d.max() <= (0 if EXACT else 1) and (d > 0).mean() <= 1e-3, ("up level", w, h, upper is not None, int(d.max()), float((d > 0).mean()))
 ctx.close()
 print("wide bloom ok")
 """
 
 
 @pytest.mark.gpu
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("force,sizes", [
-    ("1", [(2048, 64), (1040, 48), (512, 288), (304, 176), (320, 180), (96, 32), (400, 304), (160, 2080)]),
-    ("0", [(512, 288), (2080, 1296)]),
-    ("", [(2080, 1296), (3328, 2048)]),
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("knobs,exact,sizes", [
+    ({"PBR_BLOOM_WIDE": "1"}, False, [(2048, 64), (1040, 48), (512, 288), (304, 176), (320, 180), (96, 32), (400, 304), (160, 2080)]),
+    ({"PBR_BLOOM_WIDE": "1", "PBR_BLOOM_POLY": "0"}, True, [(2048, 64), (1040, 48), (512, 288), (304, 176), (320, 180), (96, 32), (400, 304), (160, 2080)]),
+    ({"PBR_BLOOM_WIDE": "0"}, True, [(512, 288), (2080, 1296)]),
+    ({}, False, [(2080, 1296), (3328, 2048)]),
 ])
-def test_bloom_wide_2x_up_kernel_bit_exact(force, sizes):
-    """k_blur_up_wide (128-wide tiles, two columns per lane; what 2x-up levels of >= 400 such tiles take) against the
-    oracle's staged chain, bit for bit: forced on at small and ragged sizes (every M_UP level of the pyramid then runs
-    it: widths below one tile, widths that are no multiple of 128, a 5-texel-wide level, image edges inside the first
-    and last rows of waves), forced off (k_blur_hv at a size that would pick it), and chosen by the threshold —
-    2080x1296: the final level only; 3328x2048: level 1 (DUAL instance) as well.  The switch is read once per process,
-    hence the child process."""
+def test_bloom_2x_up_levels_polyphase_and_shader_order(knobs, exact, sizes):
+    """The 2x-up levels of the bloom pyramid against the oracle's staged chain.  Large levels (>= 400 tiles of 128 x 32) run
+    k_blur_up_poly, the polyphase form (two six-tap filters on the coarse row, then the 1/4 | 3/4 row blend): held to SURVEY 8c's
+    bloom-stage tolerance — each level as a stage (pbr_bloom_up_level, on the oracle's own inputs) <= 1 fp16 ULP, the whole chain
+    <= 2 ULP end to end with >= 99.8 % of the texels identical — where round 3 demanded bit-exactness.  The shader-order kernels
+    stay the bit-exact checker: k_blur_up_wide (knobs build, PBR_BLOOM_POLY=0) and k_blur_hv (PBR_BLOOM_WIDE=0), bit for bit.
+    Forced on at small and ragged sizes every M_UP level of the pyramid runs the wide kernels: widths below one tile, widths that
+    are no multiple of 128, a 5-texel-wide level, image edges inside the first and last rows of waves.  Product library, chosen by
+    the threshold — 2080x1296: the final level only; 3328x2048: level 1 (DUAL instance) as well.  The switches are read once per
+    process and exist in the knobs build only (the product library never reads the environment), hence the child process."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env.pop("PBR_BLOOM_WIDE", None)
-    if force:   # the switch exists in the knobs build only (the product library never reads the environment)
-        env["PBR_BLOOM_WIDE"] = force
+    for k in ("PBR_BLOOM_WIDE", "PBR_BLOOM_POLY"):
+        env.pop(k, None)
+    if knobs:
+        env.update(knobs)
         env["PBR_HIP_LIB"] = os.path.join(root, "direct12pbrrenderer_amd", "libpbr_hip_knobs.so")
         assert os.path.exists(env["PBR_HIP_LIB"]), "build with make -C direct12pbrrenderer_amd/csrc (target knobs)"
-    r = subprocess.run(["timeout", "-k", "10", "500", sys.executable, "-c", _WIDE_BLOOM % (root, os.path.join(root, "tests"), sizes)],
+    r = subprocess.run(["timeout", "-k", "10", "800", sys.executable, "-c", _WIDE_BLOOM % (root, os.path.join(root, "tests"), exact, sizes)],
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "wide bloom ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 

@@ -6,9 +6,9 @@ tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 if [ "$2" = "quick" ]; then
-  timeout -k 10 900 python -m pytest tests/test_host_graph.py tests/test_gpu_comm.py -m gpu -x -q -s > $out/${tag}_pytest_gpu.log 2>&1; rc=$?
+  timeout -k 10 900 python -m pytest tests/test_host_graph.py tests/test_gpu_comm.py -m gpu -x -q -s -rs > $out/${tag}_pytest_gpu.log 2>&1; rc=$?
 else
-  timeout -k 10 1100 python -m pytest tests -m gpu -x -q -s > $out/${tag}_pytest_gpu.log 2>&1; rc=$?
+  timeout -k 10 1100 python -m pytest tests -m gpu -x -q -s -rs > $out/${tag}_pytest_gpu.log 2>&1; rc=$?
 fi
 tail -n 15 $out/${tag}_pytest_gpu.log
 [ $rc -eq 0 ] || exit $rc
