@@ -131,7 +131,8 @@ class HostRenderer:
         self._check(self.lib.pbrh_set_frames_in_flight(self.h, int(k)))
 
     def set_tail_overlap(self, on):
-        self._check(self.lib.pbrh_set_tail_overlap(self.h, 1 if on else 0))
+        """0 / False: off; 1 / True: from the average-luminance dispatch; 2: from the bloom pass (frames without a halo exchange)"""
+        self._check(self.lib.pbrh_set_tail_overlap(self.h, int(on)))
 
     def comm_init(self, world, rank, unique_id):
         buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None

@@ -136,19 +136,24 @@ void HipCommandList::WaitIdle() {
     if (mTailOverlap) Check(pbr_ctx_side_join(mCtx), "pbr_ctx_side_join");
 }
 void HipCommandList::SetFramesInFlight(uint32 k) {
+    if (k > 8) throw HipException("SetFramesInFlight: at most 8");   // refused BEFORE any state is touched: the renderer keeps its mode
     WaitIdle();
     for (hipEvent_t e : mFrameFence) (void)hipEventDestroy(e);
     mFrameFence.clear();
     mFrameIndex = 0;
-    if (k <= 1) return;   // the reference's per-frame fence wait
-    if (k > 8) throw HipException("SetFramesInFlight: at most 8");
+    if (k <= 1) {          // the reference's per-frame fence wait: there is no next frame to overlap a tail with
+        mTailOverlap = 0;
+        return;
+    }
     mFrameFence.resize(k, nullptr);
     for (hipEvent_t& e : mFrameFence) ThrowIfFailed(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
 }
-void HipCommandList::SetTailOverlap(bool on) {
+void HipCommandList::SetTailOverlap(int mode) {
+    if (mode < 0 || mode > 2) throw HipException("SetTailOverlap: mode 0 (off), 1 (from the average-luminance dispatch) or 2 (from the bloom pass)");
+    if (mode && mFrameFence.empty()) throw HipException("SetTailOverlap: throughput mode only (SetFramesInFlight(k > 1) first): with the per-frame fence there is no next frame to overlap");
+    if (mode == 2 && !mHaloPlan.empty()) throw HipException("SetTailOverlap: mode 2 is for frames without a halo exchange");
     WaitIdle();
-    if (on && mFrameFence.empty()) throw HipException("SetTailOverlap: throughput mode only (SetFramesInFlight(k > 1) first): with the per-frame fence there is no next frame to overlap");
-    mTailOverlap = on;
+    mTailOverlap = mode;
 }
 void HipCommandList::BeginTail() {
     if (!mTailOverlap || mInTail) return;
@@ -286,6 +291,7 @@ void HipCommandList::Dispatch(ShadingState* s, uint32 gx, uint32 gy, uint32 gz) 
         Check(pbr_cluster_cull(mCtx, &mGlobal, (const pbr_light*)s->Buffer("PointLights")->DevicePtr(), c.NumLight,
                                (pbr_cluster*)s->Buffer("Clusters")->DevicePtr()), "pbr_cluster_cull");
     } else if (f == "bloom_prefilter.hlsl") {
+        if (mTailOverlap == 2) BeginTail();   // the first dispatch of BloomPass::Execute issued one by one
         const auto& c = s->Constants<BloomPrefilterConstant>();
         Mip in = MipOf(s->Texture("InputTexture")), out = MipOf(s->RWTexture("OutputTexture"));
         // the reference sizes this grid by the FULL resolution (quirk Q9); the kernel covers the half-res output
@@ -409,6 +415,7 @@ void HipCommandList::Bloom(DeviceTexture2D* hdr, DeviceTexture2D* mip_chain, Dev
         throw HipException("Bloom: the mip chains must have the HDR target's size");
     mDispatchCount++;
     FlushPendingBloom();
+    if (mTailOverlap == 2) BeginTail();
     mPendingBloom = PendingBloom{PendingBloom::Whole, hdr, mip_chain, temp, threshold, knee};
     if (!mFusedPasses) FlushPendingBloom();
 }

@@ -31,8 +31,10 @@ public:
     // all-reduce, average, tone-map — a frame's commands go to the context's high-priority side stream (pbr_ctx_side_*), so that
     // the collective's latency and the two small launches run beside the NEXT frame's cluster pass and shade.  The frame graph
     // must double-buffer what the tail reads (FrameGraph::DoubleBufferResources: HDR target, histogram).
-    void SetTailOverlap(bool on);
-    bool TailOverlap() const { return mTailOverlap; }
+    // mode 1: as above.  mode 2 (frames without a halo exchange): the side stream takes over at the bloom pass already — bloom chain,
+    // histogram, average, tone-map beside the next frame's shade (the bloom is HBM / latency-bound, the shade FP32-issue-bound).
+    void SetTailOverlap(int mode);
+    int TailOverlap() const { return mTailOverlap; }
     uint32 FramesInFlight() const { return (uint32)mFrameFence.size() ? (uint32)mFrameFence.size() : 1; }
     void WaitIdle();
 
@@ -146,7 +148,8 @@ private:
     PendingBloom mPendingBloom;
     std::vector<hipEvent_t> mFrameFence;   // ring of per-frame completion events (throughput mode)
     uint64_t mFrameIndex = 0;
-    bool mTailOverlap = false, mInTail = false;
+    int mTailOverlap = 0;
+    bool mInTail = false;
     void BeginTail();
     void EndTail();
     std::vector<uint32> mExternalHistogram, mCapturedHistogram;

@@ -277,7 +277,7 @@ int pbrh_set_frames_in_flight(pbrh_renderer* r, int k) {
 int pbrh_set_tail_overlap(pbrh_renderer* r, int on) {
     return guarded(r, [&] {
         HipCommandList* cmd = r->scheduler->CommandList();
-        cmd->SetTailOverlap(on != 0);
+        cmd->SetTailOverlap(on);
         if (on) r->scheduler->GetFrameGraph()->DoubleBufferResources({DeferredPipelineResource::DeferredShadingRT, DeferredPipelineResource::LuminanceHistogram});
     });
 }

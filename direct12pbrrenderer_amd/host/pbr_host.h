@@ -35,7 +35,9 @@ int pbrh_halo_copy_from(pbrh_renderer* dst, pbrh_renderer* src);
 int pbrh_set_frames_in_flight(pbrh_renderer* r, int k);
 /* throughput mode only (after pbrh_set_frames_in_flight(k > 1)): a frame's tail — histogram all-reduce, average, tone-map — on
  * the context's high-priority side stream, beside the next frame's cluster pass and shade; the HDR target and the histogram are
- * double-buffered.  Same frames as the plain order (pbrh_read waits for everything in flight). */
+ * double-buffered.  Same frames as the plain order (pbrh_read waits for everything in flight).
+ * on = 1: as described.  on = 2 (frames without a halo exchange: one GPU, apron mode): the side stream takes over at the bloom pass —
+ * bloom chain, histogram, average, tone-map run beside the next frame's cluster pass and shade.  0: off. */
 int pbrh_set_tail_overlap(pbrh_renderer* r, int on);
 void pbrh_destroy(pbrh_renderer* r);
 const char* pbrh_last_error(const pbrh_renderer* r);

@@ -463,6 +463,22 @@ class DeferredFrame:
             self.shade()
             e1.record()
             shade_events.append((e0, e1))
+        if self._tail_overlap == "bloom":
+            # everything behind the shade — the bloom chain (8 launches, HBM / latency-bound), average, tone-map — on the context's
+            # high-priority side stream, beside the NEXT frame's cluster pass and shade (FP32-issue-bound), which write the other
+            # HDR / histogram buffer.  The join makes the main stream wait for the side work of the frame BEFORE (it read the HDR
+            # buffer the next shade overwrites); the chains and the adapted luminance are touched by the side stream only, in order.
+            self.ctx.side_join()
+            self.ctx.side_begin()
+            self.bloom_histogram()
+            if self.allreduce is not None:
+                self.allreduce(self.hist)
+            self.average()
+            self.tonemap()
+            self.ctx.side_end()
+            self.hdr, self._hdr_alt = self._hdr_alt, self.hdr
+            self.hist, self._hist_alt = self._hist_alt, self.hist
+            return
         self.bloom_histogram()
         if self._tail_overlap:
             # the frame's tail — histogram all-reduce, average, tone-map — on the context's side stream: the collective's latency
@@ -470,7 +486,8 @@ class DeferredFrame:
             # histogram buffer.  The join orders the side work of the frame BEFORE last ahead of this point (long finished).
             self.ctx.side_join()
             self.ctx.side_begin()
-            self.allreduce(self.hist)
+            if self.allreduce is not None:
+                self.allreduce(self.hist)
             self.average()
             self.tonemap()
             self.ctx.side_end()
@@ -482,21 +499,25 @@ class DeferredFrame:
         self.average()
         self.tonemap()
 
-    def enable_tail_overlap(self, capi_allreduce=False):
-        """Multi-GPU frames whose histogram all-reduce runs on the context's own stream (the C ABI's RCCL communicator): double-
-        buffer the HDR target and the histogram so that a frame's tail can overlap the next frame's shade.  Throughput mode:
-        the LDR image of frame i is complete when frame i + 1's tail has been joined (or after ctx.sync(), which also waits
-        for the side stream).  The all-reduce MUST be one that is enqueued on the context's current stream — PbrContext.
-        allreduce_hist, or a stand-in the caller vouches for with capi_allreduce=True (tests: a 1-rank communicator); a
-        torch.distributed all-reduce runs on torch's own stream and would race with the double-buffered histogram."""
-        if self.allreduce is None or self.split is not None:
-            raise ValueError("tail overlap needs an all-reduce (world > 1) and the plain frame order")
-        own = getattr(self.allreduce, "__self__", None) is self.ctx and getattr(self.allreduce, "__name__", "") == "allreduce_hist"
-        if not (own or capi_allreduce):
-            raise ValueError("tail overlap needs the C ABI's all-reduce (PbrContext.allreduce_hist): it must be enqueued on the context's side stream")
+    def enable_tail_overlap(self, capi_allreduce=False, from_bloom=False):
+        """Throughput mode: double-buffer the HDR target and the histogram so that a frame's tail — histogram all-reduce, average,
+        tone-map; with from_bloom=True the bloom chain as well, i.e. everything behind the shade — runs on the context's side stream
+        beside the NEXT frame's cluster pass and shade.  The LDR image of frame i is complete when frame i + 1's tail has been
+        joined (or after ctx.sync(), which also waits for the side stream).  With an all-reduce (world > 1) it MUST be one that is
+        enqueued on the context's current stream — PbrContext.allreduce_hist, or a stand-in the caller vouches for with
+        capi_allreduce=True (tests: a 1-rank communicator); a torch.distributed all-reduce runs on torch's own stream and would
+        race with the double-buffered histogram.  from_bloom is for frames without a halo exchange (one GPU, apron mode)."""
+        if self.split is not None:
+            raise ValueError("tail overlap needs the plain frame order")
+        if self.allreduce is not None:
+            own = getattr(self.allreduce, "__self__", None) is self.ctx and getattr(self.allreduce, "__name__", "") == "allreduce_hist"
+            if not (own or capi_allreduce):
+                raise ValueError("tail overlap needs the C ABI's all-reduce (PbrContext.allreduce_hist): it must be enqueued on the context's side stream")
+        if from_bloom and self.spec.halo:
+            raise ValueError("from_bloom: the halo exchange stays on the frame's stream")
         self._hdr_alt = torch.zeros_like(self.hdr)
         self._hist_alt = torch.zeros_like(self.hist)
-        self._tail_overlap = True
+        self._tail_overlap = "bloom" if from_bloom else True
 
     def finish(self):
         """Wait (on the frame's stream) for an overlapped tail still in flight."""

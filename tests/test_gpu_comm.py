@@ -222,11 +222,11 @@ cam = scene.Camera.reference_default(W, H)
 g = scene.make_global(cam, W, H, sh_pack=sh, delta_time=1.0 / 60.0)
 lights = synth.lights_in_view_box(64, cam)
 gbs = [synth.gbuffer_tile(0, 0, W, H, W, H), synth.gbuffer_tile(0, 0, W, H, W, H, rough_min=96)]
-def run(overlap):
-    fr = DeferredFrame(ctx, TileSpec(0, 0, W, H, W, H, 0), g, lights, lut, 512, env, 512, 5, allreduce=ctx.allreduce_hist)
+def run(overlap, allreduce=True, from_bloom=False):
+    fr = DeferredFrame(ctx, TileSpec(0, 0, W, H, W, H, 0), g, lights, lut, 512, env, 512, 5, allreduce=ctx.allreduce_hist if allreduce else None)
     fr.set_prev_luminance(0.18)
     if overlap:
-        fr.enable_tail_overlap()
+        fr.enable_tail_overlap(from_bloom=from_bloom)
     out = []
     for i in range(7):
         fr.upload_gbuffer(gbs[i %% 2])               # alternating inputs: a stale buffer would show
@@ -248,10 +248,13 @@ try:
     raise SystemExit("an all-reduce that is not the C ABI's must be refused")
 except ValueError as e:
     assert "C ABI" in str(e)
-a, b = run(False), run(True)
-for i, ((la, va), (lb, vb)) in enumerate(zip(a, b)):
-    assert va == vb, (i, va, vb)
-    assert np.array_equal(la, lb), (i, int((la != lb).sum()))
+a = run(False)
+# with the RCCL all-reduce in the tail (multi-GPU frames); without one (N = 1): the tail alone, and everything behind the shade
+for what, b in (("tail + all-reduce", run(True)), ("tail, no all-reduce", run(True, allreduce=False)),
+                ("bloom + tail, no all-reduce", run(True, allreduce=False, from_bloom=True)), ("bloom + tail + all-reduce", run(True, from_bloom=True))):
+    for i, ((la, va), (lb, vb)) in enumerate(zip(a, b)):
+        assert va == vb, (what, i, va, vb)
+        assert np.array_equal(la, lb), (what, i, int((la != lb).sum()))
 ctx.close()
 print("tail overlap ok")
 """
@@ -259,9 +262,9 @@ print("tail overlap ok")
 
 @pytest.mark.timeout(400)
 def test_overlapped_frame_tail_equals_the_plain_order():
-    """DeferredFrame.enable_tail_overlap (what bench.py's multi-GPU frames run when the histogram all-reduce is the C ABI's):
-    all-reduce + average + tone-map of frame i on the context's side stream beside frame i + 1's shade, HDR target and
-    histogram double-buffered.  With a 1-rank RCCL communicator on the one GPU: LDR image and adapted luminance of every
+    """DeferredFrame.enable_tail_overlap (what bench.py's multi-GPU frames run when the histogram all-reduce is the C ABI's, and —
+    round 4 — its N = 1 frames for the `*_tail_overlapped` figures): all-reduce + average + tone-map of frame i (from_bloom: the
+    bloom chain too) on the context's side stream beside frame i + 1's shade, HDR target and histogram double-buffered.  With a 1-rank RCCL communicator on the one GPU: LDR image and adapted luminance of every
     frame of an alternating input sequence identical to the plain order, synchronised frame by frame and back to back."""
     r = subprocess.run(["timeout", "-k", "10", "300", sys.executable, "-c", _TAIL_OVERLAP % ROOT], capture_output=True, text=True)
     assert r.returncode == 0 and "tail overlap ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

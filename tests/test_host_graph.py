@@ -571,7 +571,8 @@ def test_host_graph_throughput_mode_renders_the_same_frames(host):
     """pbrh_set_frames_in_flight(3): a frame's end waits for frame i - 2 only (the host records ahead of the GPU); the
     frames themselves — adapted luminance after five of them, LDR image — are those of the reference's fence-per-frame loop.
     pbrh_set_tail_overlap(1) on top: average + tone-map (+ the all-reduce with a communicator) of frame i on the context's side
-    stream beside frame i + 1's shade, HDR target and histogram double-buffered by the frame graph — still the same frames."""
+    stream beside frame i + 1's shade, HDR target and histogram double-buffered by the frame graph — still the same frames;
+    pbrh_set_tail_overlap(2): the side stream takes over at the bloom pass (fused and dispatch by dispatch)."""
     from direct12pbrrenderer_amd import scene
     W, H, ENV, LUT, NL = 512, 288, 32, 64, 256
     sky_np = synth.env_cube(ENV)
@@ -582,7 +583,7 @@ def test_host_graph_throughput_mode_renders_the_same_frames(host):
     gb = synth.gbuffer_tile(0, 0, W, H, W, H, coverage_mask=True)
     err = C.create_string_buffer(256)
     out = []
-    for in_flight, fused, tail in ((1, 0, 0), (3, 1, 0), (3, 0, 0), (3, 1, 1), (3, 0, 1)):
+    for in_flight, fused, tail in ((1, 0, 0), (3, 1, 0), (3, 0, 0), (3, 1, 1), (3, 0, 1), (3, 1, 2), (3, 0, 2)):
         r = host.pbrh_create(0, W, H, ENV, LUT, err, 256)
         assert r, err.value
         try:
@@ -592,8 +593,13 @@ def test_host_graph_throughput_mode_renders_the_same_frames(host):
             assert host.pbrh_set_initial_luminance(r, 0.18) == 0
             assert host.pbrh_set_fused(r, fused) == 0
             assert host.pbrh_set_frames_in_flight(r, in_flight) == 0
+            # a refused call changes nothing (it used to drop the renderer back to the per-frame fence first)
             assert host.pbrh_set_frames_in_flight(r, 9) == -1 and b"at most" in host.pbrh_last_error(r)
-            assert host.pbrh_set_frames_in_flight(r, in_flight) == 0
+            if in_flight > 1:
+                assert host.pbrh_set_tail_overlap(r, 1) == 0, host.pbrh_last_error(r)      # still in throughput mode after the refusal
+                assert host.pbrh_set_tail_overlap(r, 3) == -1 and b"mode 0" in host.pbrh_last_error(r)
+                assert host.pbrh_set_frames_in_flight(r, 1) == 0                             # back to the fence: the tail mode goes with it
+                assert host.pbrh_set_frames_in_flight(r, in_flight) == 0
             if in_flight == 1:
                 assert host.pbrh_set_tail_overlap(r, 1) == -1 and b"throughput mode only" in host.pbrh_last_error(r)
             assert host.pbrh_set_tail_overlap(r, tail) == 0, host.pbrh_last_error(r)
