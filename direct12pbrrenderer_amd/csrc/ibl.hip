@@ -240,6 +240,7 @@ struct PfLaunch {
     float wsum[16];             // sum of their weights, accumulated in sample order in fp32 like the shader's total_weight
     uint32_t src_off[16];       // texel offset of padded SOURCE mip l
     uint32_t mips, size, sky_size, sky_mips;
+    uint32_t xcd_groups;        // k_prefilter_foot: 8 = blocks sharing blockIdx % 8 (one XCD) take one contiguous eighth of a mip's texels; 1 = plain order
 };
 
 // trilinear fetch of the padded fp32 chain along `d` at the (already clamped and x.8-snapped) LOD; rgb only
@@ -498,8 +499,11 @@ __global__ __launch_bounds__(PF_FOOT_BLOCK) __attribute__((amdgpu_waves_per_eu(8
     // source region behind ~3/4 of a cube face.  (Any consistent function of blockIdx % 8 keeps the grouping; which physical XCD
     // serves a group does not matter.)
     const uint32_t lb = blockIdx.x - pl.first_block[mip], nb = pl.first_block[mip + 1] - pl.first_block[mip];
-    const uint32_t xcd = lb & 7u, chunk = nb >> 3, rem = nb & 7u;
-    const uint32_t block = xcd * chunk + min(xcd, rem) + (lb >> 3);   // group x holds chunk + (x < rem) blocks; lb >> 3 < that count by construction
+    uint32_t block = lb;
+    if (pl.xcd_groups == 8u) {
+        const uint32_t xcd = lb & 7u, chunk = nb >> 3, rem = nb & 7u;
+        block = xcd * chunk + min(xcd, rem) + (lb >> 3);   // group x holds chunk + (x < rem) blocks; lb >> 3 < that count by construction
+    }
     const uint32_t t = block * PF_FOOT_BLOCK + threadIdx.x;
     if (t >= n) return;
     const uint32_t x = t % s, y = (t / s) % s, face_o = t / (s * s);
@@ -830,6 +834,8 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
     // ---- padded source chain (stream-ordered scratch) + per-mip sample tables (kept on the device)
     PfLaunch pl{};
     pl.mips = mips; pl.size = size; pl.sky_size = sky->size; pl.sky_mips = sky->mips;
+    static const int xcd_groups = pbr::knob_int("PBR_PREFILTER_XCD", 8);   // A/B switch (knobs build): 1 = the plain block order
+    pl.xcd_groups = xcd_groups == 8 ? 8u : 1u;
     PBR_REQUIRE(ctx, sky->mips <= 16, "pbr_prefilter_env: bad sky cube");
     for (uint32_t l = 0; l < sky->mips; l++) pl.src_off[l] = (uint32_t)cube_border_mip_offset(sky->size, l);
     const size_t padded_texels = cube_border_mip_offset(sky->size, sky->mips);
