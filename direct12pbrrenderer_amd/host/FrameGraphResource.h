@@ -81,6 +81,12 @@ public:
         if (DryRun()) return;
         ThrowIfFailed(hipMalloc(&mPtr, bytes ? bytes : 1), "hipMalloc");
         ThrowIfFailed(hipMemset(mPtr, 0, bytes ? bytes : 1), "hipMemset");
+        // hipMemset of device memory is ASYNCHRONOUS to the host and runs on the null stream, which the contexts' non-blocking
+        // streams do not wait for: without this wait a kernel enqueued next on a context's stream can write the buffer BEFORE the
+        // zero-fill lands and lose part of what it wrote (round 4: the padded env chain built right after its allocation came out
+        // with zeroed texels once in ~10 renderer creations — a few hundred wrong pixels per frame; found by
+        // test_host_graph_throughput_mode_renders_the_same_frames).  Allocation is rare: a host wait here costs nothing per frame.
+        ThrowIfFailed(hipStreamSynchronize(nullptr), "hipStreamSynchronize(null stream) after zero-fill");
     }
     ~DeviceMemory() { if (mPtr) (void)hipFree(mPtr); }
     DeviceMemory(const DeviceMemory&) = delete;

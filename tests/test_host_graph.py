@@ -612,5 +612,5 @@ def test_host_graph_throughput_mode_renders_the_same_frames(host):
             out.append((ldr, float(avg[0])))
         finally:
             host.pbrh_destroy(r)
-    for ldr, avg in out[1:]:
-        assert avg == out[0][1] and np.array_equal(ldr, out[0][0])
+    bad = [(k, avg == out[0][1], int((ldr != out[0][0]).sum())) for k, (ldr, avg) in enumerate(out) if avg != out[0][1] or not np.array_equal(ldr, out[0][0])]
+    assert not bad, f"(config index, same adapted luminance, differing LDR pixels): {bad}"
