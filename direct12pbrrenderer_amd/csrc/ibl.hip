@@ -492,15 +492,19 @@ __global__ __launch_bounds__(PF_FOOT_BLOCK) __attribute__((amdgpu_waves_per_eu(8
     __syncthreads();
     const uint32_t s = pl.size >> mip;
     const uint32_t n = 6u * s * s;
-    // XCD-aware block -> texel mapping.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with its own
-    // 4 MB L2: with the plain mapping every XCD samples for texels all over the cube, i.e. needs the WHOLE source chain in its L2 —
-    // the fp32 chain (33.6 MB) then thrashes (round 3: FETCH 3.1 GB for a 50 MB compulsory footprint, TCC hit 85 %).  Here the
-    // blocks that share blockIdx % 8 — one XCD — take one CONTIGUOUS eighth of the mip's texels, so an XCD's working set is the
-    // source region behind ~3/4 of a cube face.  (Any consistent function of blockIdx % 8 keeps the grouping; which physical XCD
-    // serves a group does not matter.)
+    // XCD-aware block -> texel mapping, fp32 instance.  The dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with
+    // its own 4 MB L2: with the plain mapping every XCD samples for texels all over the cube, i.e. needs the WHOLE source chain in its
+    // L2 — the fp32 chain (33.6 MB; levels 1 + 2 alone are 8 MB) then thrashes: round 3 measured FETCH 3.1 GB for a 50 MB compulsory
+    // footprint at a TCC hit rate of 85 %.  Here the blocks that share blockIdx % 8 — one XCD — take one CONTIGUOUS eighth of the mip's
+    // texels, so an XCD's working set is the source region behind ~3/4 of a cube face: FETCH 17 MB, TCC hit 99.9 %
+    // (profiles/r04_c_pmc_prefilter_f32.json), 2.34-2.39 -> 2.18-2.31 ms — the launch is bound by the texture addresser's data
+    // return (TA busy 81 %: four 12-byte loads per level) once the misses are gone.  (Any consistent function of blockIdx % 8 keeps
+    // the grouping; which physical XCD serves a group does not matter.)  The HALF instance keeps the plain order: its 16.8 MB chain
+    // hits L2 at 99.5 % either way, and with the grouping the 128 blocks of an XCD contend for the same L2 channels — measured
+    // 1.42-1.44 -> 1.51-1.56 ms (profiles/r04_c_prefilter_xcd_ab.txt).
     const uint32_t lb = blockIdx.x - pl.first_block[mip], nb = pl.first_block[mip + 1] - pl.first_block[mip];
     uint32_t block = lb;
-    if (pl.xcd_groups == 8u) {
+    if (!HALF && pl.xcd_groups == 8u) {
         const uint32_t xcd = lb & 7u, chunk = nb >> 3, rem = nb & 7u;
         block = xcd * chunk + min(xcd, rem) + (lb >> 3);   // group x holds chunk + (x < rem) blocks; lb >> 3 < that count by construction
     }

@@ -332,6 +332,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
                     light2(qs, ts, (const lds_cf*)(uintptr_t)pair.x, (const lds_cf*)(uintptr_t)pair.y, au);
                     i += 2;
                 } while (i < nl);
+                // (reading the NEXT trip's two entries one trip ahead was measured in round 4: two more live registers push the
+                //  kernel's scratch from 12 to 24 bytes per lane at its 96-VGPR budget, in-frame 0.3356 -> 0.3470 ms; removed —
+                //  profiles/r04_d_ab_shade_prefetch.txt)
             };
             if (q_safe & 1) {
                 if (t_ok) { if (q_safe & 2) walk(std::true_type{}, std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::true_type{}, std::false_type{}); }
