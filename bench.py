@@ -896,6 +896,7 @@ def main():
                 "histogram": (frame.histogram, None, BYTES_PER_PX["histogram"] * int_px),
                 "average": (frame.average, frame.histogram, 0.0),
                 "tonemap": (frame.tonemap, None, BYTES_PER_PX["tonemap"] * int_px),
+                "average+tonemap": (frame.average_tonemap, frame.histogram, BYTES_PER_PX["tonemap"] * int_px),   # what the frame runs: one launch
             }
             if spec.halo:
                 stages["halo prefilter"] = (frame.halo_prefilter, None, 0.0)

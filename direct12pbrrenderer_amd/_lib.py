@@ -64,6 +64,7 @@ SIGNATURES = {
     "pbr_lum_histogram": (_int, [_vp, _vp, _u32, _u32, _u32, _f32, _f32, _vp]),
     "pbr_lum_average": (_int, [_vp, _vp, _u32, _f32, _f32, _f32, _vp]),
     "pbr_tonemap": (_int, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _u32]),
+    "pbr_average_tonemap": (_int, [_vp, _vp, _u32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _u32]),
     "pbr_comm_unique_id": (_int, [_vp]),
     "pbr_comm_init": (_int, [_vp, _int, _int, _vp]),
     "pbr_allreduce_hist": (_int, [_vp, _vp]),

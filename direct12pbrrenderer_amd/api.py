@@ -262,6 +262,12 @@ class PbrContext:
     def tonemap(self, hdr, w, h, pitch, avg, out, out_pitch):
         self._check(self.lib.pbr_tonemap(self.h, _ptr(hdr), w, h, pitch, _ptr(avg), _ptr(out), out_pitch))
 
+    def average_tonemap(self, hist, pixel_count, dt, avg_in, avg_out, hist_clear, hdr, w, h, pitch, out, out_pitch,
+                        min_log=MIN_LOG_LUMINANCE, log_range=LOG_LUMINANCE_RANGE):
+        """pbr_lum_average + pbr_tonemap as one launch: avg_out != avg_in, hist_clear != hist (see pbr_hip.h)"""
+        self._check(self.lib.pbr_average_tonemap(self.h, _ptr(hist), pixel_count, min_log, log_range, dt, _ptr(avg_in), _ptr(avg_out),
+                                                 _ptr(hist_clear) if hist_clear is not None else None, _ptr(hdr), w, h, pitch, _ptr(out), out_pitch))
+
     def membench_read(self, buf, sink, blocks):
         """One streaming-read pass over `buf` (measurement aid: the device's achievable HBM-read bandwidth)."""
         self._check(self.lib.pbr_membench_read(self.h, _ptr(buf), buf.numel() * buf.element_size(), _ptr(sink), blocks))

@@ -297,14 +297,23 @@ __global__ __launch_bounds__(256) void k_bloom_prefilter_2x(const pbr_half* __re
     const OutRect rc{rs.x0[r], rs.y0[r], rs.x1[r], rs.y1[r], rs.ox, rs.oy, rs.pitch};
     const int bx0 = rc.x0 + (lb % rs.tiles_x[r]) * PF_TW, by0 = rc.y0 + (lb / rs.tiles_x[r]) * PF_TH;   // tiles are laid over the output rect
     const int px0 = bx0 - 1, py0 = by0 - 1;
-    for (int e = tid; e < (PF_TH + 2) * (PF_TW + 2); e += 256) {
+    // one position = the quad (2p-1, 2p) x (2q-1, 2q), weights 1/2 (position p samples u = p / ow: texel coordinate 2p - 1/2).  The four
+    // texels of the NEXT position of this thread are loaded before the current one is evaluated (its three IEEE divides): eight loads in
+    // flight per thread instead of four (round 4)
+    struct Quad { H4 a, b, c, d; };
+    auto load_quad = [&](int e) {
         const int r = e / (PF_TW + 2), c = e - r * (PF_TW + 2);
         const int p = px0 + c, q = py0 + r;
-        // position p samples u = p / ow: texel coordinate 2p - 1/2, i.e. the quad (2p-1, 2p) x (2q-1, 2q), weights 1/2
         const int x0 = clampi(2 * p - 1, 0, w - 1), x1 = clampi(2 * p, 0, w - 1);
         const int y0 = clampi(2 * q - 1, 0, h - 1), y1 = clampi(2 * q, 0, h - 1);
-        const F4 s = bilerp(load_h4(hdr + 4 * ((size_t)y0 * pitch + x0)), load_h4(hdr + 4 * ((size_t)y0 * pitch + x1)),
-                            load_h4(hdr + 4 * ((size_t)y1 * pitch + x0)), load_h4(hdr + 4 * ((size_t)y1 * pitch + x1)), 0.5f, 0.5f);
+        const H4* r0 = reinterpret_cast<const H4*>(hdr) + (size_t)y0 * pitch;
+        const H4* r1 = reinterpret_cast<const H4*>(hdr) + (size_t)y1 * pitch;
+        return Quad{r0[x0], r0[x1], r1[x0], r1[x1]};
+    };
+    constexpr int NPOS = (PF_TH + 2) * (PF_TW + 2);
+    auto evaluate = [&](int e, const Quad& t) {
+        const int r = e / (PF_TW + 2), c = e - r * (PF_TW + 2);
+        const F4 s = bilerp(h4f(t.a), h4f(t.b), h4f(t.c), h4f(t.d), 0.5f, 0.5f);
         const float brightness = fmaxf(s.x, fmaxf(s.y, s.z));
         float soft = fminf(fmaxf(brightness - threshold + threshold * knee, 0.0f), 2.0f * threshold * knee);
         soft /= 4.0f * threshold * knee + 0.00001f;
@@ -312,6 +321,16 @@ __global__ __launch_bounds__(256) void k_bloom_prefilter_2x(const pbr_half* __re
         const float cr = s.x * contribution, cg = s.y * contribution, cb = s.z * contribution;
         const float wgt = 1.0f / (luminance(cr, cg, cb) + 1.0f);
         pos[r][c] = make_float4(cr * wgt, cg * wgt, cb * wgt, wgt);
+    };
+    // two register sets in turn (a copy `cur = nxt` would wait for the next quad's data at the end of every trip)
+    Quad qa = load_quad(tid);   // tid < 256 < NPOS
+    for (int e = tid; e < NPOS; e += 512) {
+        const Quad qb = load_quad(min(e + 256, NPOS - 1));
+        evaluate(e, qa);
+        if (e + 256 < NPOS) {
+            qa = load_quad(min(e + 512, NPOS - 1));
+            evaluate(e + 256, qb);
+        }
     }
     __syncthreads();
     const int lx = tid & 63, x = bx0 + lx;

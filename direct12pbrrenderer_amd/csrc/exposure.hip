@@ -192,6 +192,29 @@ __global__ __launch_bounds__(256) void k_tonemap(const pbr_half* __restrict__ hd
     tonemap_pixels(hdr, w, h, pitch, avg[0], out, out_pitch, aligned);
 }
 
+// hdr_average_histogram.hlsl + hdr_tone_mapping.hlsl in ONE launch (round 4).  The average is a 256-bin reduction — microseconds of
+// work behind a launch of its own (4.7 us + a dependency gap in the 4K frame): here every block of the tone-map re-derives it from the
+// bins with the same fixed-order LDS tree (bit-identical in every block), then tone-maps its pixels.  Nothing the blocks read is
+// written by this launch: the adapted luminance goes to avg_OUT (!= avg_in), and the histogram that is zeroed "for the next frame" is
+// ANOTHER one (hist_clear: the one the next frame accumulates into; the counts read here are cleared by the next frame's call) — the
+// caller alternates two histograms and two luminance cells, so no block can race block 0's writes.
+__global__ __launch_bounds__(256) void k_average_tonemap(const uint32_t* __restrict__ hist, uint32_t pixel_count, float min_log, float range,
+                                                           float delta_time, const float* __restrict__ avg_in, float* __restrict__ avg_out,
+                                                           uint32_t* __restrict__ hist_clear,
+                                                           const pbr_half* __restrict__ hdr, uint32_t w, uint32_t h, uint32_t pitch,
+                                                           uint32_t* __restrict__ out, uint32_t out_pitch, bool aligned) {
+    __shared__ float sh[PBR_HISTOGRAM_BINS];
+    __shared__ float s_avg;
+    const float r = adapted_luminance(sh, hist, pixel_count, min_log, range, delta_time, avg_in[0]);
+    if (threadIdx.x == 0) s_avg = r;
+    if (blockIdx.x == 0) {
+        if (hist_clear) hist_clear[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) avg_out[0] = r;
+    }
+    __syncthreads();
+    tonemap_pixels(hdr, w, h, pitch, s_avg, out, out_pitch, aligned);
+}
+
 extern "C" {
 
 pbr_status pbr_lum_histogram(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
@@ -229,6 +252,22 @@ pbr_status pbr_tonemap(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h
     const bool aligned = (((uintptr_t)hdr & 15u) == 0u) && (((uintptr_t)rgba8 & 7u) == 0u) && (((pitch | out_pitch) & 1u) == 0u);
     hipLaunchKernelGGL(k_tonemap, grid, dim3(256), 0, ctx->stream, hdr, w, h, pitch, avg, rgba8, out_pitch, aligned);
     return launched(ctx, "k_tonemap");
+}
+
+pbr_status pbr_average_tonemap(pbr_ctx* ctx, const uint32_t* hist256, uint32_t pixel_count, float min_log, float range, float delta_time,
+                               const float* avg_in, float* avg_out, uint32_t* hist_clear256,
+                               const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch, uint32_t* rgba8, uint32_t out_pitch) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, hist256 && avg_in && avg_out && hdr && rgba8, "pbr_average_tonemap: null pointer");
+    PBR_REQUIRE(ctx, avg_in != avg_out && hist_clear256 != hist256, "pbr_average_tonemap: avg_out must differ from avg_in and hist_clear256 from hist256 (every block reads them)");
+    PBR_REQUIRE(ctx, w && h && w <= 65535 && h <= 65535 && pitch >= w && out_pitch >= w, "pbr_average_tonemap: bad size");
+    size_t pairs = (size_t)((w + 1) / 2) * h;
+    unsigned blocks = (unsigned)((pairs + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    const bool aligned = (((uintptr_t)hdr & 15u) == 0u) && (((uintptr_t)rgba8 & 7u) == 0u) && (((pitch | out_pitch) & 1u) == 0u);
+    hipLaunchKernelGGL(k_average_tonemap, dim3(blocks), dim3(256), 0, ctx->stream, hist256, pixel_count, min_log, range, delta_time, avg_in, avg_out,
+                       hist_clear256, hdr, w, h, pitch, rgba8, out_pitch, aligned);
+    return launched(ctx, "k_average_tonemap");
 }
 
 }  // extern "C"

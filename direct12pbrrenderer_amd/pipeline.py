@@ -259,7 +259,7 @@ class DeferredFrame:
     """Owns the device buffers of one rank and runs the per-frame passes through the C ABI."""
 
     def __init__(self, ctx: PbrContext, spec: TileSpec, g: Global, lights_np, lut, lut_res, env, env_size,
-                 env_mips=ENV_MIPS, allreduce=None, sky=None, all_specs=None, rank=0, halo_transport=None, overlap=False):
+                 env_mips=ENV_MIPS, allreduce=None, sky=None, all_specs=None, rank=0, halo_transport=None, overlap=False, fused_exposure=True):
         """sky: optional (cube tensor fp32 RGBA with mips, size, mips) — resolved on stencil == 0 pixels
         before the shade like the reference's SkyboxPass; without it those pixels keep what the buffer holds.
         Halo mode (spec.halo): all_specs = the TileSpec of every rank, rank = this one, halo_transport = HaloTransport.
@@ -281,6 +281,11 @@ class DeferredFrame:
         self.hist = ctx.zeros((HISTOGRAM_BINS,), torch.int32)
         self._tail_overlap = False
         self.avg = ctx.zeros((1,), torch.float32)
+        # fused_exposure (default): average + tone-map as ONE launch (pbr_average_tonemap), which reads one histogram / luminance cell
+        # and writes the other — the frame alternates two of each; `hist` / `avg` always name the current ones
+        self.fused_exposure = fused_exposure
+        self._hist_next = ctx.zeros((HISTOGRAM_BINS,), torch.int32)
+        self._avg_next = ctx.zeros((1,), torch.float32)
         self.ldr = ctx.zeros((spec.h, spec.w), torch.int32)
         self.gb = None
         self.tile = Tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h)
@@ -435,6 +440,22 @@ class DeferredFrame:
         s = self.spec
         self.ctx.tonemap(self._hdr_interior_ptr(), s.w, s.h, s.sw, self.avg, self.ldr, s.w)
 
+    def average_tonemap(self):
+        """The frame's last two dispatches as one launch; afterwards `avg` is the new adapted luminance and `hist` the zeroed
+        histogram the next frame accumulates into."""
+        s = self.spec
+        self.ctx.average_tonemap(self.hist, s.full_w * s.full_h, float(self.g.DeltaTime), self.avg, self._avg_next, self._hist_next,
+                                 self._hdr_interior_ptr(), s.w, s.h, s.sw, self.ldr, s.w)
+        self.avg, self._avg_next = self._avg_next, self.avg
+        self.hist, self._hist_next = self._hist_next, self.hist
+
+    def exposure_and_tonemap(self):
+        if self.fused_exposure:
+            self.average_tonemap()
+        else:
+            self.average()
+            self.tonemap()
+
     def render(self, shade_events=None):
         """One frame: every per-frame dispatch of the reference, in the frame graph's order.
         shade_events: optional list; a (start, end) pair of torch events bracketing the shade launch is appended."""
@@ -452,8 +473,7 @@ class DeferredFrame:
                 shade_events.append((e0, e1))
             if self.allreduce is not None:
                 self.allreduce(self.hist)
-            self.average()
-            self.tonemap()
+            self.exposure_and_tonemap()
             return
         if shade_events is None:
             self.shade()
@@ -496,8 +516,7 @@ class DeferredFrame:
             return
         if self.allreduce is not None:
             self.allreduce(self.hist)
-        self.average()
-        self.tonemap()
+        self.exposure_and_tonemap()
 
     def enable_tail_overlap(self, capi_allreduce=False, from_bloom=False):
         """Throughput mode: double-buffer the HDR target and the histogram so that a frame's tail — histogram all-reduce, average,

@@ -348,6 +348,14 @@ pbr_status pbr_lum_average(pbr_ctx* ctx, uint32_t* hist256, uint32_t pixel_count
 /* hdr_tone_mapping.hlsl:9-52 (DeferredPipeline.cpp:320-336): hdr -> RGBA8 UNORM. */
 pbr_status pbr_tonemap(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch,
                        const float* avg, uint32_t* rgba8, uint32_t out_pitch);
+/* hdr_average_histogram.hlsl + hdr_tone_mapping.hlsl as ONE launch (the last two dispatches of a frame): *avg_out = the adapted
+ * luminance of pbr_lum_average(hist256, *avg_in), rgba8 = pbr_tonemap(hdr, *avg_out) — bit-identical to the two calls.  Every block of
+ * the launch re-derives the average from the 256 bins, so NOTHING it reads may be written by it: avg_out != avg_in, and the histogram
+ * zeroed "for the next frame" is hist_clear256 != hist256 (NULL: none) — a caller alternates two histograms (the next frame accumulates
+ * into the one cleared here; the counts read here are cleared by the next frame's call) and two luminance cells. */
+pbr_status pbr_average_tonemap(pbr_ctx* ctx, const uint32_t* hist256, uint32_t pixel_count, float min_log, float range, float delta_time,
+                               const float* avg_in, float* avg_out, uint32_t* hist_clear256,
+                               const pbr_half* hdr, uint32_t w, uint32_t h, uint32_t pitch, uint32_t* rgba8, uint32_t out_pitch);
 /* ---- multi-GPU (new) -------------------------------------------------------------- */
 /* RCCL communicator over the ranks of one node.  unique_id: 128 bytes from
  * pbr_comm_unique_id() on rank 0, broadcast by the caller (e.g. torch.distributed store). */

@@ -722,6 +722,39 @@ def test_average_truncation_overflow_and_black_frame(ctx, orc):
     assert (np.isnan(got) and np.isnan(want)) or got == pytest.approx(want, rel=2e-6)
 
 
+def test_average_tonemap_one_launch_equals_the_two_dispatches(ctx, orc):
+    """pbr_average_tonemap (round 4: every block of the tone-map re-derives the adapted luminance from the bins) against
+    pbr_lum_average + pbr_tonemap: the same luminance cell and LDR image bit for bit, the OTHER histogram zeroed, the one read left
+    alone; ragged and interior-view sizes; and the aliasing the contract forbids is refused."""
+    from direct12pbrrenderer_amd.api import PbrError
+    for (w, h, pitch, x0) in ((512, 288, 512, 0), (333, 77, 400, 40), (2, 2, 2, 0)):
+        img = synth.hdr_noise_image(pitch, h, seed=w + h)
+        d = dev_half(ctx, img)
+        view = d.data_ptr() + 8 * x0
+        hist = ctx.zeros((256,), torch.int32)
+        ctx.lum_histogram(view, w, h, pitch, hist)
+        hist_b, stale = hist.clone(), ctx.upload(np.arange(256, dtype=np.int32) + 7)
+        for dt, prev in ((1.0 / 60.0, 0.18), (1e9, 0.0)):
+            a = ctx.upload(np.array([prev], dtype=np.float32))
+            h1 = hist.clone()
+            ldr_a = ctx.zeros((h, w), torch.int32)
+            ctx.lum_average(h1, w * h, dt, a)
+            ctx.tonemap(view, w, h, pitch, a, ldr_a, w)
+            a_in, a_out = ctx.upload(np.array([prev], dtype=np.float32)), ctx.upload(np.array([-1.0], dtype=np.float32))
+            ldr_b = ctx.zeros((h, w), torch.int32)
+            clear = stale.clone()
+            ctx.average_tonemap(hist_b, w * h, dt, a_in, a_out, clear, view, w, h, pitch, ldr_b, w)
+            ctx.sync()
+            assert a_out.cpu().numpy().view(np.uint32)[0] == a.cpu().numpy().view(np.uint32)[0] and float(a_in.cpu()[0]) == np.float32(prev)
+            assert torch.equal(ldr_a, ldr_b)
+            assert int(clear.abs().sum()) == 0 and torch.equal(hist_b, hist) and int(h1.abs().sum()) == 0
+    a = ctx.upload(np.array([0.18], dtype=np.float32))
+    with pytest.raises(PbrError, match="avg_out must differ"):
+        ctx.average_tonemap(hist, 4, 0.1, a, a, None, d, 2, 2, 2, ctx.zeros((2, 2), torch.int32), 2)
+    with pytest.raises(PbrError, match="avg_out must differ"):
+        ctx.average_tonemap(hist, 4, 0.1, a, a.clone(), hist, d, 2, 2, 2, ctx.zeros((2, 2), torch.int32), 2)
+
+
 # ------------------------------------------------------------------------------------------ whole frame
 def test_frame_1080p_region_properties_and_oracle_sample(ctx, orc, ibl):
     """cfg2-sized frame (1920x1080, 1 light): full-size run checked through size-independent
