@@ -259,7 +259,7 @@ class DeferredFrame:
     """Owns the device buffers of one rank and runs the per-frame passes through the C ABI."""
 
     def __init__(self, ctx: PbrContext, spec: TileSpec, g: Global, lights_np, lut, lut_res, env, env_size,
-                 env_mips=ENV_MIPS, allreduce=None, sky=None, all_specs=None, rank=0, halo_transport=None, overlap=False, fused_exposure=True):
+                 env_mips=ENV_MIPS, allreduce=None, sky=None, all_specs=None, rank=0, halo_transport=None, overlap=False, fused_exposure=False):
         """sky: optional (cube tensor fp32 RGBA with mips, size, mips) — resolved on stencil == 0 pixels
         before the shade like the reference's SkyboxPass; without it those pixels keep what the buffer holds.
         Halo mode (spec.halo): all_specs = the TileSpec of every rank, rank = this one, halo_transport = HaloTransport.
@@ -281,8 +281,10 @@ class DeferredFrame:
         self.hist = ctx.zeros((HISTOGRAM_BINS,), torch.int32)
         self._tail_overlap = False
         self.avg = ctx.zeros((1,), torch.float32)
-        # fused_exposure (default): average + tone-map as ONE launch (pbr_average_tonemap), which reads one histogram / luminance cell
-        # and writes the other — the frame alternates two of each; `hist` / `avg` always name the current ones
+        # fused_exposure: average + tone-map as ONE launch (pbr_average_tonemap), which reads one histogram / luminance cell and writes
+        # the other — the frame alternates two of each; `hist` / `avg` always name the current ones.  Off by default: measured in round 4
+        # (tools/frame_ab.py, profiles/r04_g_frame_ab.txt) the launch it saves does not show in the frame (0.4670 / 0.4672 / 0.4680 vs
+        # 0.4659 / 0.4682 / 0.4674 ms), so the frame keeps the reference's two dispatches
         self.fused_exposure = fused_exposure
         self._hist_next = ctx.zeros((HISTOGRAM_BINS,), torch.int32)
         self._avg_next = ctx.zeros((1,), torch.float32)
