@@ -30,6 +30,7 @@ SIGNATURES = {
     "pbr_ctx_side_begin": (_int, [_vp]),
     "pbr_ctx_side_end": (_int, [_vp]),
     "pbr_ctx_side_join": (_int, [_vp]),
+    "pbr_ctx_set_cu_masks": (_int, [_vp, _vp, _vp, _u32]),
     "pbr_last_error": (C.c_char_p, [_vp]),
     "pbr_sync": (_int, [_vp]),
     "pbr_brdf_lut": (_int, [_vp, _u32, _vp]),

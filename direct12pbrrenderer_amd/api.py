@@ -82,6 +82,29 @@ class PbrContext:
     def sync(self):
         self._check(self.lib.pbr_sync(self.h))
 
+    def use_own_stream(self):
+        """Enqueue on the context's private stream (not torch's): the caller orders torch work with ctx.sync() / torch.cuda.synchronize()."""
+        self._check(self.lib.pbr_ctx_use_own_stream(self.h))
+
+    def partition_cus(self, side_cus, total_cus=None, layout="low"):
+        """pbr_ctx_set_cu_masks with `side_cus` compute units, spread evenly over the device, for the side stream and the rest for the
+        context's private stream (0: no partition, every CU for both).  The context must be on its private stream (use_own_stream)."""
+        if not side_cus:
+            self._check(self.lib.pbr_ctx_set_cu_masks(self.h, None, None, 0))
+            return
+        n = int(total_cus or torch.cuda.get_device_properties(self.torch_device).multi_processor_count)
+        words = (n + 31) // 32
+        side = np.zeros(words, np.uint32)
+        main = np.zeros(words, np.uint32)
+        # On MI355X the bits of a CU mask run XCD by XCD in groups of four (measured: tools/cu_partition.py), and a kernel's workgroups
+        # are dealt to the XCDs in equal shares whatever their CU counts — so both partitions must hold the SAME number of CUs of every
+        # XCD, or the XCD with the fewest sets the pace: the side stream gets the low side_cus bits, side_cus a multiple of 32
+        # (layout="strided": every (n / side_cus)-th bit instead, for the measurement of exactly that effect).
+        picked = set(range(side_cus)) if layout == "low" else set(int(round(k * n / side_cus)) % n for k in range(side_cus))
+        for cu in range(n):
+            (side if cu in picked else main)[cu // 32] |= np.uint32(1 << (cu % 32))
+        self._check(self.lib.pbr_ctx_set_cu_masks(self.h, main.ctypes.data, side.ctypes.data, words))
+
     # ---- allocation helpers (torch = device memory plumbing) ---------------------------------
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.torch_device)

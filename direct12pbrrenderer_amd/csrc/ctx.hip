@@ -364,12 +364,37 @@ pbr_status pbr_halo_exchange(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint
 static pbr_status ensure_side(pbr_ctx* ctx) {
     if (ctx->side_stream) return PBR_OK;
     PBR_HIP(ctx, hipSetDevice(ctx->device));
-    int lo = 0, hi = 0;
-    PBR_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = greatest priority
-    PBR_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+    if (!ctx->side_cu_mask.empty()) {   // pbr_ctx_set_cu_masks: the side stream owns a set of CUs (no priority: it does not compete)
+        PBR_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)ctx->side_cu_mask.size(), ctx->side_cu_mask.data()));
+    } else {
+        int lo = 0, hi = 0;
+        PBR_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = greatest priority
+        PBR_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, hi));
+    }
+    if (ctx->ev_side_fork) return PBR_OK;
     PBR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_fork, hipEventDisableTiming));
     PBR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_join, hipEventDisableTiming));
     return PBR_OK;
+}
+
+pbr_status pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const uint32_t* side_mask, uint32_t words) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, !ctx->on_side && !ctx->side_pending, "pbr_ctx_set_cu_masks: side-stream work pending (pbr_ctx_side_end / _join first)");
+    PBR_REQUIRE(ctx, (main_mask == nullptr && side_mask == nullptr) || (words >= 1 && words <= 64), "pbr_ctx_set_cu_masks: 1 .. 64 mask words");
+    auto any = [&](const uint32_t* m) { for (uint32_t i = 0; m && i < words; i++) if (m[i]) return true; return m == nullptr; };
+    PBR_REQUIRE(ctx, any(main_mask) && any(side_mask), "pbr_ctx_set_cu_masks: an empty CU mask");
+    PBR_HIP(ctx, hipSetDevice(ctx->device));
+    PBR_HIP(ctx, hipDeviceSynchronize());
+    const bool on_own = ctx->stream == ctx->own_stream;
+    hipStream_t fresh = nullptr;
+    if (main_mask) PBR_HIP(ctx, hipExtStreamCreateWithCUMask(&fresh, words, main_mask));
+    else PBR_HIP(ctx, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    (void)hipStreamDestroy(ctx->own_stream);
+    ctx->own_stream = fresh;
+    if (on_own) ctx->stream = fresh;
+    if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
+    ctx->side_cu_mask.assign(side_mask ? side_mask : nullptr, side_mask ? side_mask + words : nullptr);
+    return ensure_side(ctx);
 }
 
 pbr_status pbr_ctx_side_begin(pbr_ctx* ctx) {

@@ -30,6 +30,7 @@ struct pbr_ctx {
     hipStream_t side_stream = nullptr, main_saved = nullptr;
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
     bool on_side = false, side_pending = false, main_was_null = false;
+    std::vector<uint32_t> side_cu_mask;   // pbr_ctx_set_cu_masks: the side stream's CUs (empty: all, high priority)
 };
 
 namespace pbr {

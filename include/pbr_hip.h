@@ -157,6 +157,15 @@ void*       pbr_ctx_get_stream(const pbr_ctx* ctx);
 pbr_status  pbr_ctx_side_begin(pbr_ctx* ctx);
 pbr_status  pbr_ctx_side_end(pbr_ctx* ctx);
 pbr_status  pbr_ctx_side_join(pbr_ctx* ctx);
+/* Partition the device's compute units between the context's private stream and its side stream (throughput mode: a frame's bloom +
+ * exposure tail on the side stream's CUs while the next frame's shade has the others to itself — two kernels that both want the whole
+ * chip only take turns otherwise).  masks: bit i = CU i (hipExtStreamCreateWithCUMask), `words` 32-bit words each; NULL = every CU.
+ * On MI355X the bits run XCD by XCD in groups of four (bits 0-3 = four CUs of XCD 0, 4-7 = of XCD 1, ... 32-35 = the next four of XCD 0),
+ * and a kernel's workgroups are dealt to the XCDs in equal shares whatever their CU counts: a partition must hold the same number of CUs
+ * of every XCD (a multiple of 32 low bits), or its XCD with the fewest sets the pace (measured: profiles/r04_h_cu_partition_*.txt).
+ * Recreates both streams (the context must be idle on its private stream: pbr_ctx_use_own_stream, no side work pending) and
+ * waits for the device.  A context bound to a foreign stream (pbr_ctx_set_stream) keeps that stream: only the side stream is masked. */
+pbr_status  pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const uint32_t* side_mask, uint32_t words);
 const char* pbr_last_error(const pbr_ctx* ctx);
 /* blocks until everything enqueued through the context is done: its stream AND side-stream work not joined yet */
 pbr_status  pbr_sync(pbr_ctx* ctx);

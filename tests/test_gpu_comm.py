@@ -270,6 +270,39 @@ def test_overlapped_frame_tail_equals_the_plain_order():
     assert r.returncode == 0 and "tail overlap ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
 
 
+@pytest.mark.timeout(400)
+def test_cu_partition_renders_the_same_frames():
+    """pbr_ctx_set_cu_masks: the device's CUs split between the context's private stream and its side stream (64 CUs = 8 per XCD for
+    the side stream) — in order and in post-shade throughput mode the frames are those of the unpartitioned in-order render; and the
+    contract: an empty mask, or a call while side work is pending, is refused.  Own process: the masks recreate the context's streams."""
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from direct12pbrrenderer_amd.api import PbrContext, PbrError
+ctx = PbrContext(0)
+ctx.use_own_stream()
+zero = np.zeros(8, np.uint32); full = np.full(8, 0xFFFFFFFF, np.uint32)
+for args, why in (((zero.ctypes.data, full.ctypes.data, 8), "empty CU mask"), ((full.ctypes.data, full.ctypes.data, 0), "mask words")):
+    try:
+        ctx._check(ctx.lib.pbr_ctx_set_cu_masks(ctx.h, *args)); raise SystemExit("accepted: " + why)
+    except PbrError as e:
+        assert why in str(e), e
+ctx.side_begin()
+try:
+    ctx.partition_cus(64); raise SystemExit("accepted while on the side stream")
+except PbrError as e:
+    assert "pending" in str(e), e
+ctx.side_end(); ctx.side_join(); ctx.sync()
+ctx.close()
+print("contract ok")
+""" % ROOT
+    r = subprocess.run(["timeout", "-k", "10", "120", sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "contract ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    r = subprocess.run(["timeout", "-k", "10", "300", sys.executable, os.path.join(ROOT, "tools", "cu_partition.py"), "low", "0", "64"], capture_output=True, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("[low] side CUs")]
+    assert r.returncode == 0 and len(lines) == 2 and all(l.endswith("True") for l in lines), (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_halo_pack_unpack_roundtrip(ctx):
     """The two halves of pbr_halo_exchange on their own (what a non-RCCL transport uses): staging layout = all send
     rectangles in peer order, then all recv rectangles."""
