@@ -100,7 +100,13 @@ class PbrContext:
         # are dealt to the XCDs in equal shares whatever their CU counts — so both partitions must hold the SAME number of CUs of every
         # XCD, or the XCD with the fewest sets the pace: the side stream gets the low side_cus bits, side_cus a multiple of 32
         # (layout="strided": every (n / side_cus)-th bit instead, for the measurement of exactly that effect).
-        picked = set(range(side_cus)) if layout == "low" else set(int(round(k * n / side_cus)) % n for k in range(side_cus))
+        if layout == "low":          # the low side_cus bits: even per XCD only for multiples of 32
+            picked = set(range(side_cus))
+        elif layout == "per_xcd":    # side_cus / 8 CUs of EVERY XCD (bit = 32 * (j // 4) + 4 * xcd + j % 4 for the j-th CU of an XCD)
+            k = side_cus // 8
+            picked = set(32 * (j // 4) + 4 * x + (j % 4) for x in range(8) for j in range(k))
+        else:                        # "strided": every (n / side_cus)-th bit — uneven per XCD, for the measurement of exactly that effect
+            picked = set(int(round(i * n / side_cus)) % n for i in range(side_cus))
         for cu in range(n):
             (side if cu in picked else main)[cu // 32] |= np.uint32(1 << (cu % 32))
         self._check(self.lib.pbr_ctx_set_cu_masks(self.h, main.ctypes.data, side.ctypes.data, words))

@@ -162,7 +162,8 @@ pbr_status  pbr_ctx_side_join(pbr_ctx* ctx);
  * chip only take turns otherwise).  masks: bit i = CU i (hipExtStreamCreateWithCUMask), `words` 32-bit words each; NULL = every CU.
  * On MI355X the bits run XCD by XCD in groups of four (bits 0-3 = four CUs of XCD 0, 4-7 = of XCD 1, ... 32-35 = the next four of XCD 0),
  * and a kernel's workgroups are dealt to the XCDs in equal shares whatever their CU counts: a partition must hold the same number of CUs
- * of every XCD (a multiple of 32 low bits), or its XCD with the fewest sets the pace (measured: profiles/r04_h_cu_partition_*.txt).
+ * of every XCD, and a group of four bits is honoured as a whole only — i.e. a multiple of 32 low bits — or its XCD with the fewest sets the
+ * pace (measured: profiles/r04_h_cu_partition_*.txt, r04_j_cu_partition_per_xcd.txt).
  * Recreates both streams (the context must be idle on its private stream: pbr_ctx_use_own_stream, no side work pending) and
  * waits for the device.  A context bound to a foreign stream (pbr_ctx_set_stream) keeps that stream: only the side stream is masked. */
 pbr_status  pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const uint32_t* side_mask, uint32_t words);

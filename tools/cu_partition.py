@@ -58,7 +58,7 @@ def signature(fr, frames=5):
 
 layout = "low"
 args = sys.argv[1:]
-if args and args[0] in ("low", "strided"):
+if args and args[0] in ("low", "strided", "per_xcd"):
     layout, args = args[0], args[1:]
 counts = [int(v) for v in args] or [0, 16, 24, 32, 40, 48, 64]
 ref = None
