@@ -1021,6 +1021,32 @@ def test_bloom_2x_up_levels_polyphase_and_shader_order(knobs, exact, sizes):
 
 
 @pytest.mark.gpu
+def test_bloom_4k_constant_field_is_uniform_and_size_independent(ctx, orc):
+    """A size-independent property at BASELINE's full size (3840x2160: both polyphase instances run, 2 040 + 510 tiles): a constant HDR
+    field stays constant through every level (clamp addressing, weights summing to 0.9999 per pass), so the bloomed frame is ONE value
+    everywhere — borders, tile seams, the partial bottom tiles — and that value is the one the oracle computes on a small constant
+    image (<= 1 fp16 ULP: the polyphase levels; the small image takes the shader-order kernels)."""
+    W, H = 3840, 2160
+    for rgb in ((2.0, 1.5, 0.75), (6.0, 0.5, 0.25)):
+        small = np.zeros((72, 128, 4), np.float16)
+        small[..., :3] = rgb
+        small[..., 3] = 1.0
+        want = small.copy()
+        orc.bloom(want)
+        assert (want.reshape(-1, 4) == want[0, 0]).all()          # the oracle agrees that the field stays constant
+        img = torch.zeros((H, W, 4), dtype=torch.float16, device="cuda")
+        img[..., 0], img[..., 1], img[..., 2], img[..., 3] = rgb[0], rgb[1], rgb[2], 1.0
+        hist = ctx.zeros((256,), torch.int32)
+        ctx.bloom_histogram(img, W, H, W, ctx.alloc_bloom_chain(W, H), ctx.alloc_bloom_chain(W, H), (0, 0, W, H), hist)
+        ctx.sync()
+        flat = img.view(-1, 4)
+        assert bool((flat == flat[0]).all()), "the bloomed constant field is not uniform"
+        got = flat[0].cpu().view(torch.int16).numpy().view(np.float16)
+        assert common.half_ulp_diff(got[:3], want[0, 0, :3]).max() <= 1, (got, want[0, 0])
+        assert int(hist.sum()) == W * H and int((hist > 0).sum()) == 1    # one luminance, one bin
+
+
+@pytest.mark.gpu
 def test_deferred_shade_attenuation_floor_and_odd_lists(ctx, orc, ibl):
     """Lights whose attenuation polynomial can drop below the shader's 1e-6 floor (C0 = 0: the floor binds near the
     light) take the kernel's unhoisted-floor path; 7 lights give odd per-cluster lists (padded with the null light)."""
