@@ -92,14 +92,33 @@ CASES = [(2, None, False, 512, 288, False), (3, None, False, 512, 288, False), (
          (3, None, True, 832, 400, True)]
 
 
+# the last two cases: the ranks load the knobs build with PBR_BLOOM_WIDE=1, so every 2x-up level of their (small) tiles runs the
+# POLYPHASE kernel — its merge rectangle / buffer origin / interior-only histogram (pbr_bloom_tiled, pbr_bloom_histogram with a
+# rect), which the frame sizes of this file would otherwise leave to k_blur_hv; the single frame they are compared with runs in this
+# process on the product library (shader-order kernels at this size): <= 2 fp16 ULP as everywhere in this file
+CASES += [(2, None, True, 512, 288, "poly"), (4, (2, 2), False, 384, 288, "poly")]
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("world,layout,halo,tile_w,tile_h,overlap", CASES)
 def test_ranks_match_single_gpu_frame(ctx, ibl, world, layout, halo, tile_w, tile_h, overlap):
     from direct12pbrrenderer_amd.pipeline import TileSpec, grid_for_world
     cols, rows = grid_for_world(world, layout)
-    with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d, layout, halo, tile_w, tile_h, overlap), nprocs=world, join=True)
-        ranks = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
+    poly, overlap = overlap == "poly", overlap is True
+    saved = {k: os.environ.get(k) for k in ("PBR_HIP_LIB", "PBR_BLOOM_WIDE")}
+    if poly:   # spawned ranks inherit the environment; this process has loaded the product library long ago
+        os.environ["PBR_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "direct12pbrrenderer_amd", "libpbr_hip_knobs.so")
+        os.environ["PBR_BLOOM_WIDE"] = "1"
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_worker, args=(world, _free_port(), d, layout, halo, tile_w, tile_h, overlap), nprocs=world, join=True)
+            ranks = [dict(np.load(os.path.join(d, f"rank{r}.npz"))) for r in range(world)]
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     W, H = tile_w * cols, tile_h * rows
     fr = _frame(ctx, TileSpec(0, 0, W, H, W, H, 0), _ibl_dev(ctx, ibl), ibl[3])
     full_hdr = fr.hdr_interior()
