@@ -266,6 +266,84 @@ def test_reference_scene_lights_reach_the_light_buffer_verbatim():
     assert L.pbrh_light_buffer(1440, 960, cp.ctypes.data, got.ctypes.data, n, buf.ctypes.data, 4) == -1    # a buffer too small is an error
 
 
+def test_scene_file_reader_survives_mutated_input():
+    """Property test (hypothesis): whatever bytes arrive, the scene-file reader of the C++ host answers with a count or with -1 and a
+    reason — never a crash (tools/asan_cpu.sh runs this against the ASan + UBSan build); documents in the serializer's shape
+    round-trip every float exactly."""
+    import ctypes as C
+    import json
+    from hypothesis import given, settings, strategies as st
+    L = _host_lib()
+    L.pbrh_parse_scene_lights.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    err = C.create_string_buffer(256)
+    f32 = st.floats(min_value=-400.0, max_value=400.0, width=32)
+    pos32 = st.floats(min_value=0.125, max_value=64.0, width=32)
+    vec = st.fixed_dictionaries({"x": f32, "y": f32, "z": f32})
+    light = st.fixed_dictionaries({"@SceneObject": st.fixed_dictionaries({"mName": st.text(max_size=12), "mTranslation": vec,
+                                                                          "mRotation": st.just({"x": 0.0, "y": 0.0, "z": 0.0}),
+                                                                          "mScale": st.just({"x": 1.0, "y": 1.0, "z": 1.0})}),
+                                   "mColor": vec, "mRadius": pos32, "mIntensity": pos32})
+    base = common.scene_json_text(common.reference_scene_lights()).encode()
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(light, max_size=6), st.booleans())
+    def roundtrip(lights, pretty):
+        text = json.dumps({"mSceneLight": lights, "mSkyBoxPath": "x"}, indent=1 if pretty else None, ensure_ascii=pretty).encode()
+        got = np.zeros((max(len(lights), 1), 8), np.float32)
+        assert L.pbrh_parse_scene_lights(text, len(text), got.ctypes.data, len(lights), err, 256) == len(lights), err.value
+        for i, l in enumerate(lights):
+            t, c = l["@SceneObject"]["mTranslation"], l["mColor"]
+            want = np.float32([t["x"], t["y"], t["z"], c["x"], c["y"], c["z"], l["mRadius"], l["mIntensity"]])
+            assert np.array_equal(got[i], want)
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(0, len(base) - 1), st.integers(0, 255), st.integers(0, len(base)))
+    def mutated(pos, byte, cut):
+        blob = bytearray(base)
+        blob[pos] = byte
+        for data in (bytes(blob), bytes(blob[:cut]), base[:cut] + bytes([byte]) + base[cut:]):
+            out = np.zeros((16, 8), np.float32)
+            n = L.pbrh_parse_scene_lights(data, len(data), out.ctypes.data, 16, err, 256)
+            assert n == -1 or 0 <= n <= 16, n
+            assert n != -1 or err.value                    # a refusal names its reason
+
+    roundtrip()
+    mutated()
+
+
+def test_hdr_parser_survives_mutated_input():
+    """The same property for the Radiance .hdr reader: mutated and truncated files (flat and run-length coded) are parsed or refused with
+    a reason, the declared size bounds the output, nothing crashes."""
+    import ctypes as C
+    import hdr_writer
+    from hypothesis import given, settings, strategies as st
+    L = _host_lib()
+    L.pbrh_parse_hdr.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0.0, 4.0, size=(9, 16, 3)).astype(np.float32)
+    rgbe = hdr_writer.float_to_rgbe(img)
+    bases = [hdr_writer.encode_hdr(rgbe, rle=False), hdr_writer.encode_hdr(rgbe, rle=True)]
+    err = C.create_string_buffer(256)
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(0, 1), st.integers(0, 4000), st.integers(0, 255), st.integers(0, 4000))
+    def mutated(which, pos, byte, cut):
+        base = bases[which]
+        blob = bytearray(base)
+        blob[pos % len(blob)] = byte
+        for data in (bytes(blob), bytes(blob[:cut % (len(blob) + 1)])):
+            w, h = C.c_uint32(0), C.c_uint32(0)
+            st_ = L.pbrh_parse_hdr(data, len(data), C.byref(w), C.byref(h), None, 0, err, 256)
+            assert st_ in (0, -1)
+            if st_ == 0 and 0 < w.value * h.value <= 1 << 16:
+                out = np.zeros((h.value, w.value, 4), np.uint8)
+                assert L.pbrh_parse_hdr(data, len(data), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes, err, 256) in (0, -1)
+            elif st_ == -1:
+                assert err.value
+
+    mutated()
+
+
 # ------------------------------------------------------------------------- SURVEY 8f row 3: .hdr ingestion
 def _parse_hdr(L, blob, cap=None):
     import ctypes as C
