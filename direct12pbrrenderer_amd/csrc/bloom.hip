@@ -45,7 +45,7 @@ struct OutRects {
     int x0[PF_MAX_RECTS], y0[PF_MAX_RECTS], x1[PF_MAX_RECTS], y1[PF_MAX_RECTS], tiles_x[PF_MAX_RECTS], first[PF_MAX_RECTS + 1];
 };
 __global__ __launch_bounds__(256) void k_bloom_prefilter(const pbr_half* __restrict__ hdr, int w, int h, int pitch,
-                                                           pbr_half* __restrict__ out, int ow, int oh, OutRect rc,
+                                                           pbr_half* __restrict__ out, OutRect rc,
                                                            float tx, float ty, float threshold, float knee) {
     const int x = rc.x0 + blockIdx.x * 64 + threadIdx.x;
     const int y = rc.y0 + blockIdx.y * 4 + threadIdx.y;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_bloom_merge(pbr_half* __restrict__ hdr,
 
 constexpr int PF_TW = 64, PF_TH = 16;
 __global__ __launch_bounds__(256) void k_bloom_prefilter_2x(const pbr_half* __restrict__ hdr, int w, int h, int pitch,
-                                                              pbr_half* __restrict__ out, int ow, int oh, OutRects rs, float threshold, float knee) {
+                                                              pbr_half* __restrict__ out, OutRects rs, float threshold, float knee) {
     __shared__ float4 pos[PF_TH + 2][PF_TW + 2];   // (colour * weight, weight) of every sample position the tile touches
     const int tid = threadIdx.x;
     int r = 0;
@@ -1167,13 +1167,13 @@ static pbr_status prefilter_launch(pbr_ctx* ctx, const pbr_half* hdr, uint32_t w
             blocks += rs.tiles_x[r] * ((rcs[r].y1 - rcs[r].y0 + PF_TH - 1) / PF_TH);
         }
         rs.first[n] = blocks;
-        hipLaunchKernelGGL(k_bloom_prefilter_2x, dim3(blocks), dim3(256), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, rs, threshold, knee);
+        hipLaunchKernelGGL(k_bloom_prefilter_2x, dim3(blocks), dim3(256), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, rs, threshold, knee);
         return launched(ctx, "k_bloom_prefilter_2x");
     }
     for (int r = 0; r < n; r++) {
         const uint32_t rw = (uint32_t)(rcs[r].x1 - rcs[r].x0), rh = (uint32_t)(rcs[r].y1 - rcs[r].y0);
         dim3 grid((rw + 63) / 64, (rh + 3) / 4);
-        hipLaunchKernelGGL(k_bloom_prefilter, grid, dim3(64, 4), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, (int)ow, (int)oh, rcs[r], tx, ty, threshold, knee);
+        hipLaunchKernelGGL(k_bloom_prefilter, grid, dim3(64, 4), 0, ctx->stream, hdr, (int)w, (int)h, (int)pitch, out, rcs[r], tx, ty, threshold, knee);
         pbr_status st = launched(ctx, "k_bloom_prefilter");
         if (st) return st;
     }

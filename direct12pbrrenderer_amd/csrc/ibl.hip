@@ -541,9 +541,9 @@ __global__ __launch_bounds__(PF_FOOT_BLOCK) __attribute__((amdgpu_waves_per_eu(8
         if (HALF) pf_level_half(ar, ag, ab, foot, la, facef, cu, cv, wl.x);
         else pf_level_f32(ar, ag, ab, chain32, la, facef, cu, cv, wl.x);
         if (word & PF_TWO_LEVELS) {   // scalar branch
-            const PfLevel lb = fo.lev[l0 + 1u];
-            if (HALF) pf_level_half(br, bg, bb, foot, lb, facef, cu, cv, wl.y);
-            else pf_level_f32(br, bg, bb, chain32, lb, facef, cu, cv, wl.y);
+            const PfLevel lnext = fo.lev[l0 + 1u];
+            if (HALF) pf_level_half(br, bg, bb, foot, lnext, facef, cu, cv, wl.y);
+            else pf_level_f32(br, bg, bb, chain32, lnext, facef, cu, cv, wl.y);
         }
     }
     const float w = pl.wsum[mip];   // 0 samples -> 0/0 = NaN like the reference
