@@ -75,6 +75,7 @@ SIGNATURES = {
     "pbr_runtime_error": (C.c_char_p, []),
     "pbr_runtime_mismatch_dirs": (_int, [C.c_char_p, C.c_char_p]),
     "pbr_membench_read": (_int, [_vp, _vp, _sz, _vp, _u32]),
+    "pbr_valubench": (_int, [_vp, _u32, _u32, _u32, _vp]),
 }
 
 _lib = None

@@ -301,6 +301,11 @@ class PbrContext:
         """One streaming-read pass over `buf` (measurement aid: the device's achievable HBM-read bandwidth)."""
         self._check(self.lib.pbr_membench_read(self.h, _ptr(buf), buf.numel() * buf.element_size(), _ptr(sink), blocks))
 
+    def valubench(self, op, blocks, iters, stamps):
+        """pbr_valubench: blocks x 4 waves issue iters x 8 instructions of class op (0 v_mul_f32, 1 v_fma_f32, 2 v_pk_fma_f32,
+        3 v_rcp_f32); stamps: int64 [blocks * 4, 4] device tensor = {shader cycles start, end, 100 MHz ticks start, end} per wave"""
+        self._check(self.lib.pbr_valubench(self.h, int(op), int(blocks), int(iters), _ptr(stamps)))
+
     # ---- multi-GPU --------------------------------------------------------------------------------
     def comm_init(self, world, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None

@@ -255,6 +255,55 @@ extern "C" pbr_status pbr_membench_read(pbr_ctx* ctx, const void* buf, size_t by
     return pbr::launched(ctx, "k_membench_read");
 }
 
+// ------------------------------------------------------------------------------------------- VALU issue-rate probe
+// (the loop of tools/valu_rate3.hip as a library entry: bench.py measures the issue rate and the sustained shader clock on the
+//  box it runs on.)  Eight independent accumulators per lane, so a wave never waits for its own previous result.
+typedef float vb_f2 __attribute__((ext_vector_type(2)));
+template <int OP>
+__global__ __launch_bounds__(256) void k_valubench(uint64_t* __restrict__ stamps, int iters) {
+    float x0 = threadIdx.x + 1.5f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    const float y0 = 1.0f + 1e-7f * threadIdx.x, y1 = 1.0f - 1e-7f * threadIdx.x;
+    vb_f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, p4 = {x1, x0}, p5 = {x3, x2}, p6 = {x5, x4}, p7 = {x7, x6};
+    const vb_f2 q0 = {y0, y1}, q1 = {y1 * 1e-9f, y0 * 1e-9f};
+    const uint64_t r0 = wall_clock64(), c0 = clock64();
+    for (int i = 0; i < iters; i++) {
+        if (OP == 0)
+            asm volatile("v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %9\n\tv_mul_f32 %2, %2, %8\n\tv_mul_f32 %3, %3, %9\n\t"
+                         "v_mul_f32 %4, %4, %8\n\tv_mul_f32 %5, %5, %9\n\tv_mul_f32 %6, %6, %8\n\tv_mul_f32 %7, %7, %9"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y0), "v"(y1));
+        else if (OP == 1)
+            asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %9, %8\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %9, %8\n\t"
+                         "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %9, %8\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %9, %8"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(y0), "v"(y1));
+        else if (OP == 2)
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n\tv_pk_fma_f32 %1, %1, %9, %8\n\tv_pk_fma_f32 %2, %2, %8, %9\n\tv_pk_fma_f32 %3, %3, %9, %8\n\t"
+                         "v_pk_fma_f32 %4, %4, %8, %9\n\tv_pk_fma_f32 %5, %5, %9, %8\n\tv_pk_fma_f32 %6, %6, %8, %9\n\tv_pk_fma_f32 %7, %7, %9, %8"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(q0), "v"(q1));
+        else
+            asm volatile("v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %2, %2\n\tv_rcp_f32 %3, %3\n\t"
+                         "v_rcp_f32 %4, %4\n\tv_rcp_f32 %5, %5\n\tv_rcp_f32 %6, %6\n\tv_rcp_f32 %7, %7"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    }
+    const uint64_t c1 = clock64(), r1 = wall_clock64();
+    // keep every accumulator alive without a store the timed loop could be blamed for
+    asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7), "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7));
+    if ((threadIdx.x & 63) == 0) {
+        uint64_t* s = stamps + 4 * ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
+        s[0] = c0; s[1] = c1; s[2] = r0; s[3] = r1;
+    }
+}
+
+extern "C" pbr_status pbr_valubench(pbr_ctx* ctx, uint32_t op, uint32_t blocks, uint32_t iters, uint64_t* stamps) {
+    if (!ctx) return PBR_ERR_INVALID;
+    PBR_REQUIRE(ctx, stamps && op <= 3 && blocks >= 1 && blocks <= 65535 && iters >= 1 && iters <= (1u << 24), "pbr_valubench: bad arguments");
+    const dim3 g(blocks), b(256);
+    if (op == 0) hipLaunchKernelGGL(k_valubench<0>, g, b, 0, ctx->stream, stamps, (int)iters);
+    else if (op == 1) hipLaunchKernelGGL(k_valubench<1>, g, b, 0, ctx->stream, stamps, (int)iters);
+    else if (op == 2) hipLaunchKernelGGL(k_valubench<2>, g, b, 0, ctx->stream, stamps, (int)iters);
+    else hipLaunchKernelGGL(k_valubench<3>, g, b, 0, ctx->stream, stamps, (int)iters);
+    return pbr::launched(ctx, "k_valubench");
+}
+
 // ------------------------------------------------------------------------------------------- halo exchange
 // Level-1 strips of the bloom pyramid between neighbouring tiles (SURVEY 8e option 2).  One pack launch gathers every
 // outgoing rectangle of the plane into a contiguous staging area, one ncclGroup sends / receives all strips, one

@@ -46,6 +46,12 @@ void PreFilterEnvMapPass::Execute(FGContext* context) {   // DeferredPipeline.cp
     SkyBox* sky = context->Scene->GetSkyBox();
     if (!sky) return;
     PIXScope(context->CommandList, "Precompute PrefilterEnvMap Pass");
+    if (context->CommandList->FusedPasses()) {   // the five dispatches below as one call (same roughness ladder: mip / 4)
+        auto* cube = dynamic_cast<DeviceTexture2DArray*>(sky->Resource());
+        if (!cube) throw HipException("PreFilterEnvMapPass: the sky box is not a cube texture");
+        context->CommandList->PrefilterEnv(cube, mPrefilterEnvMap.get());
+        return;
+    }
     for (uint32 i = 0; i < PreFilterEnvMapMipsLevel; i++) {
         ShadingState& st = mShadingState[i];
         st.SetShader("env_map_gen.hlsl", true);

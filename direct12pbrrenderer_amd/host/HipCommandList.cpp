@@ -401,6 +401,15 @@ void HipCommandList::DrawScreen(ShadingState* s) {
     }
 }
 
+void HipCommandList::PrefilterEnv(DeviceTexture2DArray* sky, DeviceTexture2DArray* out) {
+    if (!sky || !out) throw HipException("PrefilterEnv: null texture");
+    mDispatchCount++;
+    FlushPendingBloom();
+    pbr_cube_f32 cube{(const float*)sky->DevicePtr(), sky->Size(), sky->MipLevels()};
+    Check(pbr_prefilter_env(mCtx, &cube, out->Size(), out->MipLevels(), (pbr_half*)out->DevicePtr()), "pbr_prefilter_env");
+    mPaddedEnv.erase(out);   // the padded copy the shade samples is stale now
+}
+
 void HipCommandList::Clustered(DeviceStructuredBuffer* clusters, DeviceStructuredBuffer* point_lights, int32 num_lights) {
     if (!clusters || !point_lights) throw HipException("Clustered: null buffer");
     mDispatchCount++;

@@ -93,6 +93,10 @@ public:
     // them when FusedPasses() is on; off (default) every reference dispatch is issued one by one.
     void SetFusedPasses(bool on) { mFusedPasses = on; }
     bool FusedPasses() const { return mFusedPasses; }
+    // PreFilterEnvMapPass::Execute's five env_map_gen.hlsl dispatches (DeferredPipeline.cpp:97-113) as ONE pbr_prefilter_env:
+    // roughness = mip / (mips - 1) for every mip of `out` — what the five constant buffers say; <= 1 fp16 ULP from the
+    // dispatch-by-dispatch chain, 6-10 x faster (the per-dispatch kernel keeps the shader's sequential sum)
+    void PrefilterEnv(DeviceTexture2DArray* sky, DeviceTexture2DArray* out);
     // ClusteredPass::Execute's two dispatches (pbr_clustered)
     void Clustered(DeviceStructuredBuffer* clusters, DeviceStructuredBuffer* point_lights, int32 num_lights);
     // BloomPass::Execute's sixteen dispatches (pbr_bloom); mip_chain / temp are scratch afterwards.  With fused passes the

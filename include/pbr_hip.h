@@ -401,6 +401,14 @@ pbr_status pbr_halo_pack(pbr_ctx* ctx, pbr_half* plane, uint32_t pitch, uint32_t
  * block into sink[blocks]) on the ctx stream: the kernel bench.py times to report the MEASURED HBM-read bandwidth of
  * the device next to the 8 TB/s nominal peak.  buf 16-byte aligned. */
 pbr_status pbr_membench_read(pbr_ctx* ctx, const void* buf, size_t bytes, uint32_t* sink, uint32_t blocks);
+/* VALU issue-rate probe: `blocks` blocks of 256 lanes (one wave per SIMD each; blocks = CUs x waves-per-SIMD fills the
+ * chip at that occupancy), every wave issuing iters x 8 independent instructions of one class — op 0: v_mul_f32 (the plain
+ * class), 1: v_fma_f32, 2: v_pk_fma_f32 (packed fp32), 3: v_rcp_f32 (transcendental) — between two reads of the shader-core
+ * cycle counter (s_memtime) and of the constant 100 MHz counter (s_memrealtime).  stamps: DEVICE, 4 x uint64 per wave
+ * {cycles at start, at end, 100 MHz ticks at start, at end}, blocks * 4 waves.  With the launch duration (HIP events on the
+ * ctx stream) this gives the chip's sustained issue rate in wave-instructions/s for that class AND the shader clock it holds
+ * under that load — the denominators bench.py's `roofline.valu` needs from the box it runs on, not from a committed file. */
+pbr_status pbr_valubench(pbr_ctx* ctx, uint32_t op, uint32_t blocks, uint32_t iters, uint64_t* stamps);
 
 #ifdef __cplusplus
 }

@@ -347,3 +347,26 @@ def test_membench_read_touches_every_byte(ctx):
     ctx.sync()
     got = np.bitwise_xor.reduce(sink.cpu().numpy().view(np.uint32))
     assert got == np.bitwise_xor.reduce(a.view(np.uint32))
+
+
+def test_valubench_stamps_cycles_and_clock(ctx):
+    """The VALU issue-rate probe of bench.py: every wave reports more shader cycles than instructions it issued (a wave64 fp32
+    instruction cannot issue faster than one per cycle), a clock between 0.5 and 3 GHz from the two counters, and the slow classes
+    cost more cycles than the plain one; bad arguments are refused."""
+    blocks, iters = 256, 2000
+    st = torch.zeros((blocks * 4, 4), dtype=torch.int64, device="cuda")
+    per_inst = {}
+    for op in (0, 2, 3):
+        st.zero_()
+        ctx.valubench(op, blocks, iters, st)
+        ctx.sync()
+        s = st.cpu().numpy()
+        cyc, ticks = s[:, 1] - s[:, 0], s[:, 3] - s[:, 2]
+        assert (cyc > iters * 8).all() and (ticks > 0).all()
+        clock = np.median(cyc / ticks) * 100e6
+        assert 0.5e9 < clock < 3.0e9, clock
+        per_inst[op] = float(np.median(cyc)) / (iters * 8)
+    assert per_inst[0] < per_inst[2] < per_inst[3] * 1.05 and per_inst[3] > 1.5 * per_inst[0], per_inst
+    from direct12pbrrenderer_amd.api import PbrError
+    with pytest.raises(PbrError):
+        ctx.valubench(7, blocks, iters, st)

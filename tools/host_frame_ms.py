@@ -28,6 +28,21 @@ for fused in (0, 1):
         ms = r.render_n(frames)
         print(f"host pass graph, {'fused passes' if fused else 'dispatch by dispatch'}, {'fence per frame' if in_flight == 1 else '3 frames in flight'}: "
               f"{ms:.4f} ms/frame ({r.dispatch_count()} dispatches/frame) = {W * H / ms / 1e3:.0f} Mpixel/s", flush=True)
+# the first frame's IBL precompute through the pass API (PreFilterEnvMapPass::Execute, DeferredPipeline.cpp:77-115): a frame right
+# after set_skybox (which invalidates the pass) minus a steady frame, dispatch by dispatch (five pbr_prefilter_env_mip) and fused
+# (one pbr_prefilter_env)
+r.set_frames_in_flight(1)
+for fused in (0, 1):
+    r.set_fused(fused)
+    steady = r.render_n(20)
+    first = []
+    for _ in range(3):
+        r.set_skybox(synth.env_cube(ENV), ENV)
+        first.append(r.render_n(1))
+    print(f"host pass graph, {'fused passes' if fused else 'dispatch by dispatch'}: frame with the env prefilter {min(first):.3f} ms, steady frame {steady:.3f} ms "
+          f"-> PreFilterEnvMapPass {min(first) - steady:.3f} ms", flush=True)
+r.set_fused(1)
+r.set_frames_in_flight(3)
 r.set_tail_overlap(True)
 r.render_n(frames)
 ms = r.render_n(frames)
