@@ -655,14 +655,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 template <int LSTRIDE>
 __device__ __forceinline__ uint2 ff_prepass(const ShadeParams& p, const float* llds, const uint16_t* lists, int tile_y0, int tiles_x, float lmax1,
-                                            bool active, uint32_t px, uint32_t py, float4 row, float u, int sx_rel) {
+                                            bool covered, uint32_t b, float depth_ndc, float4 row, float u, int sx_rel) {
     uint32_t mask = 0, key = FF_KEYS - 1, slot = 0;
-    if (active) {
-        const uint32_t gi = __umul24(py, p.pitch) + px;
-        if (p.stencil[gi] != 0) {   // stencil ref 0 < value (DeferredPipeline.h:176-181)
+    {
+        if (covered) {   // inside the rectangle and stencil ref 0 < value (DeferredPipeline.h:176-181)
             const float inv255 = 1.0f / 255.0f;
-            const uint32_t b = p.B[gi];
-            const float depth_ndc = p.depth[gi];
             // world position: the lines of shade_pixel's phase 1
             const float ndc_x = 2.0f * u - 1.0f;
             const V3 cvv = v3(ndc_x * 0.5f * p.near_width, row.y, p.Near);
@@ -685,7 +682,7 @@ __device__ __forceinline__ uint2 ff_prepass(const ShadeParams& p, const float* l
             sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
             slot = (uint32_t)(__mul24(__mul24((int)row.z - tile_y0, tiles_x) + sx_rel, PBR_CLUSTER_Z) + sz);
             typedef const __attribute__((address_space(3))) uint16_t lds_u16;
-            lds_u16* my = (lds_u16*)(lists + slot * FF_LIST_H);
+            lds_u16* my = (lds_u16*)(lists + __umul24(slot, FF_LIST_H));
             const int cnt = my[0];
             const float margin = 3.814697265625e-6f * (lmax1 + (fabsf(pos.x) + fabsf(pos.y) + fabsf(pos.z)));
             const f2 c0 = f2s(margin - dot3(d, pos));
@@ -717,8 +714,11 @@ __device__ __forceinline__ uint2 ff_prepass(const ShadeParams& p, const float* l
     return make_uint2(mask, slot | key << 7);
 }
 
+#ifndef SHADE_FF_MIN_WAVES
+#define SHADE_FF_MIN_WAVES SHADE_MIN_WAVES
+#endif
 template <int LSTRIDE, bool F32OUT>
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade_ff(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_FF_MIN_WAVES) void k_deferred_shade_ff(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
     extern __shared__ float4 lds_raw[];
     __shared__ uint32_t s_mip_off[16];
     __shared__ float4 s_row[SHADE_ROWS];
@@ -772,19 +772,20 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     const int ty_a = ty(y_begin), ty_b = ty(y_end - 1);
     const int tile_y0 = min(ty_a, ty_b), tile_y1 = max(ty_a, ty_b);
     const int tiles_x = tile_x1 - tile_x0 + 1;
-    {   // the lists of the cluster tiles the block can touch, as halfwords: [0] count, [1 .. 7] the null light, [8 + j] entry j (LDS byte addresses)
+    {   // the lists of the cluster tiles the block can touch, as halfwords: [0] count, [1 .. 7] the null light, [8 + j] entry j (LDS
+        // byte addresses).  A thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division, one index load per entry.
         const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
         const uint32_t null_addr = lds_base + 4u * (uint32_t)n_lights;
-        for (int e = threadIdx.x; e < n_cl * FF_LIST_H; e += SHADE_BLOCK) {
-            const int c = e / FF_LIST_H, j = e % FF_LIST_H;
-            const int z = c % PBR_CLUSTER_Z, t = c / PBR_CLUSTER_Z;
-            const int cx = tile_x0 + t % tiles_x, cy = tile_y0 + t / tiles_x;
+        const int j = threadIdx.x & 31;
+        for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
+            const int z = c & (PBR_CLUSTER_Z - 1), t = c >> 3;
+            static_assert(PBR_CLUSTER_Z == 8, "cluster slices");
+            const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
             const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
             const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-            uint32_t val = null_addr;
-            if (j == 0) val = (uint32_t)cnt;
-            else if (j >= FF_LIST_E && (j - FF_LIST_E) < cnt) val = lds_base + 4u * (uint32_t)min(max(cl->LightIndex[j - FF_LIST_E], 0), n_lights - 1);   // never index past the staged table
-            lists[e] = (uint16_t)val;
+            uint16_t* l = lists + c * FF_LIST_H;
+            l[FF_LIST_E + j] = (uint16_t)(j < cnt ? lds_base + 4u * (uint32_t)min(max(cl->LightIndex[j], 0), n_lights - 1) : null_addr);   // never index past the staged table
+            if (j < FF_LIST_E) l[j] = (uint16_t)(j == 0 ? (uint32_t)cnt : null_addr);
         }
     }
     if (threadIdx.x < (uint32_t)SHADE_ROWS) {
@@ -802,10 +803,27 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     {
         const float u = ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
         const int sx_rel = clampi((int)floorf(u * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1) - tile_x0;
-        for (uint32_t rr = 0; rr < nrows; rr++) {
-            const uint2 pr = ff_prepass<LSTRIDE>(p, llds, lists, tile_y0, tiles_x, lmax1, px < x_end, px, y_begin + rr, s_row[rr], u, sx_rel);
+        // The three plane words of a row are loaded a row ahead, all at once and unconditionally (a stencil test in front of the other two
+        // loads is a second memory round trip per row), as straight-line code (a branch around a load makes the compiler wait for ALL
+        // outstanding loads at the join, the prefetch included): lanes past the rectangle's edge and the row past its end read the
+        // nearest valid pixel and drop it.  Two rows per trip, each in its own registers: a copy `cur = next` would wait for the prefetch.
+        struct RowIn { uint32_t st, b; float depth; };
+        const uint32_t pxc = min(px, x_end - 1u);
+        auto load_row = [&](uint32_t rr) {
+            const uint32_t gi = __umul24(y_begin + min(rr, nrows - 1u), p.pitch) + pxc;
+            return RowIn{p.stencil[gi], p.B[gi], p.depth[gi]};
+        };
+        auto row = [&](const RowIn& in, uint32_t rr) {
+            const uint2 pr = ff_prepass<LSTRIDE>(p, llds, lists, tile_y0, tiles_x, lmax1, (in.st != 0u) & (px < x_end), in.b, in.depth, s_row[rr], u, sx_rel);
             const uint32_t rank = atomicAdd(&hist[pr.y >> 7], 1u);
             recs[rr * 64 + lane] = make_uint2(pr.x, pr.y | rank << 12);
+        };
+        RowIn a = load_row(0);
+        for (uint32_t rr = 0; rr < nrows; rr += 2) {
+            const RowIn b = load_row(rr + 1);
+            row(a, rr);
+            a = load_row(rr + 2);
+            if (rr + 1 < nrows) row(b, rr + 1);
         }
     }
     wave_lds_sync();
@@ -834,6 +852,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         wave_lds_sync();
         n_cov = hist[2 * FF_KEYS - 1];   // base of key 17 = the number of pixels to shade
     }
+#ifdef PBR_EXP_FF_P1ONLY   // diagnostic build (no image): what passes 1 and 2 cost
+    if (n_cov != 0xffffffffu) return;
+#endif
     // ---- pass 3: shade in sorted order
     for (uint32_t it = 0; it * 64u < n_cov; it++) {
         const uint32_t idx = it * 64u + (uint32_t)lane;
@@ -952,7 +973,11 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     const size_t lds = plane_bytes + (size_t)max_clusters * LIST_STRIDE * sizeof(uint32_t);
     const dim3 blk(SHADE_BLOCK);
     // the front-facing walk (k_deferred_shade_ff) wherever the lists can be staged: halfword lists + 4 KiB of sort records per wave
+#ifdef PBR_EXP_FF_OFF
+    static const int use_ff = 0;
+#else
     static const int use_ff = pbr::knob_int("PBR_SHADE_FF", 1);
+#endif
     const size_t ff_lds = (size_t)((LIGHT_PLANES * lstride + 3) & ~3) * sizeof(float) + (size_t)span_x * span_y * PBR_CLUSTER_Z * FF_LIST_H * sizeof(uint16_t) + (size_t)SHADE_BLOCK * SHADE_ROWS * sizeof(uint2);
     if (use_ff && span_x * span_y <= (uint32_t)MAX_STAGED_TILES && ff_lds + 1024 <= 65536) {
         const int ff_clusters = (int)(span_x * span_y) * PBR_CLUSTER_Z;

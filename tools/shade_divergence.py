@@ -88,3 +88,14 @@ for grp in (256, 512, 1024, 2048):
     print(f"pairs per wave, {grp:4d} pixels ({max(grp // 256, 1)} block rows) sorted by listed pairs: {per_wave(trips, grp):.2f}   by front-facing pairs: {per_wave(ftrips, grp):.2f}")
 hist = np.bincount(ftrips[covered].ravel(), minlength=17)
 print("front-facing pairs per pixel, share of the pixels: " + " ".join(f"{k}:{c / covered.sum():.3f}" for k, c in enumerate(hist) if c))
+
+
+def per_wave_cols(t, rows, cols=64):
+    """the kernel's own group: the cols x rows pixels one wave of k_deferred_shade_ff owns, sorted, 64 at a time"""
+    a = t.reshape(ROWS // rows, rows, W // cols, cols).transpose(0, 2, 1, 3).reshape(-1, rows * cols)
+    return np.sort(a, axis=-1).reshape(-1, 64).max(axis=1).mean()
+
+
+for rows in (1, 2, 4, 8, 16):
+    if ROWS % rows == 0:
+        print(f"pairs per wave-iteration, a wave's own 64 x {rows:2d} pixels sorted by front-facing pairs (k_deferred_shade_ff): {per_wave_cols(ftrips, rows):.2f}")
