@@ -29,6 +29,7 @@ struct ShadeParams {
     float near_width, near_height;   // 2 Near tan(Fov/2) [* Ratio]  (vs_main :94-95), host libm
     float log_far_near;              // log(Far/Near) of ClusterIndex (clustered.hlsli:53), host libm
     float inv_near, slice_k;         // 1 / Near and PBR_CLUSTER_Z / log2(Far/Near) (host, from double): the slice index's quick estimate
+    float inv_full_w;                // 1 / full_w (host): the front-facing walk's u
     uint32_t x0, y0, w, h, full_w, full_h;
     const uint32_t* A;
     const uint32_t* B;
@@ -205,7 +206,9 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
 
     // ---- phase 1: geometry (vs_main :91-121, screen triangle D3D12Device.cpp:167-176; uv from the GLOBAL pixel)
-    const float u = ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
+    // (FF: the pixel column changes with every record, so the IEEE divide is no longer loop-invariant; u only feeds the continuous
+    //  ndc_x there — the cluster column was fixed by the prepass with the exact expression — and takes the reciprocal's 1 ulp)
+    const float u = FF ? ((float)(p.x0 + px) + 0.5f) * p.inv_full_w : ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
     // v, cvv.y and the cluster row depend on the pixel ROW only: evaluated once per block row (k_deferred_shade, the same
     // expressions) and handed in as row = {v, cvv.y, cluster row} — an IEEE divide, a floor and their neighbours less per pixel
     V3 pos, view, n;
@@ -692,21 +695,38 @@ __device__ __forceinline__ uint2 ff_prepass(const ShadeParams& p, const float* l
             // groups: the loads of a whole list are in flight together.  The count that bounds the groups is the wave's (entries past
             // a lane's own count are the null light and are masked off below).
             const int cmax = __any(cnt > 24) ? 32 : __any(cnt > 16) ? 24 : __any(cnt > 8) ? 16 : 8;
-            auto pair = [&](uint32_t w) {
-                const lds_cf* la = (const lds_cf*)(uintptr_t)(w & 0xffffu);
-                const lds_cf* lb = (const lds_cf*)(uintptr_t)(w >> 16);
+            auto pair = [&](uint32_t ea, uint32_t eb) {
+                const lds_cf* la = (const lds_cf*)(uintptr_t)ea;
+                const lds_cf* lb = (const lds_cf*)(uintptr_t)eb;
+#ifdef PBR_EXP_FF_XONLY   // diagnostic build (wrong image): one plane read instead of three, the same VALU work — what the prepass's LDS reads cost
+                const f2 lx = f2{la[0], lb[0]}, ly = lx, lz = lx;
+#else
                 const f2 lx = f2{la[0], lb[0]}, ly = f2{la[LSTRIDE], lb[LSTRIDE]}, lz = f2{la[2 * LSTRIDE], lb[2 * LSTRIDE]};
+#endif
                 const f2 dn = lx * d.x + (ly * d.y + (lz * d.z + c0));
                 m = __builtin_amdgcn_alignbit(m, __float_as_uint(dn.y), 31);
                 m = __builtin_amdgcn_alignbit(m, __float_as_uint(dn.x), 31);
             };
+#ifdef PBR_EXP_FF_B128   // A/B partner: eight entries as one 16-byte read, unpacked with v_and / v_lshrrev (2 VALU per pair more, 7 LDS reads per group fewer)
 #pragma unroll
             for (int g = 3; g >= 0; g--)
                 if (g * 8 < cmax) {
                     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
                     const u4 e = *reinterpret_cast<const __attribute__((address_space(3))) u4*>(my + FF_LIST_E + 8 * g);
-                    pair(e.w); pair(e.z); pair(e.y); pair(e.x);
+                    pair(e.w & 0xffffu, e.w >> 16); pair(e.z & 0xffffu, e.z >> 16); pair(e.y & 0xffffu, e.y >> 16); pair(e.x & 0xffffu, e.x >> 16);
                 }
+#else
+            // every entry its own ds_read_u16 (zero-extended: the halfword IS the pointer, no unpacking on the VALU); volatile keeps
+            // the compiler from merging neighbours back into one wide read + shifts
+            typedef const volatile __attribute__((address_space(3))) uint16_t lds_vu16;
+            lds_vu16* ent = (lds_vu16*)(my + FF_LIST_E);
+#pragma unroll
+            for (int g = 3; g >= 0; g--)
+                if (g * 8 < cmax) {
+#pragma unroll
+                    for (int k = 6; k >= 0; k -= 2) pair(ent[8 * g + k], ent[8 * g + k + 1]);
+                }
+#endif
             mask = ~m & (cnt >= 32 ? 0xffffffffu : (1u << cnt) - 1u);
             key = (uint32_t)(__popc(mask) + 1) >> 1;
         }
@@ -933,6 +953,7 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     p.log_far_near = logf(g->Far / g->Near);
     p.inv_near = (float)(1.0 / (double)g->Near);
     p.slice_k = (float)((double)PBR_CLUSTER_Z / log2((double)g->Far / (double)g->Near));
+    p.inv_full_w = 1.0f / (float)tile->full_w;
     p.x0 = tile->x0; p.y0 = tile->y0; p.w = tile->w; p.h = tile->h; p.full_w = tile->full_w; p.full_h = tile->full_h;
     p.A = gb->A; p.B = gb->B; p.C = gb->C; p.depth = gb->depth; p.stencil = gb->stencil; p.pitch = gb->pitch;
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
