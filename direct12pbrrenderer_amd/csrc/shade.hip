@@ -29,7 +29,6 @@ struct ShadeParams {
     float near_width, near_height;   // 2 Near tan(Fov/2) [* Ratio]  (vs_main :94-95), host libm
     float log_far_near;              // log(Far/Near) of ClusterIndex (clustered.hlsli:53), host libm
     float inv_near, slice_k;         // 1 / Near and PBR_CLUSTER_Z / log2(Far/Near) (host, from double): the slice index's quick estimate
-    float inv_full_w;                // 1 / full_w (host): the front-facing walk's u
     uint32_t x0, y0, w, h, full_w, full_h;
     const uint32_t* A;
     const uint32_t* B;
@@ -162,17 +161,6 @@ __device__ __forceinline__ f2 zero2() {
     return r;
 }
 
-// ---- front-facing walk (k_deferred_shade_ff) ----------------------------------------------------------------------------------
-constexpr int FF_LIST_H = 40;                     // halfwords per staged list (80 B): [0] light count, [7] the null light, [8 + j] entry j — the entries 16-byte aligned
-constexpr int FF_LIST_E = 8;                      // first entry
-constexpr int FF_KEYS = 18;                       // sort key = pairs of front-facing lights, 0 .. 16; 17 = pixel not shaded
-// index of the lowest set bit, -1 for 0 (what the instruction returns; __builtin_ctz(0) is undefined)
-__device__ __forceinline__ uint32_t ffbl(uint32_t m) {
-    uint32_t r;
-    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(m));
-    return r;
-}
-
 struct alignas(8) H4x2 { H4 a, b; };   // two x-adjacent half4 texels (16 bytes, 8-byte aligned)
 struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-byte aligned)
 
@@ -188,27 +176,18 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 //        S1_c = sum col_c X (1-f5), S2_c = sum col_c X s, S3_c = sum col_c X s f5,   s = NdotL/(T A B)
 //   3. material: re-reads the A/C planes (L2 hits) and folds the sums;
 //   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
-//
-// FF (k_deferred_shade_ff): the pixel arrives through the wave's sorted record {ff_mask, ff_slot} — it is covered, its staged list is
-// number ff_slot, and bit j of ff_mask says that entry j of that list faces the surface (N.(Lpos - P) > 0, with a margin): the walk takes
-// two set bits per trip instead of two consecutive entries.  A light behind the surface multiplies its whole term by max(N.L, 0) = 0
-// (brdf.hlsli:51, deferred_shading.hlsl:186), so leaving it out changes the order of the sums and nothing else.
-template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT, bool FF = false>
+template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint32_t* lists, const uint32_t* mip_off,
-                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, int q_safe, uint32_t px, uint32_t py, float4 row,
-                                            uint32_t ff_mask = 0, uint32_t ff_slot = 0, uint32_t* ff_out = nullptr) {
+                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, int q_safe, uint32_t px, uint32_t py, float4 row) {
     // 32-bit element index (host-checked: pitch * rows * 16 < 2^32): a uniform base + one 32-bit lane offset per access instead of
     // 64-bit address arithmetic for every plane
     const uint32_t gi = __umul24(py, p.pitch) + px;
     auto at = [](const auto* base, uint32_t byte_off) { return *reinterpret_cast<std::remove_reference_t<decltype(*base)>*>(reinterpret_cast<const char*>(base) + byte_off); };
-    if constexpr (!FF)
-        if (at(p.stencil, gi) == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
+    if (at(p.stencil, gi) == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
     const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
 
     // ---- phase 1: geometry (vs_main :91-121, screen triangle D3D12Device.cpp:167-176; uv from the GLOBAL pixel)
-    // (FF: the pixel column changes with every record, so the IEEE divide is no longer loop-invariant; u only feeds the continuous
-    //  ndc_x there — the cluster column was fixed by the prepass with the exact expression — and takes the reciprocal's 1 ulp)
-    const float u = FF ? ((float)(p.x0 + px) + 0.5f) * p.inv_full_w : ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
+    const float u = ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
     // v, cvv.y and the cluster row depend on the pixel ROW only: evaluated once per block row (k_deferred_shade, the same
     // expressions) and handed in as row = {v, cvv.y, cluster row} — an IEEE divide, a floor and their neighbours less per pixel
     V3 pos, view, n;
@@ -242,10 +221,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     // branch around it — with one, the compiler zeroes the 18 accumulator registers on both sides of every branch (36 moves per pixel)
 #ifndef PBR_EXP_NOLOOP   // (PBR_EXP_*: compile-time switches of tools/isa_phase_count.py, which sizes the phases of this function)
     if (STAGED_LISTS || n_lights > 0) {
-        int sx = 0, sy = 0, sz = 0;
-        if constexpr (!FF) {   // (FF: the list was chosen by the prepass, which runs these same lines — ff_cluster_slot)
-        sx = (int)floorf(u * (float)PBR_CLUSTER_X);
-        sy = (int)row.z;
+        int sx = (int)floorf(u * (float)PBR_CLUSTER_X);
+        int sy = (int)row.z;
         float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
         // Slice index = (int)(Z * logf(zc / Near) / log(Far / Near)), a discontinuous function of the depth: its value must be the
         // shader's / the oracle's to the bit, which takes two IEEE divides and a full-precision logf (~45 instructions).  A quick
@@ -256,14 +233,13 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         // its slice coordinate, far inside the band.
         const float t_quick = p.slice_k * __builtin_amdgcn_logf(zc * p.inv_near);
         const float t_frac = t_quick - floorf(t_quick);
-        sz = (int)t_quick;
+        int sz = (int)t_quick;
         if (__any(!(t_frac > 1.0e-4f && t_frac < 1.0f - 1.0e-4f))) {
             zc = fminf(fmaxf(view_space_depth(depth_keep, p.Near, p.Far), p.Near), p.Far);
             sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
         }
         sx = clampi(sx, 0, PBR_CLUSTER_X - 1);
         sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
-        }
         // brdf() (brdf.hlsli:47-67) with D, G, the 4 NdotL NdotV denominator AND the attenuation under ONE reciprocal:
         //   D G / max(4 NdotL NdotV, 1e-4) = [a^2/pi * gV] * gl / (T * A),   a = roughness^2 (the shader's `a * a`),
         //   T  = max(t^2, 1e-6/pi), t = NdotH^2 (a^2 - 1) + 1,
@@ -343,28 +319,13 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
         };
         const lds_cf* const ltab = (const lds_cf*)llds;      // the staged light planes, as an LDS (address space 3) pointer
         if (STAGED_LISTS) {
-            const uint32_t* my = FF ? lists : lists + __mul24(__mul24(__mul24(sy - tile_y0, tiles_x) + (sx - tile_x0), PBR_CLUSTER_Z) + sz, LIST_STRIDE);
+            const uint32_t* my = lists + __mul24(__mul24(__mul24(sy - tile_y0, tiles_x) + (sx - tile_x0), PBR_CLUSTER_Z) + sz, LIST_STRIDE);
             // staged lists are padded to an even count with the null light (black, far away): no odd tail.  An entry is
             // the LDS BYTE ADDRESS of the light's first plane (table base + 4 * index), a dword of its own: packed two to a dword
             // the unpacking mask + shift were two more VALU issues per trip
-            const int nl = FF ? 0 : my[0];
+            const int nl = my[0];
             const bool t_ok = __all(ra * ra >= 6.0e-4f) != 0;
-            // FF: the staged lists are halfwords (k_deferred_shade_ff): [0] count, [7] the null light, [8 + j] entry j — each the LDS
-            // byte address of a light's first plane (< 64 KiB), so a ds_read_u16 IS the pointer.  v_ffbl_b32 of an exhausted mask is
-            // -1: entry -1 is halfword [7], the null light — an odd count needs no case, and a pixel with no light in front walks
-            // one null pair (the walk is a do-while, like the plain one).
-            const uint32_t ff_list = FF ? (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)(reinterpret_cast<const uint16_t*>(lists) + ff_slot * FF_LIST_H + FF_LIST_E) : 0u;
-            auto walk_ff = [&](auto qs, auto ts, auto au) {
-                uint32_t m = ff_mask;
-                do {
-                    const uint32_t b0 = ffbl(m); m &= m - 1u;
-                    const uint32_t b1 = ffbl(m); m &= m - 1u;
-                    const uint32_t la = *(const __attribute__((address_space(3))) uint16_t*)(uintptr_t)(ff_list + 2u * b0);
-                    const uint32_t lb = *(const __attribute__((address_space(3))) uint16_t*)(uintptr_t)(ff_list + 2u * b1);
-                    light2(qs, ts, (const lds_cf*)(uintptr_t)la, (const lds_cf*)(uintptr_t)lb, au);
-                } while (m != 0u);
-            };
-            auto walk_plain = [&](auto qs, auto ts, auto au) {
+            auto walk = [&](auto qs, auto ts, auto au) {
                 int i = 0;
                 do {   // nl >= 2.  One 8-byte LDS read = the two addresses of the trip, each in its own register
                     const uint2 pair = *reinterpret_cast<const uint2*>(my + 2 + i);   // i even -> 8-byte aligned
@@ -375,7 +336,6 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
                 //  kernel's scratch from 12 to 24 bytes per lane at its 96-VGPR budget, in-frame 0.3356 -> 0.3470 ms; removed —
                 //  profiles/r04_d_ab_shade_prefetch.txt)
             };
-            auto walk = [&](auto qs, auto ts, auto au) { if constexpr (FF) walk_ff(qs, ts, au); else walk_plain(qs, ts, au); };
             if (q_safe & 1) {
                 if (t_ok) { if (q_safe & 2) walk(std::true_type{}, std::true_type{}, std::true_type{}); else walk(std::true_type{}, std::true_type{}, std::false_type{}); }
                 else if (q_safe & 2) walk(std::true_type{}, std::false_type{}, std::true_type{});   // a rough-enough wave is a property of the PIXELS, one polynomial of the SCENE: independent
@@ -534,14 +494,7 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
 #endif
     const uint32_t ho = __umul24(py, p.hdr_pitch) + px;
     if (F32OUT) *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.hdr_f32) + ho * 16u) = make_float4(out.x, out.y, out.z, 1.0f);
-    else if constexpr (FF) {
-        // the colour goes back into the pixel's (consumed) sort record — 6 bytes, the top halfword of the record keeps the inverse
-        // permutation — and leaves the wave as whole 512-byte row segments afterwards: written straight from here, every store of
-        // the sorted order would touch 64 different 64-byte granules of the target with 8 bytes each
-        H2 xy; xy.x = to_half_rn(out.x); xy.y = to_half_rn(out.y);
-        *reinterpret_cast<H2*>(ff_out) = xy;
-        *reinterpret_cast<h16*>(ff_out + 1) = to_half_rn(out.z);
-    } else store_h4(reinterpret_cast<pbr_half*>(reinterpret_cast<char*>(p.hdr) + ho * 8u), f4(out.x, out.y, out.z, 1.0f));
+    else store_h4(reinterpret_cast<pbr_half*>(reinterpret_cast<char*>(p.hdr) + ho * 8u), f4(out.x, out.y, out.z, 1.0f));
 }
 
 // grid (ceil(w/256), ceil(h/SHADE_ROWS)), block 256.
@@ -633,273 +586,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_deferred_shade_ff — the same pass with the light walk restricted to the lights that FACE the pixel.
-//
-// Why: with independent normals half of a pixel's listed lights lie behind its surface, and max(N.L, 0) multiplies their whole term
-// (brdf.hlsli:51, deferred_shading.hlsl:186): the plain walk spends those trips adding exact zeros.  A lane skipping its own
-// back-facing lights gains nothing — some lane of 64 always faces its whole cluster (tools/shade_divergence.py: 16.0 -> 15.0 pairs
-// per wave) — so the pixels are REGROUPED: every wave sorts the 64 x SHADE_ROWS pixels it owns by the number of front-facing pairs and
-// shades them in that order (8.3 pairs per wave-iteration on the bench frame; 7.3 is the per-pixel mean).
-//   pass 1 (pixel order, coalesced plane reads): position, un-normalised normal d, cluster slot; one bit per list entry =
-//          sign of d.Lpos - d.P + margin (3 packed FMAs + 2 v_alignbit per PAIR of entries); key = ceil(popcount / 2);
-//          rank among the wave's equal keys = the return value of an LDS atomic add on the wave's private histogram;
-//   pass 2: exclusive prefix over the 18 keys, records {mask, lane | row | slot} moved to base[key] + rank — a counting sort in the
-//          wave's private 4 KiB of LDS, no block barrier anywhere (a wave's LDS operations execute in order);
-//   pass 3 (sorted order): shade_pixel<FF> per record — plane reads and the HDR store become gathers / scatters INSIDE the wave's
-//          64 x 8 pixel rectangle (16 cache lines per plane), the walk takes two set bits of the mask per trip.
-// The margin makes the test conservative: a light is only left out when N.(Lpos - P) < 0 by more than any rounding of either
-// evaluation (2^-18 of the coordinates' magnitude, ~64 ulps), i.e. when the walk's own N.L clamps to exactly 0.  The image differs
-// from the plain kernel's by the ORDER of the nine sums only.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <int LSTRIDE>
-__device__ __forceinline__ uint2 ff_prepass(const ShadeParams& p, const float* llds, const uint16_t* lists, int tile_y0, int tiles_x, float lmax1,
-                                            bool covered, uint32_t b, float depth_ndc, float4 row, float u, int sx_rel) {
-    uint32_t mask = 0, key = FF_KEYS - 1, slot = 0;
-    {
-        if (covered) {   // inside the rectangle and stencil ref 0 < value (DeferredPipeline.h:176-181)
-            const float inv255 = 1.0f / 255.0f;
-            // world position: the lines of shade_pixel's phase 1
-            const float ndc_x = 2.0f * u - 1.0f;
-            const V3 cvv = v3(ndc_x * 0.5f * p.near_width, row.y, p.Near);
-            const V3 camera_vec = v3(p.InvView[0] * cvv.x + p.InvView[1] * cvv.y + p.InvView[2] * cvv.z,
-                                     p.InvView[3] * cvv.x + p.InvView[4] * cvv.y + p.InvView[5] * cvv.z,
-                                     p.InvView[6] * cvv.x + p.InvView[7] * cvv.y + p.InvView[8] * cvv.z);
-            const float z_vs = view_space_depth_quick(depth_ndc, p.Near, p.Far);
-            const float zs = z_vs * p.inv_near;
-            const V3 pos = v3(p.CameraPos[0] + camera_vec.x * zs, p.CameraPos[1] + camera_vec.y * zs, p.CameraPos[2] + camera_vec.z * zs);
-            const V3 d = decode_octahedron((float)(b & 255u) * inv255, (float)((b >> 8) & 255u) * inv255);   // |d| in [0.57, 1]: the sign needs no normalize
-            // ClusterIndex (clustered.hlsli:45-60): the lines of shade_pixel's phase 2, see there
-            float zc = fminf(fmaxf(z_vs, p.Near), p.Far);
-            const float t_quick = p.slice_k * __builtin_amdgcn_logf(zc * p.inv_near);
-            const float t_frac = t_quick - floorf(t_quick);
-            int sz = (int)t_quick;
-            if (__any(!(t_frac > 1.0e-4f && t_frac < 1.0f - 1.0e-4f))) {
-                zc = fminf(fmaxf(view_space_depth(depth_ndc, p.Near, p.Far), p.Near), p.Far);
-                sz = (int)((float)PBR_CLUSTER_Z * logf(zc / p.Near) / p.log_far_near);
-            }
-            sz = clampi(sz, 0, PBR_CLUSTER_Z - 1);
-            slot = (uint32_t)(__mul24(__mul24((int)row.z - tile_y0, tiles_x) + sx_rel, PBR_CLUSTER_Z) + sz);
-            typedef const __attribute__((address_space(3))) uint16_t lds_u16;
-            lds_u16* my = (lds_u16*)(lists + __umul24(slot, FF_LIST_H));
-            const int cnt = my[0];
-            const float margin = 3.814697265625e-6f * (lmax1 + (fabsf(pos.x) + fabsf(pos.y) + fabsf(pos.z)));
-            const f2 c0 = f2s(margin - dot3(d, pos));
-            uint32_t m = 0;
-            // From the last entry down, so that entry j ends at bit j; bit = SIGN of d.L - d.P + margin (1: behind the surface).  Eight
-            // entries = one 16-byte read, no address arithmetic (the unrolled offsets are immediates) and no dependence between the
-            // groups: the loads of a whole list are in flight together.  The count that bounds the groups is the wave's (entries past
-            // a lane's own count are the null light and are masked off below).
-            const int cmax = __any(cnt > 24) ? 32 : __any(cnt > 16) ? 24 : __any(cnt > 8) ? 16 : 8;
-            auto pair = [&](uint32_t ea, uint32_t eb) {
-                const lds_cf* la = (const lds_cf*)(uintptr_t)ea;
-                const lds_cf* lb = (const lds_cf*)(uintptr_t)eb;
-#ifdef PBR_EXP_FF_XONLY   // diagnostic build (wrong image): one plane read instead of three, the same VALU work — what the prepass's LDS reads cost
-                const f2 lx = f2{la[0], lb[0]}, ly = lx, lz = lx;
-#else
-                const f2 lx = f2{la[0], lb[0]}, ly = f2{la[LSTRIDE], lb[LSTRIDE]}, lz = f2{la[2 * LSTRIDE], lb[2 * LSTRIDE]};
-#endif
-                const f2 dn = lx * d.x + (ly * d.y + (lz * d.z + c0));
-                m = __builtin_amdgcn_alignbit(m, __float_as_uint(dn.y), 31);
-                m = __builtin_amdgcn_alignbit(m, __float_as_uint(dn.x), 31);
-            };
-#ifdef PBR_EXP_FF_B128   // A/B partner: eight entries as one 16-byte read, unpacked with v_and / v_lshrrev (2 VALU per pair more, 7 LDS reads per group fewer)
-#pragma unroll
-            for (int g = 3; g >= 0; g--)
-                if (g * 8 < cmax) {
-                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                    const u4 e = *reinterpret_cast<const __attribute__((address_space(3))) u4*>(my + FF_LIST_E + 8 * g);
-                    pair(e.w & 0xffffu, e.w >> 16); pair(e.z & 0xffffu, e.z >> 16); pair(e.y & 0xffffu, e.y >> 16); pair(e.x & 0xffffu, e.x >> 16);
-                }
-#else
-            // every entry its own ds_read_u16 (zero-extended: the halfword IS the pointer, no unpacking on the VALU); volatile keeps
-            // the compiler from merging neighbours back into one wide read + shifts
-            typedef const volatile __attribute__((address_space(3))) uint16_t lds_vu16;
-            lds_vu16* ent = (lds_vu16*)(my + FF_LIST_E);
-#pragma unroll
-            for (int g = 3; g >= 0; g--)
-                if (g * 8 < cmax) {
-#pragma unroll
-                    for (int k = 6; k >= 0; k -= 2) pair(ent[8 * g + k], ent[8 * g + k + 1]);
-                }
-#endif
-            mask = ~m & (cnt >= 32 ? 0xffffffffu : (1u << cnt) - 1u);
-            key = (uint32_t)(__popc(mask) + 1) >> 1;
-        }
-    }
-    return make_uint2(mask, slot | key << 7);
-}
-
-#ifndef SHADE_FF_MIN_WAVES
-#define SHADE_FF_MIN_WAVES SHADE_MIN_WAVES
-#endif
-template <int LSTRIDE, bool F32OUT>
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_FF_MIN_WAVES) void k_deferred_shade_ff(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
-    extern __shared__ float4 lds_raw[];
-    __shared__ uint32_t s_mip_off[16];
-    __shared__ float4 s_row[SHADE_ROWS];
-    __shared__ uint32_t s_lmax;
-    __shared__ uint32_t s_hist[SHADE_BLOCK / 64][2 * FF_KEYS];   // per wave: counts of the keys, then their exclusive prefix
-    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
-    if (threadIdx.x == 0) s_lmax = 0u;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane < 2 * FF_KEYS) s_hist[wv][lane] = 0u;
-    float* llds = reinterpret_cast<float*>(lds_raw);
-    uint16_t* lists = reinterpret_cast<uint16_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 3) & ~3));            // 16-byte aligned (a list is 80 bytes)
-    uint2* recs = reinterpret_cast<uint2*>(lists + max_clusters * FF_LIST_H) + wv * (64 * SHADE_ROWS);
-    __syncthreads();
-    int my_safe = 1, my_same = 1;
-    float my_l1 = 0.0f;
-    const float att0 = n_lights > 0 ? p.lights[0].C0 : 1.0f, att1 = n_lights > 0 ? p.lights[0].C1 : 0.0f, att2 = n_lights > 0 ? p.lights[0].C2 : 0.0f;
-    if (threadIdx.x == 0) {   // the null light: pads odd walks; black, so its pair lane contributes exactly 0
-        llds[0 * LSTRIDE + n_lights] = 1.0e15f; llds[1 * LSTRIDE + n_lights] = 1.0e15f; llds[2 * LSTRIDE + n_lights] = 1.0e15f;
-        llds[3 * LSTRIDE + n_lights] = 0.0f; llds[4 * LSTRIDE + n_lights] = 0.0f; llds[5 * LSTRIDE + n_lights] = 0.0f;
-        llds[6 * LSTRIDE + n_lights] = 1.0f; llds[7 * LSTRIDE + n_lights] = 0.0f; llds[8 * LSTRIDE + n_lights] = 0.0f;
-    }
-    for (int i = threadIdx.x; i < n_lights; i += SHADE_BLOCK) {
-        const pbr_light l = p.lights[i];
-        my_safe &= (l.C0 >= EPSILON_F) & (l.C1 >= 0.0f) & (l.C2 >= 0.0f);
-        my_same &= (l.C0 == att0) & (l.C1 == att1) & (l.C2 == att2);
-        my_l1 = fmaxf(my_l1, fabsf(l.Position[0]) + fabsf(l.Position[1]) + fabsf(l.Position[2]));
-        llds[0 * LSTRIDE + i] = l.Position[0];
-        llds[1 * LSTRIDE + i] = l.Position[1];
-        llds[2 * LSTRIDE + i] = l.Position[2];
-        llds[3 * LSTRIDE + i] = l.Color[0] * l.Intensity;
-        llds[4 * LSTRIDE + i] = l.Color[1] * l.Intensity;
-        llds[5 * LSTRIDE + i] = l.Color[2] * l.Intensity;
-        llds[6 * LSTRIDE + i] = l.C0;
-        llds[7 * LSTRIDE + i] = l.C1;
-        llds[8 * LSTRIDE + i] = l.C2;
-    }
-    atomicMax(&s_lmax, __float_as_uint(my_l1));   // (non-negative floats order like their bit patterns)
-    // block -> rectangle -> (column block, row block): as k_deferred_shade
-    uint32_t r = 0;
-    while (r + 1 < rc.n && blockIdx.x >= rc.first[r + 1]) r++;
-    const uint32_t lb = blockIdx.x - rc.first[r];
-    const uint32_t bx0 = rc.x0[r] + (lb % rc.cols[r]) * SHADE_BLOCK, x_end = rc.x0[r] + rc.w[r];
-    const uint32_t by = lb / rc.cols[r], nb_big = rc.nb_big[r], rows_small = rc.rows_small;
-    const uint32_t y_begin = rc.y0[r] + (by < nb_big ? by * SHADE_ROWS : nb_big * SHADE_ROWS + (by - nb_big) * rows_small);
-    const uint32_t y_end = min(y_begin + (by < nb_big ? (uint32_t)SHADE_ROWS : rows_small), rc.y0[r] + rc.h[r]);
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;
-    const uint32_t bx1 = min(bx0 + SHADE_BLOCK, x_end) - 1;
-    auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
-    auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
-    const int tile_x0 = tx(bx0), tile_x1 = tx(bx1);
-    const int ty_a = ty(y_begin), ty_b = ty(y_end - 1);
-    const int tile_y0 = min(ty_a, ty_b), tile_y1 = max(ty_a, ty_b);
-    const int tiles_x = tile_x1 - tile_x0 + 1;
-    {   // the lists of the cluster tiles the block can touch, as halfwords: [0] count, [1 .. 7] the null light, [8 + j] entry j (LDS
-        // byte addresses).  A thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division, one index load per entry.
-        const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
-        const uint32_t null_addr = lds_base + 4u * (uint32_t)n_lights;
-        const int j = threadIdx.x & 31;
-        for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
-            const int z = c & (PBR_CLUSTER_Z - 1), t = c >> 3;
-            static_assert(PBR_CLUSTER_Z == 8, "cluster slices");
-            const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
-            const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
-            const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-            uint16_t* l = lists + c * FF_LIST_H;
-            l[FF_LIST_E + j] = (uint16_t)(j < cnt ? lds_base + 4u * (uint32_t)min(max(cl->LightIndex[j], 0), n_lights - 1) : null_addr);   // never index past the staged table
-            if (j < FF_LIST_E) l[j] = (uint16_t)(j == 0 ? (uint32_t)cnt : null_addr);
-        }
-    }
-    if (threadIdx.x < (uint32_t)SHADE_ROWS) {
-        const float v = ((float)(p.y0 + y_begin + threadIdx.x) + 0.5f) / (float)p.full_h;
-        const float ndc_y = 1.0f - 2.0f * v;
-        s_row[threadIdx.x] = make_float4(v, ndc_y * 0.5f * p.near_height, (float)clampi((int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1), 0.0f);
-    }
-    const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
-    const float lmax1 = __uint_as_float(s_lmax);
-    const uint32_t px = bx0 + threadIdx.x;
-    const uint32_t nrows = y_end - y_begin;
-    uint32_t* hist = s_hist[wv];
-
-    // ---- pass 1: masks, keys, ranks — records in pixel order
-    {
-        const float u = ((float)(p.x0 + px) + 0.5f) / (float)p.full_w;
-        const int sx_rel = clampi((int)floorf(u * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1) - tile_x0;
-        // The three plane words of a row are loaded a row ahead, all at once and unconditionally (a stencil test in front of the other two
-        // loads is a second memory round trip per row), as straight-line code (a branch around a load makes the compiler wait for ALL
-        // outstanding loads at the join, the prefetch included): lanes past the rectangle's edge and the row past its end read the
-        // nearest valid pixel and drop it.  Two rows per trip, each in its own registers: a copy `cur = next` would wait for the prefetch.
-        struct RowIn { uint32_t st, b; float depth; };
-        const uint32_t pxc = min(px, x_end - 1u);
-        auto load_row = [&](uint32_t rr) {
-            const uint32_t gi = __umul24(y_begin + min(rr, nrows - 1u), p.pitch) + pxc;
-            return RowIn{p.stencil[gi], p.B[gi], p.depth[gi]};
-        };
-        auto row = [&](const RowIn& in, uint32_t rr) {
-            const uint2 pr = ff_prepass<LSTRIDE>(p, llds, lists, tile_y0, tiles_x, lmax1, (in.st != 0u) & (px < x_end), in.b, in.depth, s_row[rr], u, sx_rel);
-            const uint32_t rank = atomicAdd(&hist[pr.y >> 7], 1u);
-            recs[rr * 64 + lane] = make_uint2(pr.x, pr.y | rank << 12);
-        };
-        RowIn a = load_row(0);
-        for (uint32_t rr = 0; rr < nrows; rr += 2) {
-            const RowIn b = load_row(rr + 1);
-            row(a, rr);
-            a = load_row(rr + 2);
-            if (rr + 1 < nrows) row(b, rr + 1);
-        }
-    }
-    wave_lds_sync();
-    // ---- pass 2: counting sort inside the wave's own records
-    uint32_t n_cov;
-    {
-        uint32_t base = 0;
-        for (int j = 0; j < FF_KEYS - 1; j++) { const uint32_t c = hist[j]; base += j < lane ? c : 0u; }
-        if (lane < FF_KEYS) hist[FF_KEYS + lane] = base;
-        uint2 nat[SHADE_ROWS];
-#pragma unroll
-        for (uint32_t rr = 0; rr < (uint32_t)SHADE_ROWS; rr++)
-            if (rr < nrows) nat[rr] = recs[rr * 64 + lane];
-        wave_lds_sync();
-#pragma unroll
-        for (uint32_t rr = 0; rr < (uint32_t)SHADE_ROWS; rr++)
-            if (rr < nrows) {
-                // record = {mask, lane | row | slot in the low halfword}; the top halfword of the record at the pixel's NATURAL index keeps
-                // where the pixel went (the colour comes back through it, pass 4)
-                const uint32_t dst = hist[FF_KEYS + ((nat[rr].y >> 7) & 31u)] + (nat[rr].y >> 12);
-                uint16_t* r16 = reinterpret_cast<uint16_t*>(recs);
-                recs[dst].x = nat[rr].x;
-                r16[dst * 4 + 2] = (uint16_t)((uint32_t)lane | rr << 6 | (nat[rr].y & 127u) << 9);
-                r16[(rr * 64 + lane) * 4 + 3] = (uint16_t)dst;
-            }
-        wave_lds_sync();
-        n_cov = hist[2 * FF_KEYS - 1];   // base of key 17 = the number of pixels to shade
-    }
-#ifdef PBR_EXP_FF_P1ONLY   // diagnostic build (no image): what passes 1 and 2 cost
-    if (n_cov != 0xffffffffu) return;
-#endif
-    // ---- pass 3: shade in sorted order
-    for (uint32_t it = 0; it * 64u < n_cov; it++) {
-        const uint32_t idx = it * 64u + (uint32_t)lane;
-        if (idx < n_cov) {
-            const uint2 rec = recs[idx];
-            const uint32_t rr = (rec.y >> 6) & 7u;
-            shade_pixel<true, LSTRIDE, F32OUT, true>(p, llds, reinterpret_cast<const uint32_t*>(lists), s_mip_off, 0, 0, 1, n_lights, q_safe,
-                                                     bx0 + (uint32_t)wv * 64u + (rec.y & 63u), y_begin + rr, s_row[rr], rec.x, (rec.y >> 9) & 127u,
-                                                     reinterpret_cast<uint32_t*>(recs + idx));
-        }
-    }
-    // ---- pass 4: the colours back in pixel order, one 512-byte segment per row
-    if (!F32OUT) {
-        wave_lds_sync();
-        for (uint32_t rr = 0; rr < nrows; rr++) {
-            const uint32_t dst = recs[rr * 64 + lane].y >> 16;
-            if (dst < n_cov) {
-                const uint2 c = recs[dst];
-                const uint32_t ho = __umul24(y_begin + rr, p.hdr_pitch) + px;
-                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(p.hdr) + ho * 8u) = make_uint2(c.x, (c.y & 0xffffu) | 0x3c000000u);   // alpha 1.0
-            }
-        }
-    }
-}
-
 extern "C" {
 
 pbr_status pbr_env_pad(pbr_ctx* ctx, const pbr_half* env, uint32_t size, uint32_t mips, pbr_half* out_padded) {
@@ -953,7 +639,6 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     p.log_far_near = logf(g->Far / g->Near);
     p.inv_near = (float)(1.0 / (double)g->Near);
     p.slice_k = (float)((double)PBR_CLUSTER_Z / log2((double)g->Far / (double)g->Near));
-    p.inv_full_w = 1.0f / (float)tile->full_w;
     p.x0 = tile->x0; p.y0 = tile->y0; p.w = tile->w; p.h = tile->h; p.full_w = tile->full_w; p.full_h = tile->full_h;
     p.A = gb->A; p.B = gb->B; p.C = gb->C; p.depth = gb->depth; p.stencil = gb->stencil; p.pitch = gb->pitch;
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
@@ -993,19 +678,6 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
     const size_t lds = plane_bytes + (size_t)max_clusters * LIST_STRIDE * sizeof(uint32_t);
     const dim3 blk(SHADE_BLOCK);
-    // the front-facing walk (k_deferred_shade_ff) wherever the lists can be staged: halfword lists + 4 KiB of sort records per wave
-#ifdef PBR_EXP_FF_OFF
-    static const int use_ff = 0;
-#else
-    static const int use_ff = pbr::knob_int("PBR_SHADE_FF", 1);
-#endif
-    const size_t ff_lds = (size_t)((LIGHT_PLANES * lstride + 3) & ~3) * sizeof(float) + (size_t)span_x * span_y * PBR_CLUSTER_Z * FF_LIST_H * sizeof(uint16_t) + (size_t)SHADE_BLOCK * SHADE_ROWS * sizeof(uint2);
-    if (use_ff && span_x * span_y <= (uint32_t)MAX_STAGED_TILES && ff_lds + 1024 <= 65536) {
-        const int ff_clusters = (int)(span_x * span_y) * PBR_CLUSTER_Z;
-        if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade_ff<257, F32OUT>), grid, blk, ff_lds, ctx->stream, p, num_lights, ff_clusters, rc);
-        else hipLaunchKernelGGL((k_deferred_shade_ff<PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, ff_lds, ctx->stream, p, num_lights, ff_clusters, rc);
-        return launched(ctx, "k_deferred_shade_ff");
-    }
     if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
     else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
     else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
