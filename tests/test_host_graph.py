@@ -644,7 +644,8 @@ def test_host_graph_throughput_mode_renders_the_same_frames(host):
     gb = synth.gbuffer_tile(0, 0, W, H, W, H, coverage_mask=True)
     err = C.create_string_buffer(256)
     out = []
-    for in_flight, fused, tail in ((1, 0, 0), (3, 1, 0), (3, 0, 0), (3, 1, 1), (3, 0, 1), (3, 1, 2), (3, 0, 2)):
+    configs = ((1, 0, 0), (1, 1, 0), (3, 1, 0), (3, 0, 0), (3, 1, 1), (3, 0, 1), (3, 1, 2), (3, 0, 2))
+    for in_flight, fused, tail in configs:
         r = host.pbrh_create(0, W, H, ENV, LUT, err, 256)
         assert r, err.value
         try:
@@ -673,5 +674,12 @@ def test_host_graph_throughput_mode_renders_the_same_frames(host):
             out.append((ldr, float(avg[0])))
         finally:
             host.pbrh_destroy(r)
-    bad = [(k, avg == out[0][1], int((ldr != out[0][0]).sum())) for k, (ldr, avg) in enumerate(out) if avg != out[0][1] or not np.array_equal(ldr, out[0][0])]
+    # every throughput-mode configuration against the fence-per-frame loop with the same pass fusion (configs[0] / configs[1]): fused
+    # passes prefilter the env chain in one call since round 5, within 1 fp16 ULP of the five dispatches but not identical, so a fused
+    # frame is compared with a fused frame; the two baselines agree to 1 LSB
+    base = {f: out[k] for k, (nf, f, t) in enumerate(configs) if nf == 1 for f in [f]}
+    bad = [(k, avg == base[configs[k][1]][1], int((ldr != base[configs[k][1]][0]).sum())) for k, (ldr, avg) in enumerate(out)
+           if avg != base[configs[k][1]][1] or not np.array_equal(ldr, base[configs[k][1]][0])]
     assert not bad, f"(config index, same adapted luminance, differing LDR pixels): {bad}"
+    lb = lambda a: ((a[..., None] >> np.array([0, 8, 16], dtype=np.uint32)) & 255).astype(np.int32)   # noqa: E731
+    assert np.abs(lb(base[0][0]) - lb(base[1][0])).max() <= 1 and abs(base[0][1] - base[1][1]) <= 1e-3 * base[0][1]
