@@ -1023,10 +1023,14 @@ def main():
                 fma, mul, add, trans = (mix["SQ_INSTS_VALU_FMA_F32"], mix["SQ_INSTS_VALU_MUL_F32"], mix["SQ_INSTS_VALU_ADD_F32"],
                                         mix["SQ_INSTS_VALU_TRANS_F32"])
                 other = max(nv - fma - mul - add - trans, 0.0)
-                c = MEASURED_CYCLES
-                # the counters do not tell packed from plain: price FMA/MUL/ADD once as all plain and once as all packed
-                lo = (fma * c["fma"] + (mul + add) * c["plain"] + trans * c["trans"] + other * c["plain"]) / N_SIMD / MEASURED_CLOCK_HZ * 1e3
-                hi = ((fma + mul + add) * c["packed"] + trans * c["trans"] + other * c["plain"]) / N_SIMD / MEASURED_CLOCK_HZ * 1e3
+                # the counters do not tell packed from plain: price FMA/MUL/ADD once as all plain and once as all packed — at the issue
+                # rates this box sustained per class in this run (each at the clock the chip holds under that class), else the round-2 constants
+                if on_box:
+                    r_ = {k: valu_meas[n]["Ginst_s"] * 1e9 for k, n in (("plain", "plain_v_mul_f32"), ("fma", "v_fma_f32"), ("packed", "packed_v_pk_fma_f32"), ("trans", "trans_v_rcp_f32"))}
+                else:
+                    r_ = {k: N_SIMD * MEASURED_CLOCK_HZ / v for k, v in MEASURED_CYCLES.items()}
+                lo = (fma / r_["fma"] + (mul + add) / r_["plain"] + trans / r_["trans"] + other / r_["plain"]) * 1e3
+                hi = ((fma + mul + add) / r_["packed"] + trans / r_["trans"] + other / r_["plain"]) * 1e3
                 valu["issue_model_ms"] = [round(lo, 4), round(hi, 4)]
                 valu["issue_model_frac_of_launch"] = [round(lo / shade_ms_in_frame, 3), round(hi / shade_ms_in_frame, 3)]
                 # flop upper bound: every FMA/MUL/ADD wave-instruction counted as PACKED (2 results per lane)
