@@ -100,6 +100,9 @@ def spawn_ranks(a):
     env = dict(os.environ)
     if n_dev < a.gpus:
         if n_dev < 1 or a.gpus > 6:
+            # (the GPU pool this was developed on kills a job with more than 6 processes on one card — its "process guard" — so the
+            #  N = 8 launch itself cannot be rehearsed there: its layout arithmetic runs on CPU/gloo in tests/test_multigpu_gloo.py (2x4) and
+            #  tests/test_bench_cpu.py, its orchestration — grid, cfg5 record, host-graph leg — as a 2x2 rehearsal in tests/test_gpu_bench.py)
             print(f"bench.py: --gpus {a.gpus} but {n_dev} device(s) visible (a rehearsal on one GPU takes at most 6 ranks)", file=sys.stderr)
             return 2
         env["PBR_BENCH_REHEARSAL"] = "1"
@@ -779,7 +782,21 @@ def host_graph_leg(job, r, frames):
            "frames_per_figure": frames}
     try:
         with job.wd.phase(a.deadline, "host graph leg"):
-            if world > 1:
+            if world > 1 and job.rehearsal:
+                # all ranks on one GPU: RCCL refuses several ranks of one communicator on one device, so the renderer runs its halo pass
+                # with the loopback transport (pack -> nothing moves -> unpack: the strips a rank receives stay empty) and gets the other
+                # tiles' histogram counts through the host (gloo) once — every call the pass graph makes on a tile is made, the frames are
+                # not the real ones at the tile borders.  A functional run of this leg, like the rest of a rehearsal
+                hr.set_halo_loopback(True)
+                hr.capture_histogram(True)
+                hr.render()
+                mine = torch.from_numpy(hr.captured_histogram().astype(np.int64))
+                total = mine.clone()
+                dist.all_reduce(total)
+                hr.capture_histogram(False)
+                hr.set_external_histogram((total - mine).numpy().astype(np.uint32))
+                out["rehearsal"] = "loopback halo transport + histogram counts through gloo: functional run, not a measurement"
+            elif world > 1:
                 ids = [comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 hr.comm_init(world, rank, ids[0])
@@ -1049,7 +1066,7 @@ def main():
     # ---- the drop-in path: the same workload driven by the C++ pass graph
     # (optional legs from here on: an exception on this rank is recorded, not raised — the contract line above is complete, and a
     # rank that falls out of step with the others is released by the deadline of the next collective phase)
-    if not a.no_host_graph and not rehearsal:
+    if not a.no_host_graph:
         try:
             hg = host_graph_leg(job, res, max(a.steps, 20))
         except Exception as e:   # noqa: BLE001
@@ -1062,13 +1079,15 @@ def main():
         del frame
         res["frame_obj"] = None
         torch.cuda.empty_cache()
-        s5 = strong(CFG5_FRAME[0], CFG5_FRAME[1], CFG5_GRID.get(world))
+        # (a rehearsal with a reduced tile budget exercises this leg on a reduced frame: it is a functional run either way)
+        cfg5_frame = (1920, 1088) if (rehearsal and a.width < 3840) else CFG5_FRAME
+        s5 = strong(cfg5_frame[0], cfg5_frame[1], CFG5_GRID.get(world))
         try:
             r5 = run_workload(job, "cfg5", s5[0], s5[1], s5[2], s5[3], s5[4], s5[5], a.steps, a.warmup, min(a.settle, 100), want_stage_timing=False)
             c5 = workload_config(job, r5, min(a.settle, 100))
             c5.update({"ms_per_step": round(r5["ms_per_step"], 4), "value": round(r5["value"], 2), "unit": "Mpixel/s", "scaling": "strong", "steps": a.steps})
             hg5 = None
-            if not a.no_host_graph and not rehearsal:
+            if not a.no_host_graph:
                 try:
                     hg5 = host_graph_leg(job, r5, max(a.steps, 20))
                 except Exception as e:   # noqa: BLE001
@@ -1079,7 +1098,7 @@ def main():
             single_ms = None
             with wd.phase(max(a.deadline, 600.0), "cfg5: single-GPU 8K frame on rank 0"):
                 if rank == 0:
-                    fw, fh = CFG5_FRAME
+                    fw, fh = cfg5_frame
                     from direct12pbrrenderer_amd.pipeline import TileSpec
                     fr1 = DeferredFrame(ctx, TileSpec(0, 0, fw, fh, fw, fh, 0), r5["g"], r5["lights"], job.lut, LUT_RES, job.env, ENV_SIZE, ENV_MIPS)
                     fr1.upload_gbuffer(synth.gbuffer_tile(0, 0, fw, fh, fw, fh))

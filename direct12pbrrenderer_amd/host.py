@@ -138,6 +138,29 @@ class HostRenderer:
         buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
         self._check(self.lib.pbrh_comm_init(self.h, world, rank, C.cast(buf, C.c_void_p) if buf else None))
 
+    def set_halo_loopback(self, on):
+        """halo mode without a communicator: the exchange packs / unpacks the staging area and moves nothing (tests and the one-GPU
+        rehearsal of bench.py, which carry the strips — or nothing — themselves)"""
+        self._check(self.lib.pbrh_set_halo_loopback(self.h, 1 if on else 0))
+
+    def capture_histogram(self, on):
+        self._check(self.lib.pbrh_capture_histogram(self.h, 1 if on else 0))
+
+    def captured_histogram(self):
+        """the tile's own 256 luminance counts of the last frame rendered with capture_histogram(True)"""
+        h = np.zeros(256, dtype=np.uint32)
+        self._check(self.lib.pbrh_captured_histogram(self.h, h.ctypes.data))
+        return h
+
+    def set_external_histogram(self, counts256):
+        """counts of the OTHER tiles, added before the average (what pbr_allreduce_hist does over RCCL); None: none"""
+        if counts256 is None:
+            self._check(self.lib.pbrh_set_external_histogram(self.h, None))
+        else:
+            c = np.ascontiguousarray(counts256, dtype=np.uint32)
+            assert c.size == 256
+            self._check(self.lib.pbrh_set_external_histogram(self.h, c.ctypes.data))
+
     def render(self, dt=1.0 / 60.0):
         self._check(self.lib.pbrh_render(self.h, dt))
 

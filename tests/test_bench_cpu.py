@@ -1,0 +1,53 @@
+"""bench.py's N = 8 arithmetic without a GPU: the grids, tiles and halo plans the driver's 8-GPU launch will use.  (The launch itself
+cannot be rehearsed on the one-GPU pool — more than 6 processes on one card are killed there — so what is specific to N = 8 is pinned
+here, the per-rank arithmetic of a 2x4 grid in tests/test_multigpu_gloo.py, and bench.py's orchestration as a 2x2 rehearsal in
+tests/test_gpu_bench.py.)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_bench_n8_weak_and_cfg5_layouts():
+    import bench
+    from direct12pbrrenderer_amd.pipeline import grid_for_world, halo_plan, tile_for_rank, tile_of_frame
+    # the weak-scaling headline at N = 8: a 16:9 frame of 8 x 8.3 Mpixel cut 4 x 2 (cols x rows), one 4K-equivalent tile per rank
+    cols, rows = grid_for_world(8, None)
+    assert (cols, rows) == (4, 2)
+    tw, th = bench.weak_tile(8, cols, rows, 3840, 2160)
+    assert (tw, th) == (2720, 3056) and tw % 16 == 0 and th % 16 == 0
+    assert abs(tw * th / (3840 * 2160) - 1.0) < 0.01                       # per-GPU work fixed as N grows ("weak")
+    assert abs((cols * tw) / (rows * th) - 16 / 9) < 0.02                   # the assembled frame stays 16:9
+    # BASELINE configs[4]: 7680x4320 "tiled 2x4" = 2 rows of 4 tiles of 1920x2160
+    assert bench.CFG5_GRID[8] == (4, 2) and bench.CFG5_FRAME == (7680, 4320)
+    for make, fw, fh in ((lambda r, halo: tile_for_rank(r, 8, tw, th, layout=(cols, rows), halo=halo), cols * tw, rows * th),
+                         (lambda r, halo: tile_of_frame(r, 8, 7680, 4320, layout=bench.CFG5_GRID[8], halo=halo), 7680, 4320)):
+        for halo in (False, True):
+            specs = [make(r, halo) for r in range(8)]
+            cover = np.zeros((fh // 16, fw // 16), dtype=np.int32)          # every interior pixel owned exactly once (16-px granularity)
+            for s in specs:
+                assert s.full_w == fw and s.full_h == fh and s.w % 16 == 0 and s.h % 16 == 0
+                cover[s.y0 // 16:(s.y0 + s.h) // 16, s.x0 // 16:(s.x0 + s.w) // 16] += 1
+            assert (cover == 1).all()
+            if halo:
+                plans = [halo_plan(r, 8, specs) for r in range(8)]
+                # what rank a sends to rank b is what b expects from a (both derive the rectangles from the same specs: no sizes travel)
+                sends = {(r, pr): send for r, p in enumerate(plans) for (pr, send, _recv) in p if send}
+                recvs = {(pr, r): recv for r, p in enumerate(plans) for (pr, _send, recv) in p if recv}
+                assert sends == recvs and len(sends) >= 2 * (3 * 2 + 4)     # at least the 10 shared edges of a 4x2 grid, both ways
+                for r, s in enumerate(specs):                               # the strips a rank receives + its interior tile E exactly
+                    e = np.zeros(((s.ey1 - s.ey0) // 2, (s.ex1 - s.ex0) // 2), dtype=np.int32)
+                    e[(s.y0 - s.ey0) // 2:(s.y0 + s.h - s.ey0) // 2, (s.x0 - s.ex0) // 2:(s.x0 + s.w - s.ex0) // 2] += 1
+                    for (_pr, _send, recv) in plans[r]:
+                        if recv:
+                            e[recv[1] - s.ey0 // 2:recv[3] - s.ey0 // 2, recv[0] - s.ex0 // 2:recv[2] - s.ex0 // 2] += 1
+                    assert (e == 1).all()
+
+def test_bench_refuses_a_rehearsal_beyond_six_ranks():
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    assert r.returncode == 2 and "at most 6 ranks" in r.stderr and r.stdout.strip() == ""

@@ -15,7 +15,7 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("extra,n", [([], 1), (["--gpus", "2"], 2)])
+@pytest.mark.parametrize("extra,n", [([], 1), (["--gpus", "2"], 2), (["--gpus", "4", "--width", "960", "--height", "544"], 4)])
 def test_bench_prints_one_json_line(extra, n):
     cmd = ["timeout", "-k", "10", "500", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--settle", "5", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
@@ -34,3 +34,14 @@ def test_bench_prints_one_json_line(extra, n):
         assert set(ab) >= {"as_shipped", "roughness_0_255", "two_attenuation_presets", "roughness_0_255_and_two_presets"}, ab
         lp = {k: v["mean_lights_per_pixel"] for k, v in ab.items() if isinstance(v, dict)}
         assert max(lp.values()) - min(lp.values()) < 0.02, lp      # the variants differ in the walk instantiation, not in the work
+        assert rec["roofline"]["valu"]["measured_on_this_box"]["plain_v_mul_f32"]["Ginst_s"] > 100      # the normalisers come from THIS box
+        assert rec["roofline"]["valu"]["shade_simd_cycles_per_pixel"] > 0
+    if n > 1:
+        # the multi-rank orchestration, rehearsed on the one GPU (gloo + host copies): the grid, the cfg5 sub-record with its single-GPU
+        # denominator, and the C++ pass graph leg (loopback halo transport) all come back in the one record
+        assert "rehearsal" in rec and rec["config"]["layout_rows_x_cols"] == {2: "1x2", 4: "2x2"}[n], rec["config"]
+        c5 = rec["config"]["cfg5"]
+        assert "error" not in c5 and c5["single_gpu_ms_per_step"] > 0 and c5["ms_per_step"] > 0 and c5["speedup_vs_single_gpu"] > 0, c5
+        hg = rec["host_graph"]
+        assert "error" not in hg and hg["fused_throughput_ms"] > 0 and "rehearsal" in hg, hg
+        assert "error" not in c5["host_graph"] and c5["host_graph"]["fused_throughput_ms"] > 0, c5["host_graph"]
