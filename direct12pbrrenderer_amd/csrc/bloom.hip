@@ -653,6 +653,8 @@ __device__ __forceinline__ void gauss9_pair(const float2* e, float& ge, float& g
     ge = a; go = b;
 }
 
+#ifdef PBR_DEBUG_KNOBS   // ---- k_blur_up_wide: the shader-order (bit-exact) 2x-up kernel of round 3, superseded by k_blur_up_poly.  Only the knobs
+// build carries it (PBR_BLOOM_POLY=0): as the A/B partner and as the bit-exact checker of the wide path (tests/test_gpu_parity.py)
 #ifdef PBR_BLOOM_TIMING   // experiment only (-DPBR_BLOOM_TIMING=<n>, tools/debug/tail_timing.py): shader-clock stamps of wave 0 of every block's n-th tile
 __device__ unsigned long long g_tail_stamp[8 * 4096];
 #define TSTAMP(i) do { if (TAIL == 2 && t == 0 && tile == (int)blockIdx.x + PBR_BLOOM_TIMING * (int)gridDim.x && blockIdx.x < 4096) g_tail_stamp[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -862,6 +864,7 @@ __global__ __launch_bounds__(512, TH == 16 ? 6 : 4) void k_blur_up_wide(const pb
         }
     }
 }
+#endif   // PBR_DEBUG_KNOBS (k_blur_up_wide)
 
 // ---------------------------------------------------------------- 2x-up levels, POLYPHASE form (round 4)
 // k_blur_up_wide evaluates what the shader evaluates: every one of the nine taps of a fine-grid output is a bilinear 2x-up
@@ -902,6 +905,9 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_poly(const pbr_half* __restr
     __shared__ float2 sLineU[DUAL ? NW : 1][3][NP];   // DUAL: the same-size input's fine row as column pairs (k_blur_up_wide's line)
     __shared__ H4 sT[SR][TW];
     __shared__ uint32_t sh_hist[TAIL == 2 ? NW : 1][TAIL == 2 ? PBR_HISTOGRAM_BINS : 1];
+    // two blocks (2 x 8 waves = the 4 waves per SIMD of the launch bounds) must fit a CU's 160 KiB of LDS: an instantiation that does not
+    // would still build — gfx950 allows one block the whole 160 KiB — and silently run at half the occupancy
+    static_assert(sizeof(sLineC) + sizeof(sLineU) + sizeof(sT) + sizeof(sh_hist) <= 80 * 1024, "k_blur_up_poly: two blocks per CU no longer fit the LDS");
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int vc = t & 127, vg = __builtin_amdgcn_readfirstlane(t >> 7);

@@ -2,7 +2,32 @@
 #include "pbr_internal.hpp"
 #include "pbr_device.hpp"
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // declarations only: the library is bound with dlopen (section "RCCL")
+// RCCL: declarations only — the library is bound with dlopen (section "RCCL"), so a one-GPU process never needs librccl.  A build box
+// without the development header still builds: the handful of types, enum values and signatures the calls need are restated below
+// (RCCL >= 2.18 ABI) and the static_asserts that pin them to the header are skipped.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define PBR_HAVE_RCCL_HEADER 1
+#else
+#define PBR_HAVE_RCCL_HEADER 0
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint32 = 3 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef struct ncclConfig_v21700 ncclConfig_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclCommSplit(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+}
+#endif
 #include <link.h>
 #include <unistd.h>
 #include <cstring>
@@ -182,13 +207,17 @@ static void comm_teardown(pbr_ctx* ctx) {
 pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_id_128_bytes) {
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world, "pbr_comm_init: bad world/rank");
+    // a call that is REFUSED (bad arguments, a second init of a context that has a communicator) changes nothing — world and rank
+    // included (they used to be overwritten before the "already has a communicator" check).  A call that is accepted and
+    // then FAILS inside RCCL keeps the world / rank the caller asked for, with no communicator: both collectives refuse from then on
+    // (comm_teardown), the context never falls back to single-GPU behaviour silently.
+    PBR_REQUIRE(ctx, world == 1 || unique_id_128_bytes != nullptr, "pbr_comm_init: null unique id");
+    PBR_REQUIRE(ctx, unique_id_128_bytes == nullptr || ctx->comm == nullptr, "pbr_comm_init: the context already has a communicator");
     ctx->world = world;
     ctx->rank = rank;
     // world 1 needs no communicator; with a unique id one is created all the same (a 1-rank RCCL communicator is
     // legal) so that the RCCL entry points can be exercised on a single GPU
     if (world == 1 && unique_id_128_bytes == nullptr) return PBR_OK;
-    PBR_REQUIRE(ctx, unique_id_128_bytes != nullptr, "pbr_comm_init: null unique id");
-    PBR_REQUIRE(ctx, ctx->comm == nullptr, "pbr_comm_init: the context already has a communicator");
     if (!ctx->rccl_lib) ctx->rccl_lib = open_rccl();
     if (!ctx->rccl_lib) return pbr::fail(ctx, PBR_ERR_COMM, "pbr_comm_init: librccl not found");
     auto f = RCCL_FN(ctx->rccl_lib, ncclCommInitRank);
