@@ -241,7 +241,6 @@ struct PfLaunch {
     uint32_t src_off[16];       // texel offset of padded SOURCE mip l
     uint32_t mips, size, sky_size, sky_mips;
     uint32_t xcd_groups;        // k_prefilter_foot: 8 = blocks sharing blockIdx % 8 (one XCD) take one contiguous eighth of a mip's texels; 1 = plain order
-    uint32_t stage_from, stage_off, stage_texels;   // k_prefilter_foot<false, true>: padded source levels >= stage_from (texel offset stage_off, stage_texels of them) live in LDS
 };
 
 // trilinear fetch of the padded fp32 chain along `d` at the (already clamped and x.8-snapped) LOD; rgb only
@@ -455,37 +454,15 @@ __device__ __forceinline__ void pf_level_f32(float& r, float& g, float& b, const
     r = __builtin_fmaf(t11.x, w.w11, r); g = __builtin_fmaf(t11.y, w.w11, g); b = __builtin_fmaf(t11.z, w.w11, b);
 }
 
-// the same four texels out of the block's LDS copy of the coarsest source levels (k_prefilter_foot<false, true>): the level's texels sit at
-// float4 index lv.off - stage_off of `stage`, in the padded chain's own layout — same values, same order of operations as pf_level_f32
-__device__ __forceinline__ void pf_level_lds(float& r, float& g, float& b, const float4* stage, uint32_t base, const PfLevel& lv, float facef, float cu, float cv, float wl) {
-    const PfCoord c = pf_coord(lv, facef, cu, cv);
-    const float4* q = stage + base + c.o;
-    const float4 t00 = q[0], t10 = q[1], t01 = q[lv.sp], t11 = q[lv.sp + 1u];
-    const PfWeights w = pf_weights(c, wl);
-    r = __builtin_fmaf(t00.x, w.w00, r); g = __builtin_fmaf(t00.y, w.w00, g); b = __builtin_fmaf(t00.z, w.w00, b);
-    r = __builtin_fmaf(t10.x, w.w10, r); g = __builtin_fmaf(t10.y, w.w10, g); b = __builtin_fmaf(t10.z, w.w10, b);
-    r = __builtin_fmaf(t01.x, w.w01, r); g = __builtin_fmaf(t01.y, w.w01, g); b = __builtin_fmaf(t01.z, w.w01, b);
-    r = __builtin_fmaf(t11.x, w.w11, r); g = __builtin_fmaf(t11.y, w.w11, g); b = __builtin_fmaf(t11.z, w.w11, b);
-}
-
 // HALF: sample the half copy (runs when it is exact: *lossy == 0); !HALF: the same loop on the padded fp32 chain (runs when
 // *lossy != 0).  pbr_prefilter_env launches both; the flag k_cube_pad_chain wrote picks the one that works on the device.
 constexpr uint32_t PF_TWO_LEVELS = 0x100u, PF_EXACT_FACE = 0x200u;   // flags beside the level number in a table entry's .w
 // Blocks of 512 lanes: the two sample tables take 24 KB of LDS, and the 8 192 waves of a 512^2 cube's mips 1-4 are exactly 8 per
 // SIMD — with 256-lane blocks LDS allowed 6 of them at a time and the last two ran alone, their load latency exposed.
-constexpr uint32_t PF_FOOT_BLOCK = 512u, pbr_pf_foot_block = PF_FOOT_BLOCK;
-// STAGE (fp32 instance; north_star's "LDS-staged cubemap tiles"): the coarsest source levels — every level from the first whose
-// padded tail fits PF_STAGE_TEXELS float4 (a 512^2 sky: levels 5 .. 9, edge <= 16, 2 910 texels = 46.6 KB) — are copied into LDS once
-// per block, and a sample level that lies there (wave-uniform: a scalar branch) reads its four texels from LDS instead of through the
-// texture addresser, which is what bounds this instance (TA busy 81 %: four 12-byte loads per level).  On the 512^2 / 5-mip job 18 % of
-// the evaluated samples have both levels there and 17 % their second one: 26 % of the loads leave the TA path.  The block is 1 024
-// lanes so that two blocks — 2 x (24 KB of sample tables + 46.6 KB of texels) — still fill a CU's 32 wave slots.
-constexpr uint32_t PF_STAGE_BLOCK = 1024u, PF_STAGE_TEXELS = 2912u;
-template <bool HALF, bool STAGE = false>
-__global__ __launch_bounds__(STAGE ? PF_STAGE_BLOCK : PF_FOOT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_prefilter_foot(const void* __restrict__ chain, PfLevels fo, const float4* __restrict__ tables,
+constexpr uint32_t PF_FOOT_BLOCK = 512u;
+template <bool HALF>
+__global__ __launch_bounds__(PF_FOOT_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_prefilter_foot(const void* __restrict__ chain, PfLevels fo, const float4* __restrict__ tables,
                                                           PfLaunch pl, pbr_half* __restrict__ out, const uint32_t* __restrict__ lossy) {
-    static_assert(!(HALF && STAGE), "the staged instance samples the fp32 chain");
-    constexpr uint32_t PF_FOOT_BLOCK = STAGE ? PF_STAGE_BLOCK : pbr_pf_foot_block;   // (shadows the namespace constant: this instance's block size)
     if ((*lossy != 0u) == HALF) return;
     const pbr_half* foot = reinterpret_cast<const pbr_half*>(chain);
     const float4* chain32 = reinterpret_cast<const float4*>(chain);
@@ -494,9 +471,6 @@ __global__ __launch_bounds__(STAGE ? PF_STAGE_BLOCK : PF_FOOT_BLOCK) __attribute
     // used" and "exact face rule" scalar: level constants come by scalar loads, branches are scalar.
     __shared__ float4 tab[PBR_SAMPLE_COUNT];
     __shared__ float2 lvl[PBR_SAMPLE_COUNT];
-    __shared__ float4 stage[STAGE ? PF_STAGE_TEXELS : 1];
-    if (STAGE)
-        for (uint32_t i = threadIdx.x; i < pl.stage_texels; i += PF_FOOT_BLOCK) stage[i] = chain32[pl.stage_off + i];
     uint32_t mip = 1;
     while (mip + 1 < pl.mips && blockIdx.x >= pl.first_block[mip + 1]) mip++;
     const uint32_t count = pl.count[mip];
@@ -565,12 +539,10 @@ __global__ __launch_bounds__(STAGE ? PF_STAGE_BLOCK : PF_FOOT_BLOCK) __attribute
         const uint32_t l0 = word & 0xFFu;
         const PfLevel la = fo.lev[l0];
         if (HALF) pf_level_half(ar, ag, ab, foot, la, facef, cu, cv, wl.x);
-        else if (STAGE && l0 >= pl.stage_from) pf_level_lds(ar, ag, ab, stage, la.off - pl.stage_off, la, facef, cu, cv, wl.x);   // scalar branch
         else pf_level_f32(ar, ag, ab, chain32, la, facef, cu, cv, wl.x);
         if (word & PF_TWO_LEVELS) {   // scalar branch
             const PfLevel lnext = fo.lev[l0 + 1u];
             if (HALF) pf_level_half(br, bg, bb, foot, lnext, facef, cu, cv, wl.y);
-            else if (STAGE && l0 + 1u >= pl.stage_from) pf_level_lds(br, bg, bb, stage, lnext.off - pl.stage_off, lnext, facef, cu, cv, wl.y);
             else pf_level_f32(br, bg, bb, chain32, lnext, facef, cu, cv, wl.y);
         }
     }
@@ -951,22 +923,7 @@ pbr_status pbr_prefilter_env(pbr_ctx* ctx, const pbr_cube_f32* sky, uint32_t siz
         {   // both instances; the flag k_cube_pad_chain wrote picks the one that works, the other returns at once
             hipLaunchKernelGGL(k_prefilter_foot<true>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)foot, fo, tables, pl, out, lossy);
             r = launched(ctx, "k_prefilter_foot<half>");
-            // the fp32 instance with the coarsest source levels in LDS: its own block table (1 024 lanes per block)
-            static const int stage_knob = pbr::knob_int("PBR_PREFILTER_STAGE", 1);   // A/B switch (knobs build): 0 = every level through the TA
-            PfLaunch ps = pl;
-            uint32_t from = sky->mips;
-            while (from > 0 && padded_texels - pl.src_off[from - 1] <= PF_STAGE_TEXELS) from--;
-            if (stage_knob && from < sky->mips) {
-                ps.stage_from = from; ps.stage_off = pl.src_off[from]; ps.stage_texels = (uint32_t)(padded_texels - pl.src_off[from]);
-                uint32_t sb = 0;
-                for (uint32_t m = 1; m < mips; m++) {
-                    ps.first_block[m] = sb;
-                    const uint32_t sm = size >> m;
-                    sb += (6u * sm * sm + PF_STAGE_BLOCK - 1) / PF_STAGE_BLOCK;
-                }
-                ps.first_block[mips] = sb;
-                if (r == PBR_OK) hipLaunchKernelGGL((k_prefilter_foot<false, true>), dim3(sb), dim3(PF_STAGE_BLOCK), 0, ctx->stream, (const void*)padded, fo, tables, ps, out, lossy);
-            } else if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_foot<false>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)padded, fo, tables, pl, out, lossy);
+            if (r == PBR_OK) hipLaunchKernelGGL(k_prefilter_foot<false>, dim3(blocks), dim3(PF_FOOT_BLOCK), 0, ctx->stream, (const void*)padded, fo, tables, pl, out, lossy);
         }
         if (r == PBR_OK) r = launched(ctx, "k_prefilter_*");
     }
