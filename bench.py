@@ -975,7 +975,10 @@ def main():
                 "histogram": (frame.histogram, None, BYTES_PER_PX["histogram"] * int_px),
                 "average": (frame.average, frame.histogram, 0.0),
                 "tonemap": (frame.tonemap, None, BYTES_PER_PX["tonemap"] * int_px),
-                "average+tonemap": (frame.average_tonemap, frame.histogram, BYTES_PER_PX["tonemap"] * int_px),   # what the frame runs: one launch
+                # pbr_average_tonemap: the two dispatches above as ONE launch — timed for the record only, the frame keeps the two
+                # (DeferredFrame.fused_exposure is off: no gain at frame level, EXPERIMENTS.md round 4).  The call swaps the frame's
+                # histogram / luminance cells, so it is made an even number of times (time_stage: 1 + iters calls; one more below)
+                "average+tonemap": (frame.average_tonemap, frame.histogram, BYTES_PER_PX["tonemap"] * int_px),
             }
             if spec.halo:
                 stages["halo prefilter"] = (frame.halo_prefilter, None, 0.0)
@@ -987,6 +990,9 @@ def main():
             kern = {}
             for name, (fn, pre, nbytes) in stages.items():
                 ms = time_stage(fn, iters, pre)
+                if name == "average+tonemap" and iters % 2 == 0:   # 1 + iters calls so far: restore the frame's own cells
+                    frame.histogram()
+                    fn()
                 kern[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1) if nbytes else None}
                 frame.hist.zero_()
             hbm_meas = measure_hbm_read(ctx)

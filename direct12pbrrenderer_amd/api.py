@@ -88,7 +88,13 @@ class PbrContext:
 
     def partition_cus(self, side_cus, total_cus=None, layout="low"):
         """pbr_ctx_set_cu_masks with `side_cus` compute units, spread evenly over the device, for the side stream and the rest for the
-        context's private stream (0: no partition, every CU for both).  The context must be on its private stream (use_own_stream)."""
+        context's private stream (0: no partition, every CU for both).  The context must be on its private stream (use_own_stream).
+        Masked streams synchronise with the legacy null stream (hipExtStreamCreateWithCUMask takes no flags): default-stream torch work
+        (.zero_(), event records) or a hipMemset inside a partitioned frame makes the two partitions take turns.
+        layout="low" needs side_cus to be a multiple of 32 (the same number of CUs from every XCD): anything else runs at the pace of
+        the poorest XCD and is refused — the uneven layouts exist as "strided" / "per_xcd", for the measurement of exactly that."""
+        if side_cus and layout == "low" and int(side_cus) % 32:
+            raise PbrError(f"partition_cus: layout 'low' takes a multiple of 32 compute units (got {side_cus}): an uneven share per XCD runs at the poorest XCD's pace")
         if not side_cus:
             self._check(self.lib.pbr_ctx_set_cu_masks(self.h, None, None, 0))
             return

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pbrh_read": (C.c_long, [_vp, C.c_char_p, _vp, C.c_size_t]),
     "pbrh_get_global": (_int, [_vp, _vp]),
     "pbrh_cull_lights": (_int, [_u32, _u32, _vp, _vp, _int, _vp, _int]),
+    "pbrh_scene_light_bounds": (_int, [_u32, _u32, _vp, C.c_char_p, C.c_size_t, _vp, _int, _vp, _vp, C.c_char_p, C.c_size_t]),
     "pbrh_dry_run_execution_order": (_int, [_u32, _u32, C.c_char_p, C.c_size_t]),
     "pbrh_probe_binding": (_int, [C.c_char_p, _int, C.c_char_p, _int]),
     "pbrh_parse_hdr": (_int, [_vp, C.c_size_t, _vp, _vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t]),

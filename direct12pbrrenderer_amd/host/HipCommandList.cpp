@@ -180,6 +180,10 @@ void HipCommandList::EndFrame() {
 }
 
 void HipCommandList::SetLayout(const TileLayout& l) {
+    // tail mode 2 moves the bloom pass onto the side stream, which a halo exchange in the middle of that pass rules out: SetTailOverlap(2)
+    // refuses a halo plan, and a halo layout installed afterwards falls back to mode 1 (average + tone-map only) instead of leaving the
+    // combination in place (reachable through the C++ API only: the C ABI fixes the layout at creation)
+    if (mTailOverlap == 2 && !l.HaloPlan().empty()) mTailOverlap = 1;
     mLayout = l;
     mTile = pbr_tile{l.Shaded.x, l.Shaded.y, l.Shaded.w, l.Shaded.h, l.FullW, l.FullH};
     mInterior = l.Tiled() ? l.InteriorInShaded() : Rect{};

@@ -31,9 +31,13 @@ std::vector<SceneLightRecord> ParseSceneLights(const char* text, size_t bytes);
 std::vector<SceneLightRecord> LoadSceneLights(const std::string& path);
 
 // Scene::PostDeserialized for the light list: clears the scene's lights and adds the records in file order.
-// A light's culling bound is a cube around its translation (Scene.cpp:122-130) moved by the object's matrix
-// (Scene.h:31 GetWorldBound = matrix * local bound): a non-unit mScale stretches it per axis; a rotated bound is
-// not restated — the reference's scenes never rotate a light — and is refused.
+// A light's culling bound is a cube around the origin (Scene.cpp:122-130) moved by the object's matrix (Scene.h:29 GetWorldBound =
+// matrix * local bound; SceneObject::PostDeserialized, Scene.cpp:31-36: FromEulerAngle(mRotation in degrees) with its columns scaled
+// by mScale, then the translation) — and `matrix * AABB` transforms the TWO CORNERS only and takes their component-wise min / max
+// (MathLib.cpp:5-10), so a rotated light's bound is the box spanned by its two rotated corners, not the rotated cube's hull; restated
+// as the reference computes it (tests/test_host.py compares with a numpy restatement, cull membership included).
+// Stricter than the reference: the reader refuses radius <= 0 and intensity < 0 (the reference would take them and cull with a
+// degenerate or NaN bound — sqrt of a negative intensity); every light of Asset/Scene/main.json passes.
 void AddSceneLights(Scene* scene, const std::vector<SceneLightRecord>& records);
 
 }  // namespace MRendererHip

@@ -188,6 +188,36 @@ int pbrh_parse_scene_lights(const char* json, size_t bytes, float* lights, int m
     }
 }
 
+int pbrh_scene_light_bounds(uint32_t width, uint32_t height, const float cam_pos_yaw[4], const char* json, size_t bytes,
+                            float* bounds6, int max_lights, int* visible, int* n_visible, char* err, size_t err_len) {
+    try {
+        Scene scene;
+        AddSceneLights(&scene, ParseSceneLights(json, bytes));
+        const int n = (int)scene.GetLightCount();
+        for (int i = 0; i < n && i < max_lights && bounds6; i++) {
+            const AABB b = scene.LightAt((size_t)i)->GetWorldBound();
+            float* o = bounds6 + 6 * i;
+            o[0] = b.Min.x; o[1] = b.Min.y; o[2] = b.Min.z; o[3] = b.Max.x; o[4] = b.Max.y; o[5] = b.Max.z;
+        }
+        if (n_visible) {
+            Camera camera(0.333f * 3.14159265359f, width, height, 0.1f, 1000.0f);
+            camera.Move(Vector3{cam_pos_yaw[0], cam_pos_yaw[1], cam_pos_yaw[2]});
+            camera.Rotate(0, cam_pos_yaw[3], 0);
+            const Matrix4x4 vp = camera.GetProjectionMatrix() * camera.GetLocalSpaceMatrix();
+            int count = 0;
+            scene.CullLight(FrustumVolume::FromMatrix(vp.m), [&](SceneLight* light) {
+                if (visible && count < max_lights) visible[count] = (int)(light - scene.LightAt(0));
+                count++;
+            });
+            *n_visible = count;
+        }
+        return n;
+    } catch (const std::exception& e) {
+        if (err && err_len) std::snprintf(err, err_len, "%s", e.what());
+        return -1;
+    }
+}
+
 int pbrh_set_gbuffer(pbrh_renderer* r, const uint32_t* A, const uint32_t* B, const uint32_t* C, const float* depth, const uint8_t* stencil) {
     return guarded(r, [&] {
         GBufferSource& g = r->scene->GBuffer();

@@ -98,6 +98,13 @@ int pbrh_cull_lights(uint32_t width, uint32_t height, const float cam_pos_yaw[4]
 /* CPU only: the PointLight[] (pbr_light, 44 bytes each) ClusteredPass::Execute commits for these lights and that camera
  * (DeferredPipeline.cpp:224-241): cull membership + order, attenuation presets (Scene.cpp:132-165); count, or -1 */
 int pbrh_light_buffer(uint32_t width, uint32_t height, const float cam_pos_yaw[4], const float* lights, int n, void* out_pbr_lights, int capacity);
+/* CPU only: the scene file's lights through Scene::PostDeserialized (AddSceneLights) and Scene::CullLight for the reference default
+ * camera moved / rotated as given: bounds6[i] = world AABB {min xyz, max xyz} of light i as the cull sees it (SceneObject::GetWorldBound:
+ * the object's matrix — FromEulerAngle(mRotation in degrees), SetScale, translation — applied to the two corners of the local cube,
+ * MathLib.cpp:5-10), visible[k] = indices in visiting order.  Returns the number of lights (<= max_lights filled), *n_visible the number
+ * visited; -1 + reason on malformed input. */
+int pbrh_scene_light_bounds(uint32_t width, uint32_t height, const float cam_pos_yaw[4], const char* json, size_t bytes,
+                            float* bounds6, int max_lights, int* visible, int* n_visible, char* err, size_t err_len);
 int pbrh_dry_run_execution_order(uint32_t width, uint32_t height, char* buf, size_t len);
 /* ShadingState contract probes (no GPU work): 1 = the call returned true */
 int pbrh_probe_binding(const char* shader_file, int is_compute, const char* semantic_name, int kind);

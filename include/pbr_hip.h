@@ -164,6 +164,9 @@ pbr_status  pbr_ctx_side_join(pbr_ctx* ctx);
  * and a kernel's workgroups are dealt to the XCDs in equal shares whatever their CU counts: a partition must hold the same number of CUs
  * of every XCD, and a group of four bits is honoured as a whole only — i.e. a multiple of 32 low bits — or its XCD with the fewest sets the
  * pace (measured: profiles/r04_h_cu_partition_*.txt, r04_j_cu_partition_per_xcd.txt).
+ * Masked streams are created with hipExtStreamCreateWithCUMask, which takes no flags: unlike the non-blocking streams they replace, they
+ * SYNCHRONISE WITH THE LEGACY NULL STREAM — any null-stream work of the process (a hipMemset, a default-stream torch op or event record)
+ * serialises both partitions, so no default-stream work belongs inside a partitioned frame.
  * Recreates both streams (the context must be idle on its private stream: pbr_ctx_use_own_stream, no side work pending) and
  * waits for the device.  A context bound to a foreign stream (pbr_ctx_set_stream) keeps that stream: only the side stream is masked. */
 pbr_status  pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const uint32_t* side_mask, uint32_t words);

@@ -113,3 +113,29 @@ def cull_lights(camera, positions, radius, intensity):
             return None
     vp = matmul44(camera.projection_matrix().astype(F), camera.local_space_matrix().astype(F))
     return tree.cull(frustum_planes(vp))
+
+
+def rotated_scaled_bound(pos, rotation_deg, scale, radius, intensity):
+    """SceneObject::GetWorldBound of a light whose object carries a rotation / scale (Scene.h:29, Scene.cpp:31-36, MathLib.h:656-670,
+    769-782, MathLib.cpp:5-10): matrix = FromEulerAngle(rotation in radians) with its columns scaled, translation in the last column;
+    matrix * AABB = component-wise min / max of the two transformed CORNERS of the local cube."""
+    a, b, c = (F(F(v) * F(3.14159265359 / 180.0)) for v in rotation_deg)
+    ca, sa, cb, sb, cc, sc = F(np.cos(a)), F(np.sin(a)), F(np.cos(b)), F(np.sin(b)), F(np.cos(c)), F(np.sin(c))
+    rot = np.array([[ca * cb, ca * sb * sc - sa * cc, ca * sb * cc + sa * sc],
+                    [sa * cb, sa * sb * sc + ca * cc, sa * sb * cc - ca * sc],
+                    [-sb, cb * sc, cb * cc]], dtype=F)
+    m = rot * np.asarray(scale, dtype=F)[None, :]
+    r = F(radius) * CULL_COEFF * np.sqrt(F(intensity))
+    lo = (m @ np.full(3, -r, F)).astype(F) + np.asarray(pos, F)
+    hi = (m @ np.full(3, r, F)).astype(F) + np.asarray(pos, F)
+    return np.minimum(lo, hi), np.maximum(lo, hi)
+
+
+def cull_bounds(camera, bounds):
+    """cull_lights for explicit world bounds [(min, max), ...]"""
+    tree = Octree()
+    for i, (bmin, bmax) in enumerate(bounds):
+        if not tree.add(np.asarray(bmin, F), np.asarray(bmax, F), i):
+            return None
+    vp = matmul44(camera.projection_matrix().astype(F), camera.local_space_matrix().astype(F))
+    return tree.cull(frustum_planes(vp))

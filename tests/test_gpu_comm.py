@@ -193,7 +193,8 @@ def test_two_ranks_on_one_gpu_through_real_rccl(tmp_path):
     """What no one-rank communicator can show: ncclSend / ncclRecv between DISTINCT ranks and the
     ncclCommSplit communicator's all-reduce under concurrency, through the C ABI.  Two fresh child processes, both on
     device 0, one 2-rank RCCL communicator; hard timeouts.  If RCCL on this pool refuses two ranks per device the test
-    skips with RCCL's reason (and has then checked that a refused pbr_comm_init leaves the context in single-GPU mode)."""
+    skips with RCCL's reason (and has then checked that the context whose pbr_comm_init failed inside RCCL keeps the world it was
+    asked for WITHOUT a communicator: both collectives refuse — it is never half in multi-GPU mode, and never silently single-GPU)."""
     id_file = str(tmp_path / "rccl_unique_id")
     env = dict(os.environ, NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = [subprocess.Popen(["timeout", "-k", "10", "150", sys.executable, "-c", _TWO_RANKS % ROOT, str(r), id_file],

@@ -266,6 +266,52 @@ def test_reference_scene_lights_reach_the_light_buffer_verbatim():
     assert L.pbrh_light_buffer(1440, 960, cp.ctypes.data, got.ctypes.data, n, buf.ctypes.data, 4) == -1    # a buffer too small is an error
 
 
+def test_rotated_and_scaled_scene_lights_cull_like_the_reference_bound():
+    """a light whose object carries mRotation / mScale.  The reference's world bound is matrix * local cube with only the two
+    CORNERS transformed (MathLib.cpp:5-10) — AddSceneLights restates exactly that: bounds and frustum-cull membership + order against
+    the numpy restatement (tests/light_cull_ref.py), on random rotations / scales and on the unrotated fixture lights."""
+    import ctypes as C
+    import common
+    import light_cull_ref
+    L = _host_lib()
+    L.pbrh_scene_light_bounds.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(0x5EED0051)
+    n = 96
+    recs = {"name": [f"l{i}" for i in range(n)], "translation": rng.uniform(-40, 40, (n, 3)).astype(np.float32),
+            "rotation": np.where(rng.random((n, 1)) < 0.7, rng.uniform(-180, 180, (n, 3)), 0.0).astype(np.float32),
+            "scale": np.where(rng.random((n, 1)) < 0.7, rng.uniform(0.25, 3.0, (n, 3)), 1.0).astype(np.float32),
+            "color": rng.uniform(0, 1, (n, 3)).astype(np.float32), "radius": rng.choice(np.float32([0.5, 2.0, 7.0]), n).astype(np.float32),
+            "intensity": rng.uniform(0.5, 10.0, n).astype(np.float32)}
+    assert ((recs["rotation"] != 0).any(axis=1) | (recs["scale"] != 1).any(axis=1)).sum() > 60
+    text = common.scene_json_text(recs).encode()
+    err = C.create_string_buffer(256)
+    for (w, h, cam) in ((1440, 960, (0.0, 3.0, 10.0, np.pi)), (1280, 720, (3.0, 1.0, -4.0, 0.4))):
+        cp = np.float32(cam)
+        bounds = np.zeros((n, 6), np.float32)
+        vis = np.zeros(n, np.int32)
+        nvis = C.c_int(0)
+        assert L.pbrh_scene_light_bounds(w, h, cp.ctypes.data, text, len(text), bounds.ctypes.data, n, vis.ctypes.data, C.byref(nvis), err, 256) == n, err.value
+        want = [light_cull_ref.rotated_scaled_bound(recs["translation"][i], recs["rotation"][i], recs["scale"][i], recs["radius"][i], recs["intensity"][i])
+                if (recs["rotation"][i] != 0).any() or (recs["scale"][i] != 1).any()
+                else light_cull_ref.light_bound(recs["translation"][i], recs["radius"][i], recs["intensity"][i]) for i in range(n)]
+        wb = np.array([np.concatenate(b) for b in want], dtype=np.float32)
+        assert np.abs(bounds - wb).max() <= 2e-5 * np.abs(wb).max(), np.abs(bounds - wb).max()      # libm cos / sin vs numpy's: a few ulps
+        c = scene.Camera(0.333 * 3.14159265359, w, h, 0.1, 1000.0)
+        c.move(cam[:3])
+        c.rotate(0.0, cam[3], 0.0)
+        # membership and visiting order from the C++ side's OWN bounds (so that an ulp of cos / sin cannot flip a boundary case)
+        order = light_cull_ref.cull_bounds(c, [(b[:3], b[3:]) for b in bounds])
+        assert order is not None and nvis.value == len(order) and list(vis[:nvis.value]) == order and 0 < len(order) < n
+    # a rotated light's bound is NOT the hull of the rotated cube: 45 degrees about one axis collapses two extents to (almost) nothing
+    one = {k: (v[:1] if not isinstance(v, list) else v[:1]) for k, v in recs.items()}
+    one["rotation"] = np.float32([[0.0, 0.0, 45.0]]); one["scale"] = np.float32([[1.0, 1.0, 1.0]])
+    t1 = common.scene_json_text(one).encode()
+    b1 = np.zeros((1, 6), np.float32)
+    assert L.pbrh_scene_light_bounds(640, 360, np.float32([0, 3, 10, np.pi]).ctypes.data, t1, len(t1), b1.ctypes.data, 1, None, None, err, 256) == 1
+    ext = b1[0, 3:] - b1[0, :3]
+    assert ext.min() < 1e-4 * ext.max()
+
+
 def test_scene_file_reader_survives_mutated_input():
     """Property test (hypothesis): whatever bytes arrive, the scene-file reader of the C++ host answers with a count or with -1 and a
     reason — never a crash (tools/asan_cpu.sh runs this against the ASan + UBSan build); documents in the serializer's shape
