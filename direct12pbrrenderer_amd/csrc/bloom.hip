@@ -1053,8 +1053,10 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_poly(const pbr_half* __restr
                 o.hi = round_h2(s.z + (float)a2, s.w + a0w);
                 *reinterpret_cast<O4*>(hdr_row0 + k * hdr_pitch + hdr_x) = o;
                 if (TAIL == 2) {
+#ifndef PBR_EXP_TAIL_NOCOUNT   // diagnostic builds (wrong histogram): what the per-pixel count / the per-block flush cost
                     if (xv >= tr.hx0 && xv < tr.hx1 && y >= tr.hy0 && y < tr.hy1)
                         atomicAdd(&sh_hist[wv][luminance_bin_exact((float)o.lo.x, (float)o.lo.y, (float)o.hi.x, min_log, inv_range)], 1u);
+#endif
                 }
             }
         }
@@ -1067,7 +1069,9 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_poly(const pbr_half* __restr
             uint32_t sum = 0;
 #pragma unroll
             for (int w2 = 0; w2 < NW; w2++) sum += sh_hist[w2][i];
+#ifndef PBR_EXP_TAIL_NOFLUSH
             if (sum) atomicAdd(&hist[i], sum);
+#endif
         }
     }
 }
