@@ -28,8 +28,13 @@ def test_allreduce_contract_branches(ctx):
             c2.comm_init(2, 0, None)
         with pytest.raises(PbrError, match="bad world/rank"):
             c2.comm_init(2, 2, b"\0" * 128)
-        with pytest.raises(PbrError, match="no communicator"):   # world was recorded as 2, the init never completed
-            c2.allreduce_hist(hist)
+        # a REFUSED init changes nothing (world / rank used to be overwritten before the checks): the context is still the
+        # single-GPU context it was, its all-reduce the identity.  ("no communicator" is for an init that was accepted and then failed
+        # inside RCCL: tests/test_gpu_comm.py::test_two_ranks_on_one_gpu_through_real_rccl checks that one where RCCL refuses.)
+        hist2 = hist.clone()
+        c2.allreduce_hist(hist2)
+        c2.sync()
+        assert torch.equal(hist2, hist)
         with pytest.raises(PbrError, match="null histogram"):
             c2.allreduce_hist(None)
     finally:

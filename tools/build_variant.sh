@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../direct12pbrrenderer_amd/csrc" && mkdir -p ../../tools/ab 
 extra=""; case $tu in bloom|ibl|raster) extra="-ffp-contract=off";; esac
 [ $tu = ibl ] && extra="$extra -fno-slp-vectorize"
 objs=""; for o in ctx ibl cluster shade raster bloom exposure; do [ $o = $tu ] && objs="$objs ../../tools/ab/${tu}_$tag.o" || objs="$objs $o.o"; done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include $extra "$@" -c $tu.hip -o ../../tools/ab/${tu}_$tag.o &&
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include $extra "$@" -c ${SRC:-$tu.hip} -o ../../tools/ab/${tu}_$tag.o &&
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../tools/ab/libpbr_$tag.so $objs -ldl && echo built $tag
