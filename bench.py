@@ -1029,6 +1029,14 @@ def main():
                                    "stage_GBps of the fused bloom is EFFECTIVE (the 16 reference passes' bytes / the fused launches' time), not traffic; "
                                    "traffic (when present) is the committed rocprofv3 PMC figure for this workload and this version of shade.hip, "
                                    "IBL gathers served by L2/MALL included"}
+        # what THIS box sustains, measured in this run (pbr_valubench at the shade's occupancy): VALU issue rate and shader clock per
+        # instruction class — present whether or not a committed counter profile matches the kernel (the `valu` block below needs one)
+        out["roofline"]["box"] = dict(valu_meas, hbm_read_GBps=round(hbm_meas, 1))
+        if "packed_v_pk_fma_f32" in valu_meas:
+            # the shade's launch in SHADER CYCLES (SIMD-cycles per pixel, at the clock the chip holds under packed-fp32 load — 46 of the walk's 52
+            # instructions are packed): separates a slower box (lower clock, same cycles) from slower code (more cycles)
+            clk_ = valu_meas["packed_v_pk_fma_f32"]["clock_GHz"] * 1e9
+            out["roofline"]["box"]["shade_simd_cycles_per_pixel"] = round(shade_ms_in_frame * 1e-3 * clk_ * valu_meas["compute_units"] * 4 / shaded_px, 2)
         sq = kernel_entry(load_profile("pmc_sq_latest.json", shaded_px), "k_deferred_shade", ("SQ_INSTS_VALU",))
         if sq:
             # Supplementary compute roofline for the VALU-bound shade, against BOTH ceilings:
@@ -1051,7 +1059,7 @@ def main():
                     "spec_peak_Ginst_s": round(N_SIMD * CLOCK_HZ / 2.0 / 1e9, 1), "frac_of_spec": round(rate / (N_SIMD * CLOCK_HZ / 2.0), 3),
                     "measured_plain_peak_Ginst_s": round(plain_peak / 1e9, 1),
                     "frac_of_measured_plain": round(rate / plain_peak, 3),
-                    "measured_on_this_box": valu_meas if on_box else False,
+                    "measured_on_this_box": "roofline.box" if on_box else False,
                     "source": "SQ_INSTS_VALU: profiles/pmc_sq_latest.json + pmc_shade_issue_latest.json (rocprofv3, same shade.hip); peaks and clocks: "
                               + ("pbr_valubench in this run, at the shade's occupancy" if on_box else "profiles/r02_valu_rate3.txt (the on-box probe failed)")}
             if on_box:

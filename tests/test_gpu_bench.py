@@ -34,8 +34,11 @@ def test_bench_prints_one_json_line(extra, n):
         assert set(ab) >= {"as_shipped", "roughness_0_255", "two_attenuation_presets", "roughness_0_255_and_two_presets"}, ab
         lp = {k: v["mean_lights_per_pixel"] for k, v in ab.items() if isinstance(v, dict)}
         assert max(lp.values()) - min(lp.values()) < 0.02, lp      # the variants differ in the walk instantiation, not in the work
-        assert rec["roofline"]["valu"]["measured_on_this_box"]["plain_v_mul_f32"]["Ginst_s"] > 100      # the normalisers come from THIS box
-        assert rec["roofline"]["valu"]["shade_simd_cycles_per_pixel"] > 0
+        box = rec["roofline"]["box"]                                   # the normalisers come from THIS box, in this run
+        assert box["plain_v_mul_f32"]["Ginst_s"] > 100 and 0.5 < box["packed_v_pk_fma_f32"]["clock_GHz"] < 3.0 and box["hbm_read_GBps"] > 1000
+        assert box["shade_simd_cycles_per_pixel"] > 10
+        if "valu" in rec["roofline"]:                                  # (needs a committed counter profile of this very shade.hip)
+            assert rec["roofline"]["valu"]["shade_simd_cycles_per_pixel"] > 0
     if n > 1:
         # the multi-rank orchestration, rehearsed on the one GPU (gloo + host copies): the grid, the cfg5 sub-record with its single-GPU
         # denominator, and the C++ pass graph leg (loopback halo transport) all come back in the one record
