@@ -178,23 +178,12 @@ struct alignas(4) H2x2 { H2 a, b; };   // two x-adjacent LUT texels (8 bytes, 4-
 //   4. IBL: SH diffuse + split-sum specular from the padded env chain and the LUT.
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* llds, const uint32_t* lists, const uint32_t* mip_off,
-                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, int q_safe, uint32_t px, uint32_t py, float4 row,
-                                            uint32_t pre_st = 0, uint32_t pre_b = 0, uint32_t pre_c = 0, float pre_depth = 0.0f) {
+                                            int tile_x0, int tile_y0, int tiles_x, int n_lights, int q_safe, uint32_t px, uint32_t py, float4 row) {
     // 32-bit element index (host-checked: pitch * rows * 16 < 2^32): a uniform base + one 32-bit lane offset per access instead of
     // 64-bit address arithmetic for every plane
     const uint32_t gi = __umul24(py, p.pitch) + px;
     auto at = [](const auto* base, uint32_t byte_off) { return *reinterpret_cast<std::remove_reference_t<decltype(*base)>*>(reinterpret_cast<const char*>(base) + byte_off); };
-#if defined(PBR_EXP_ROW_PREFETCH)   // experiment: the row's plane words were loaded while the previous row was shaded (k_deferred_shade)
-    const uint32_t b_early = pre_b, c_early = pre_c;
-    const float depth_early = pre_depth;
-    if (pre_st == 0) return;
-#elif defined(PBR_EXP_GROUPED_LOADS)   // experiment: the row's plane words requested together, the stencil test afterwards (one memory round trip per row less)
-    const uint32_t st_ = at(p.stencil, gi), b_early = at(p.B, gi * 4u), c_early = at(p.C, gi * 4u);
-    const float depth_early = at(p.depth, gi * 4u);
-    if (st_ == 0) return;
-#else
     if (at(p.stencil, gi) == 0) return;   // stencil ref 0 < value (DeferredPipeline.h:176-181)
-#endif
     const float inv255 = 1.0f / 255.0f;   // UNORM8 -> float
 
     // ---- phase 1: geometry (vs_main :91-121, screen triangle D3D12Device.cpp:167-176; uv from the GLOBAL pixel)
@@ -204,13 +193,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     V3 pos, view, n;
     float z_vs, roughness, depth_keep;
     {
-#if defined(PBR_EXP_GROUPED_LOADS) || defined(PBR_EXP_ROW_PREFETCH)
-        const uint32_t b = b_early, c = c_early;
-        const float depth_ndc = depth_early;
-#else
         const uint32_t b = at(p.B, gi * 4u), c = at(p.C, gi * 4u);
         const float depth_ndc = at(p.depth, gi * 4u);
-#endif
         const float ndc_x = 2.0f * u - 1.0f;
         const V3 cvv = v3(ndc_x * 0.5f * p.near_width, row.y, p.Near);
         const V3 camera_vec = v3(p.InvView[0] * cvv.x + p.InvView[1] * cvv.y + p.InvView[2] * cvv.z,
@@ -598,23 +582,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
     const uint32_t px = bx0 + threadIdx.x;
     if (px >= x_end) return;
-#ifdef PBR_EXP_ROW_PREFETCH
-    struct RowIn { uint32_t st, b, c; float depth; };
-    auto load_row = [&](uint32_t py) {
-        const uint32_t gi = __umul24(min(py, y_end - 1u), p.pitch) + px;
-        return RowIn{p.stencil[gi], p.B[gi], p.C[gi], p.depth[gi]};
-    };
-    RowIn ra = load_row(y_begin);
-    for (uint32_t py = y_begin; py < y_end; py += 2) {   // two rows per trip, each in its own registers (a copy would wait for the prefetch)
-        const RowIn rb = load_row(py + 1);
-        shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin], ra.st, ra.b, ra.c, ra.depth);
-        ra = load_row(py + 2);
-        if (py + 1 < y_end) shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py + 1, s_row[py + 1 - y_begin], rb.st, rb.b, rb.c, rb.depth);
-    }
-#else
     for (uint32_t py = y_begin; py < y_end; py++)
         shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin]);
-#endif
 }
 
 extern "C" {
