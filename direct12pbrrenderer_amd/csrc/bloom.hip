@@ -1126,17 +1126,6 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
                 return launched(ctx, "k_blur_up_wide");
             }
 #endif
-#ifdef PBR_DEBUG_KNOBS   // experiment (knobs build): the polyphase kernel on 128 x 16 tiles for the levels without a tail — level 1 of a 4K frame is 510 tiles of
-            // 128 x 32 for 512 block slots: one generation, every block loading / computing / storing in step; 1 020 half-height tiles are two
-            static const int poly_th = pbr::knob_int("PBR_BLOOM_POLY_TH", 32);
-            if (TAIL == 0 && poly_th == 16) {
-                tr.ty0 = tr.my0 / 16;
-                const int wn16 = wtiles_x * ((tr.my1 + 15) / 16 - tr.ty0);
-                hipLaunchKernelGGL((k_blur_up_poly<DUAL, TAIL, 16>), dim3(wn16), dim3(512), 0, ctx->stream,
-                                   in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, wtiles_x, wn16, tr, min_log, inv_range, hist);
-                return launched(ctx, "k_blur_up_poly<16>");
-            }
-#endif
             hipLaunchKernelGGL((k_blur_up_poly<DUAL, TAIL, 32>), dim3(TAIL == 2 ? even_blocks(wn) : wn), dim3(512), 0, ctx->stream,
                                in, (int)iw, (int)ih, in2, out, (int)ow, (int)oh, (int)out_pitch, wtiles_x, wn, tr, min_log, inv_range, hist);
             return launched(ctx, "k_blur_up_poly");
