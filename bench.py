@@ -92,37 +92,16 @@ def parse():
     return p.parse_args()
 
 
-def visible_gpus():
-    """Number of GPUs the ranks will see, WITHOUT opening one in this launcher process: the KFD topology in sysfs (a node with SIMDs is a
-    GPU), cut down by a *_VISIBLE_DEVICES list.  (torch.cuda.device_count() does not initialise the runtime either, but it opens the
-    device: on a pool that counts the processes holding a GPU open, the launcher would be one of them.)  Falls back to torch's count."""
-    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v is not None:
-            return len([t for t in v.split(",") if t.strip() != ""])
-    try:
-        import glob
-        n = 0
-        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
-            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
-        if n > 0:
-            return n
-    except Exception:   # noqa: BLE001 — no sysfs view of the topology: ask torch
-        pass
-    return torch.cuda.device_count()
-
-
 def spawn_ranks(a):
     """`python bench.py --gpus N` from a bare shell: start N fresh rank processes BEFORE anything here touches the GPU
     (never re-exec a process that has), relay their output, return their exit code.  With fewer than N devices on the
     box the ranks share cuda:0 in rehearsal mode (gloo + host copies): a functional run, not a measurement."""
-    n_dev = visible_gpus()
+    n_dev = torch.cuda.device_count()   # does not initialise the GPU (and, measured, does not count as a holder of the device either)
     env = dict(os.environ)
     if n_dev < a.gpus:
         if n_dev < 1 or a.gpus > 5:
             # (the GPU pool this was developed on kills a job with more than 6 processes holding one card open — its "process guard" — and
-            #  the launcher side of torch.distributed.run is one of them (measured: 6 ranks = 7 holders), so the N = 8 launch itself cannot
+            #  torch.distributed.run's agent is one of them (measured: 6 ranks = 7 holders), so the N = 8 launch itself cannot
             #  be rehearsed there: its layout arithmetic runs on CPU/gloo in tests/test_multigpu_gloo.py (2x4) and tests/test_bench_cpu.py,
             #  its orchestration — grid, cfg5 record, host-graph leg — as a 2x2 rehearsal in tests/test_gpu_bench.py)
             print(f"bench.py: --gpus {a.gpus} but {n_dev} device(s) visible (a rehearsal on one GPU takes at most 5 ranks)", file=sys.stderr)
