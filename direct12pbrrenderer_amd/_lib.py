@@ -76,6 +76,7 @@ SIGNATURES = {
     "pbr_runtime_mismatch_dirs": (_int, [C.c_char_p, C.c_char_p]),
     "pbr_membench_read": (_int, [_vp, _vp, _sz, _vp, _u32]),
     "pbr_valubench": (_int, [_vp, _u32, _u32, _u32, _vp]),
+    "pbr_ctx_set_bloom_shader_order": (_int, [_vp, _int]),
 }
 
 _lib = None

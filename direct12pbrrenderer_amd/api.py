@@ -86,6 +86,11 @@ class PbrContext:
         """Enqueue on the context's private stream (not torch's): the caller orders torch work with ctx.sync() / torch.cuda.synchronize()."""
         self._check(self.lib.pbr_ctx_use_own_stream(self.h))
 
+    def set_bloom_shader_order(self, on):
+        """pbr_ctx_set_bloom_shader_order: the large 2x-up bloom levels in the shader's operation order (bit-exact at any size) instead
+        of the polyphase form (<= 1 fp16 ULP per stage)"""
+        self._check(self.lib.pbr_ctx_set_bloom_shader_order(self.h, 1 if on else 0))
+
     def partition_cus(self, side_cus, total_cus=None, layout="low"):
         """pbr_ctx_set_cu_masks with `side_cus` compute units, spread evenly over the device, for the side stream and the rest for the
         context's private stream (0: no partition, every CU for both).  The context must be on its private stream (use_own_stream).

@@ -1109,7 +1109,7 @@ static pbr_status launch_hv(pbr_ctx* ctx, const pbr_half* in, uint32_t iw, uint3
 #endif
         const int wtx0 = tr.mx0 / 128, wty0 = tr.my0 / 32;
         const int wtiles_x = (tr.mx1 + 127) / 128 - wtx0, wn = wtiles_x * ((tr.my1 + 31) / 32 - wty0);
-        if (wide_forced >= 0 ? wide_forced == 1 : wn >= 400) {
+        if (wide_forced >= 0 ? wide_forced == 1 : (wn >= 400 && !ctx->bloom_shader_order)) {
             tr.tx0 = wtx0; tr.ty0 = wty0;
 #ifdef PBR_DEBUG_KNOBS   // the shader-order (bit-identical) kernel of round 3: A/B partner and checker, PBR_BLOOM_POLY=0
             static const bool poly_off = pbr::knob_int("PBR_BLOOM_POLY", 1) == 0;

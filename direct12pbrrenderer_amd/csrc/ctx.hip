@@ -141,6 +141,12 @@ pbr_status pbr_ctx_use_own_stream(pbr_ctx* ctx) {
     return PBR_OK;
 }
 
+pbr_status pbr_ctx_set_bloom_shader_order(pbr_ctx* ctx, int on) {
+    if (!ctx) return PBR_ERR_INVALID;
+    ctx->bloom_shader_order = on != 0;
+    return PBR_OK;
+}
+
 void* pbr_ctx_get_stream(const pbr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 const char* pbr_last_error(const pbr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

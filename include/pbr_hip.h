@@ -170,6 +170,12 @@ pbr_status  pbr_ctx_side_join(pbr_ctx* ctx);
  * Recreates both streams (the context must be idle on its private stream: pbr_ctx_use_own_stream, no side work pending) and
  * waits for the device.  A context bound to a foreign stream (pbr_ctx_set_stream) keeps that stream: only the side stream is masked. */
 pbr_status  pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const uint32_t* side_mask, uint32_t words);
+/* Bloom, the two large 2x-up levels of frames above ~1.6 Mpixel (levels of >= 400 tiles of 128 x 32): by default they run in polyphase
+ * form — not the shader's operation order: <= 1 fp16 ULP per stage, <= 2 for the chain — so a whole frame and a smaller tile of it (which
+ * takes the shader-order kernels) agree to 2 fp16 ULP, not bit for bit.  on != 0: every level in the shader's operation order
+ * (k_blur_hv), bit-identical to the staged dispatches at any size — for hosts that compare tiles with frames or frames across sizes;
+ * costs the polyphase form's gain (~2 % of a 4K frame). */
+pbr_status  pbr_ctx_set_bloom_shader_order(pbr_ctx* ctx, int on);
 const char* pbr_last_error(const pbr_ctx* ctx);
 /* blocks until everything enqueued through the context is done: its stream AND side-stream work not joined yet */
 pbr_status  pbr_sync(pbr_ctx* ctx);

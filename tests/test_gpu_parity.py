@@ -1021,6 +1021,34 @@ def test_bloom_2x_up_levels_polyphase_and_shader_order(knobs, exact, sizes):
 
 
 @pytest.mark.gpu
+def test_bloom_shader_order_switch_is_bit_exact_at_large_sizes(ctx, orc):
+    """pbr_ctx_set_bloom_shader_order (PRODUCT library): with the switch on the two large 2x-up levels run the shader-order
+    kernels instead of the polyphase form, and a frame above the ~1.6 Mpixel threshold is bit-identical to the oracle's staged chain —
+    what a host needs that compares a rank's tile with the whole frame; off again, the same call is within 2 fp16 ULP."""
+    w, h = 2080, 1296          # the merge level takes the polyphase kernel by default (650 tiles of 128 x 32)
+    img = synth.hdr_noise_image(w, h, seed=w + h)
+    want = img.copy()
+    orc.bloom(want)
+    up = lambda a: ctx.upload(np.ascontiguousarray(a, dtype=np.float16).view(np.uint16)).view(torch.float16)   # noqa: E731
+    ca, cb = ctx.alloc_bloom_chain(w, h), ctx.alloc_bloom_chain(w, h)
+    try:
+        ctx.set_bloom_shader_order(True)
+        hdr, hist = up(img), ctx.zeros((256,), torch.int32)
+        ctx.bloom_histogram(hdr, w, h, w, ca, cb, (0, 0, w, h), hist)
+        ctx.sync()
+        got = hdr.cpu().view(torch.int16).numpy().view(np.float16)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), int((got.view(np.uint16) != want.view(np.uint16)).sum())
+        assert int(hist.sum()) == w * h
+    finally:
+        ctx.set_bloom_shader_order(False)
+    hdr2 = up(img)
+    ctx.bloom(hdr2, w, h, w, ca, cb)
+    ctx.sync()
+    d = common.half_ulp_diff(hdr2.cpu().view(torch.int16).numpy().view(np.float16)[..., :3], want[..., :3])
+    assert 0 < d.max() <= 2          # the default path is the polyphase one here: close, not identical
+
+
+@pytest.mark.gpu
 def test_bloom_4k_constant_field_is_uniform_and_size_independent(ctx, orc):
     """A size-independent property at BASELINE's full size (3840x2160: both polyphase instances run, 2 040 + 510 tiles): a constant HDR
     field stays constant through every level (clamp addressing, weights summing to 0.9999 per pass), so the bloomed frame is ONE value
