@@ -467,6 +467,56 @@ def test_deferred_shade_band_with_the_bench_ibl(ctx, orc, bench_ibl, w, h, rows)
     _check_shade(orc, to_np_half(hdr), want, want_f32, truth, gb["stencil"], f"{w}x{h} band fp16, bench IBL", hard_ulp=None, rough=gb["C"] & 255)
 
 
+def test_deferred_shade_full_4k_frame_is_linear_in_the_light_colours(ctx, orc, bench_ibl):
+    """Size-independent properties at BASELINE's full size — the whole 3840x2160 / 256-light frame of the bench, every pixel, every cluster
+    list, no CPU in the loop (the oracle could not shade 8.3 Mpixel in test time):
+      * the light term is LINEAR in the lights' colours, and a factor 1/2 is exact in every product and sum of the walk, so with
+        A = no lights (IBL + emission), B = the lights, C = the same lights at half colour:  B - A = 2 (C - A)  to fp32 rounding of the two
+        differences — any pixel that walked a wrong or partial list, dropped or doubled a light, or mixed lists between lanes breaks it;
+      * black lights add exactly nothing: D = the lights with colour 0 equals A bit for bit (same IBL path, sums of exact zeros);
+      * a frame shaded as two half-height tiles equals the frame shaded whole, bit for bit (global pixel coordinates: pbr_tile)."""
+    lut_d, env_d, sh, _lut, _env = bench_ibl
+    W, H = 3840, 2160
+    cam, g, lights, gb, tile = common.shade_scene(W, H, 256, sh, rough_min=48, coverage_mask=False)
+    cl = orc.cluster_build(g)
+    orc.cluster_cull(g, lights, cl)                      # integer lists: the GPU cull is tested against them elsewhere
+    gbd = {k: ctx.upload(v) for k, v in gb.items()}
+    envp = ctx.env_pad(env_d, 512, 5)
+    cld = ctx.upload(cl)
+
+    def shade(lts, n):
+        out = ctx.zeros((H, W, 4), torch.float32)
+        ctx.deferred_shade_f32(g, tile, gbd, W, lut_d, 512, envp, 512, 5, cld, ctx.upload(lts), n, out, W)
+        ctx.sync()
+        return out[..., :3]
+
+    half, black = lights.copy(), lights.copy()
+    half["Color"] *= np.float32(0.5)
+    black["Color"] = 0.0
+    A, B, Cc, D = shade(lights, 0), shade(lights, len(lights)), shade(half, len(lights)), shade(black, len(lights))
+    assert bool(torch.isfinite(B).all())
+    # with n = 0 the kernel walks null pairs; with black lights it walks the real lists: both must add nothing.  (-0 vs +0 sums aside,
+    # compare values, not bits)
+    assert bool((A == D).all()), int((A != D).sum())
+    scale = float(B.abs().max())
+    lhs, rhs = B - A, 2.0 * (Cc - A)
+    err = (lhs - rhs).abs()
+    # the light term itself scales EXACTLY (power of two); what is left is the rounding of `light + rest` in the kernel's last additions
+    # and of the two differences here: a few ulps of the pixel's own magnitude
+    tol = 16.0 * torch.finfo(torch.float32).eps * (B.abs() + A.abs()) + 1e-12
+    bad = err > tol
+    assert not bool(bad.any()), (int(bad.sum()), float(err.max()), scale)
+    assert float(lhs.abs().max()) > 0.05 * scale                      # the lights do light the frame
+    # two tiles vs the whole frame
+    for (y0, hh) in ((0, 1080), (1080, 1080)):
+        t = Tile(0, y0, W, hh, W, H)
+        sub = {k: ctx.upload(np.ascontiguousarray(v[y0:y0 + hh])) for k, v in gb.items()}
+        out = ctx.zeros((hh, W, 4), torch.float32)
+        ctx.deferred_shade_f32(g, t, sub, W, lut_d, 512, envp, 512, 5, cld, ctx.upload(lights), len(lights), out, W)
+        ctx.sync()
+        assert bool(torch.equal(out[..., :3], B[y0:y0 + hh])), (y0, int((out[..., :3] != B[y0:y0 + hh]).sum()))
+
+
 @pytest.mark.parametrize("size", [16, 32, 64])   # 32: mip 4 is 2 x 2 — its corner texel is an exact three-way face tie for sample 0
 def test_prefilter_env_on_a_half_representable_source_takes_the_half_copy_and_stays_within_one_ulp(ctx, orc, size):
     """pbr_prefilter_env samples mips >= 1 from a half-precision copy of the source chain when that copy is exact (what the
