@@ -15,7 +15,7 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("extra,n", [([], 1), (["--gpus", "2"], 2), (["--gpus", "4", "--width", "960", "--height", "544"], 4)])
+@pytest.mark.parametrize("extra,n", [([], 1), (["--gpus", "2"], 2), (["--gpus", "3", "--width", "960", "--height", "544"], 3)])
 def test_bench_prints_one_json_line(extra, n):
     cmd = ["timeout", "-k", "10", "500", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--settle", "5", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
@@ -41,8 +41,10 @@ def test_bench_prints_one_json_line(extra, n):
             assert rec["roofline"]["valu"]["shade_simd_cycles_per_pixel"] > 0
     if n > 1:
         # the multi-rank orchestration, rehearsed on the one GPU (gloo + host copies): the grid, the cfg5 sub-record with its single-GPU
-        # denominator, and the C++ pass graph leg (loopback halo transport) all come back in the one record
-        assert "rehearsal" in rec and rec["config"]["layout_rows_x_cols"] == {2: "1x2", 4: "2x2"}[n], rec["config"]
+        # denominator, and the C++ pass graph leg (loopback halo transport) all come back in the one record.  (Three ranks, not four: the
+        # pool kills a job with more than 6 processes holding the card, and this test runs inside a pytest process that holds it too,
+        # next to torch.distributed.run's agent; the 2x2 rehearsal is kept as profiles/r05_p_rehearsal4.json)
+        assert "rehearsal" in rec and rec["config"]["layout_rows_x_cols"] == {2: "1x2", 3: "1x3"}[n], rec["config"]
         c5 = rec["config"]["cfg5"]
         assert "error" not in c5 and c5["single_gpu_ms_per_step"] > 0 and c5["ms_per_step"] > 0 and c5["speedup_vs_single_gpu"] > 0, c5
         hg = rec["host_graph"]
