@@ -359,7 +359,9 @@ def test_valubench_stamps_cycles_and_clock(ctx):
     """The VALU issue-rate probe of bench.py: every wave reports more shader cycles than instructions it issued (a wave64 fp32
     instruction cannot issue faster than one per cycle), a clock between 0.5 and 3 GHz from the two counters, and the slow classes
     cost more cycles than the plain one; bad arguments are refused."""
-    blocks, iters = 256, 2000
+    # five waves per SIMD (the shade's occupancy): there the three issue classes are well apart (per wave ~7.7 / 15 / 24 cycles per
+    # instruction on this part; with one wave per SIMD they are 7.5-8 / 9 / 11.5 and an ordering assert would sit on the noise)
+    blocks, iters = 5 * torch.cuda.get_device_properties(0).multi_processor_count, 2000
     st = torch.zeros((blocks * 4, 4), dtype=torch.int64, device="cuda")
     per_inst = {}
     for op in (0, 2, 3):
@@ -372,7 +374,7 @@ def test_valubench_stamps_cycles_and_clock(ctx):
         clock = np.median(cyc / ticks) * 100e6
         assert 0.5e9 < clock < 3.0e9, clock
         per_inst[op] = float(np.median(cyc)) / (iters * 8)
-    assert per_inst[0] < per_inst[2] < per_inst[3] * 1.05 and per_inst[3] > 1.5 * per_inst[0], per_inst
+    assert 1.2 * per_inst[0] < per_inst[2] and 1.2 * per_inst[2] < per_inst[3], per_inst
     from direct12pbrrenderer_amd.api import PbrError
     with pytest.raises(PbrError):
         ctx.valubench(7, blocks, iters, st)
