@@ -127,7 +127,7 @@ struct ShadeRects {
 };
 
 constexpr int SHADE_BLOCK = 256;
-constexpr int SHADE_ROWS = 8;          // rows of 256 pixels one block walks after staging its tables
+constexpr int SHADE_ROWS = 8;          // rows of 256 pixels one block walks after staging its tables (12: no change, 16: +3 %, round 5)
 constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per block
 // staged list: count, pad, 32 u16 indices = 34 halfwords (68 B) per cluster
 constexpr int LIST_STRIDE = 34;         // dwords per staged cluster list: count, pad, 32 entries (8-byte aligned pairs)
@@ -555,19 +555,21 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         const int tile_y1 = max(ty_a, ty_b);
         tiles_x = tile_x1 - tile_x0 + 1;
         const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
-        for (int e = threadIdx.x; e < n_cl * LIST_STRIDE; e += SHADE_BLOCK) {
-            const int c = e / LIST_STRIDE, j = e % LIST_STRIDE;
-            const int z = c % PBR_CLUSTER_Z, t = c / PBR_CLUSTER_Z;
-            const int cx = tile_x0 + t % tiles_x, cy = tile_y0 + t / tiles_x;
-            const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
-            const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-            int val = 0;
-            if (j == 0) val = max((cnt + 1) & ~1, 2);   // padded to even with the null light; an empty list = one null pair (the walk is a do-while)
-            else if (j >= 2) {
-                const int li = (j - 2) < cnt ? min(max(cl->LightIndex[j - 2], 0), n_lights - 1) : n_lights;   // never index past the staged table
-                val = (int)(lds_base + 4u * (uint32_t)li);   // LDS byte address of the light's first plane
+        // a thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry (round 5:
+        // ~170 instructions per thread and block less than the entry-major loop it replaces; shade in frame -0.4 %, profiles/r05_ac_stage_fast.txt)
+        {
+            static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
+            const int j = threadIdx.x & 31;
+            for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
+                const int z = c & 7, t = c >> 3;
+                const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
+                const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+                const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
+                uint32_t* l = lists + c * LIST_STRIDE;
+                const int li = j < cnt ? min(max(cl->LightIndex[j], 0), n_lights - 1) : n_lights;   // never index past the staged table
+                l[2 + j] = lds_base + 4u * (uint32_t)li;
+                if (j < 2) l[j] = j == 0 ? (uint32_t)max((cnt + 1) & ~1, 2) : 0u;
             }
-            lists[e] = (uint32_t)val;
         }
     }
     // per-row terms of the block's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
