@@ -854,6 +854,13 @@ def main():
     # PBR_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives + host copies — exercises this file's
     # multi-rank path on a one-GPU box; not a measurement
     rehearsal = os.environ.get("PBR_BENCH_REHEARSAL", "0") == "1"
+    if world > 1 and not rehearsal and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        # started as ranks by torch.distributed.run itself (the driver's launch form) on a box with fewer devices than ranks: the same
+        # rehearsal mode spawn_ranks() would have chosen, instead of a crash in set_device
+        if torch.cuda.device_count() < 1 or world > 5:
+            print(f"bench.py: WORLD_SIZE={world} but {torch.cuda.device_count()} device(s) visible (a rehearsal on one GPU takes at most 5 ranks)", file=sys.stderr)
+            sys.exit(2)
+        rehearsal = True
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
