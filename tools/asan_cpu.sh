@@ -1,10 +1,10 @@
 #!/bin/bash
 # CPU-side sanitizer run (build container or any box; no GPU used): builds the C++ host pass graph and the oracle with
 # -fsanitize=address,undefined and runs the CPU test files that exercise them against those builds.
-#   tools/asan_cpu.sh [out_file]        (default profiles/r04_asan_cpu.txt)
+#   tools/asan_cpu.sh [out_file]        (default profiles/r05_asan_cpu.txt)
 set -u
 cd "$(dirname "$0")/.."
-OUT=${1:-profiles/r04_asan_cpu.txt}
+OUT=${1:-profiles/r05_asan_cpu.txt}
 make -C direct12pbrrenderer_amd/host asan -j4 >/dev/null || exit 1
 make -C oracle asan >/dev/null || exit 1
 ASAN_LIB=$(g++ -print-file-name=libasan.so)
