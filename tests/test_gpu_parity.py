@@ -1099,6 +1099,32 @@ def test_bloom_shader_order_switch_is_bit_exact_at_large_sizes(ctx, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
+def test_bloom_up_levels_scale_exactly_at_full_size(ctx, w, h):
+    """A size-independent property of the two large 2x-up levels of the 4K frame, without the CPU: the upsample, the two six-tap
+    polyphase filters, the nine same-size taps and the V pass are LINEAR, every intermediate is rounded to fp16 where a dispatch stores
+    it, and scaling by a power of two commutes with every one of those roundings (no overflow, no subnormals on this input) — so doubling
+    both inputs must double every output texel BIT FOR BIT.  1920x1080 = level 1 of the 4K pyramid (k_blur_up_poly, DUAL instance, 510
+    tiles); 3840x2160 = the merge level's blur (the instance without the merge, 2 040 tiles).  A tap with a wrong weight, a halo entry from
+    the wrong column, a tile seam or a row blend off by one survive no such test: every output would still be 'plausible'."""
+    lower = synth.hdr_noise_image(w // 2, h // 2, seed=3 * w + h, impulse=False)
+    upper = synth.hdr_noise_image(w, h, seed=w + 7 * h, impulse=False)
+    up = lambda a: ctx.upload(np.ascontiguousarray(a, dtype=np.float16).view(np.uint16)).view(torch.float16)   # noqa: E731
+    lo1, up1 = up(lower), up(upper)
+    lo2, up2 = lo1 * 2, up1 * 2                      # exact in fp16 (values in [2^-6, 2^3])
+    for dual in (True, False):
+        o1, o2 = ctx.zeros((h, w, 4), torch.float16), ctx.zeros((h, w, 4), torch.float16)
+        ctx.bloom_up_level(up1 if dual else None, lo1, w // 2, h // 2, o1, w, h)
+        ctx.bloom_up_level(up2 if dual else None, lo2, w // 2, h // 2, o2, w, h)
+        ctx.sync()
+        assert bool(torch.isfinite(o1).all()) and float(o1[..., :3].min()) > 2.0 ** -13      # no subnormal anywhere near
+        assert bool(torch.equal(o2[..., :3], o1[..., :3] * 2)), (w, h, dual, int((o2[..., :3] != o1[..., :3] * 2).sum()))
+        # ... and the level is not trivially zero or a copy: it is a blur (smaller spread than its input, same mean to 1 %)
+        m_in = (up1[..., :3].float().mean() if dual else 0.0) + lo1[..., :3].float().mean()
+        assert abs(float(o1[..., :3].float().mean()) / float(m_in) / (0.9999 ** 2) - 1.0) < 0.01
+
+
+@pytest.mark.gpu
 def test_bloom_4k_constant_field_is_uniform_and_size_independent(ctx, orc):
     """A size-independent property at BASELINE's full size (3840x2160: both polyphase instances run, 2 040 + 510 tiles): a constant HDR
     field stays constant through every level (clamp addressing, weights summing to 0.9999 per pass), so the bloomed frame is ONE value
