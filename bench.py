@@ -248,37 +248,37 @@ def measure_hbm_read(ctx):
     return best
 
 
-def measure_valu(ctx, waves_per_simd=5, iters=20000):
-    """Issue rate of the VALU and the shader clock it sustains ON THIS BOX, per instruction class (pbr_valubench: the loop of
+def measure_valu(ctx, waves_per_simd=5, iters=60000, launches=12):
+    """Issue rate of the VALU and the shader clock it SUSTAINS on this box, per instruction class (pbr_valubench: the loop of
     tools/valu_rate3.hip): every SIMD of the chip holds `waves_per_simd` waves (the shade's occupancy), each issuing iters x 8
-    independent instructions between two reads of the shader-cycle counter and of the 100 MHz counter.  Per class:
-    Ginst_s = wave-instructions of the launch / its HIP-event duration (best of 3), clock_GHz = median over the waves of shader
-    cycles / real time inside the loop, cycles_per_inst = clock x SIMDs / rate (aggregate cycles per wave-instruction per SIMD).
-    Not part of the timed step."""
+    independent instructions between two reads of the shader-cycle counter and of the 100 MHz counter.  A class is loaded for `launches`
+    back-to-back launches of 3-10 ms each (a short burst reads the clock on its way up from idle: ~1.75 GHz in the first launch against
+    ~1.98 sustained under packed fp32, profiles/r05_af_box_probe_*.txt); reported: the median of the last four.  Per class: Ginst_s =
+    wave-instructions of a launch / its HIP-event duration, clock_GHz = median over the waves of shader cycles / real time inside the
+    loop, cycles_per_inst_per_simd = clock x SIMDs / rate.  Not part of the timed step (~0.4 s)."""
     cus = torch.cuda.get_device_properties(ctx.torch_device).multi_processor_count
     blocks = cus * waves_per_simd
     stamps = torch.zeros((blocks * 4, 4), dtype=torch.int64, device=ctx.torch_device)
-    out = {"waves_per_simd": waves_per_simd, "compute_units": cus}
+    out = {"waves_per_simd": waves_per_simd, "compute_units": cus, "sustained_ms_per_class": None}
+    spent = []
     for name, op in (("plain_v_mul_f32", 0), ("v_fma_f32", 1), ("packed_v_pk_fma_f32", 2), ("trans_v_rcp_f32", 3)):
-        ctx.valubench(op, blocks, 2000, stamps)   # clock ramp
-        torch.cuda.synchronize()
-        best = None
-        for _ in range(3):
+        runs = []
+        for _ in range(launches):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             ctx.valubench(op, blocks, iters, stamps)
             e1.record()
             e1.synchronize()
-            ms = e0.elapsed_time(e1)
-            if best is None or ms < best[0]:
-                st = stamps.cpu().numpy()
-                best = (ms, st)
-        ms, st = best
-        cyc, ticks = (st[:, 1] - st[:, 0]).astype(np.float64), (st[:, 3] - st[:, 2]).astype(np.float64)
-        clock = float(np.median(cyc / np.maximum(ticks, 1.0)) * 100e6)
+            st = stamps.cpu().numpy()
+            cyc, ticks = (st[:, 1] - st[:, 0]).astype(np.float64), (st[:, 3] - st[:, 2]).astype(np.float64)
+            runs.append((e0.elapsed_time(e1), float(np.median(cyc / np.maximum(ticks, 1.0)) * 100e6), float(np.median(cyc)) / (iters * 8)))
+        spent.append(round(sum(r[0] for r in runs), 1))
+        last = runs[-4:]
+        ms, clock, per_wave = (float(np.median([r[k] for r in last])) for k in range(3))
         rate = blocks * 4 * iters * 8 / (ms * 1e-3)
         out[name] = {"Ginst_s": round(rate / 1e9, 1), "clock_GHz": round(clock / 1e9, 3), "cycles_per_inst_per_simd": round(clock * cus * 4 / rate, 2),
-                     "per_wave_cycles_per_inst": round(float(np.median(cyc)) / (iters * 8), 2)}
+                     "per_wave_cycles_per_inst": round(per_wave, 2), "clock_GHz_first_launch": round(runs[0][1] / 1e9, 3)}
+    out["sustained_ms_per_class"] = spent
     return out
 
 
