@@ -116,20 +116,21 @@ __global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ sr
 // moves; the plane stride is a compile-time constant so the plane offset rides in the DS offset field.
 constexpr int LIGHT_PLANES = 9;
 
-// Which pixels of the tile a launch shades: up to SHADE_MAX_RECTS rectangles (tile-local), walked by ONE 1-D grid — a
-// whole tile is one rectangle; the overlapped multi-GPU frame shades the tile's border ring (<= 4 rectangles) in one
-// launch and its core in another.  Per rectangle the two-zone schedule of the kernel applies.
+// Which pixels of the tile a launch shades: up to SHADE_MAX_RECTS rectangles (tile-local) — a whole tile is one
+// rectangle; the overlapped multi-GPU frame shades the tile's border ring (<= 4 rectangles) in one launch and its core
+// in another.  A rectangle is cut into WORK ITEMS of 256 columns x rows_big rows (its first nb_big item rows) or
+// x rows_small rows (the rest: short items, handed out last, fill the tail of the launch).
 constexpr int SHADE_MAX_RECTS = 5;
 struct ShadeRects {
-    uint32_t n, rows_small;
+    uint32_t n, rows_big, rows_small;
     uint32_t x0[SHADE_MAX_RECTS], y0[SHADE_MAX_RECTS], w[SHADE_MAX_RECTS], h[SHADE_MAX_RECTS];
-    uint32_t cols[SHADE_MAX_RECTS], nb_big[SHADE_MAX_RECTS], first[SHADE_MAX_RECTS + 1];   // first block of rect r; [n] = total
+    uint32_t cols[SHADE_MAX_RECTS], nb_big[SHADE_MAX_RECTS], first[SHADE_MAX_RECTS + 1];   // first item of rect r; [n] = total
 };
 
 constexpr int SHADE_BLOCK = 256;
-constexpr int SHADE_ROWS = 8;          // rows of 256 pixels one block walks after staging its tables (12: no change, 16: +3 %, round 5)
-constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per block
-// staged list: count, pad, 32 u16 indices = 34 halfwords (68 B) per cluster
+constexpr int SHADE_ROWS = 8;          // most rows of 256 pixels one work item may hold
+constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per item
+// staged list: count, pad, 32 entries
 constexpr int LIST_STRIDE = 34;         // dwords per staged cluster list: count, pad, 32 entries (8-byte aligned pairs)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -497,19 +498,76 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     else store_h4(reinterpret_cast<pbr_half*>(reinterpret_cast<char*>(p.hdr) + ho * 8u), f4(out.x, out.y, out.z, 1.0f));
 }
 
-// grid (ceil(w/256), ceil(h/SHADE_ROWS)), block 256.
-// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 136 B of light lists.
-template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
-#ifndef SHADE_MIN_WAVES
-#define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
+// ------------------------------------------------------------------------------------------------
+// Launch schedule.  Blocks are PERSISTENT: the grid is what the device holds at once (compute units x resident blocks),
+// a block stages the 9-plane light table ONCE and then pulls work items — 256 columns x 1..8 rows — from a queue until it is
+// dry.  One schedule for every render-target size: a 1080p frame (1.3 Mpixel per 1 280 resident blocks) is cut into
+// one-row items and keeps every compute unit busy to the end, where a static grid of 256 x 8-pixel blocks was 0.84 of ONE
+// generation; an 8K frame takes 8-row items.  Per-pixel arithmetic does not depend on the schedule: the output is the same
+// to the bit whichever block shades a pixel.
+//
+// Queue (pbr_ctx::shade_q, one slot per stream): 8 head words on 128-byte lines of their own + a retired-block count.
+// Item i belongs to shard i % 8 and is the (i / 8)-th pull of that shard's head; a block pulls from shard blockIdx % 8 (the
+// dispatcher deals consecutive blocks to consecutive XCDs) with ONE returning agent-scope atomic add, issued a whole item ahead
+// of its use (one head word saturates at ~90 pulls per microsecond: MI355X_MICROARCH.md, "dequeue"; a 1080p single-light launch
+// wants ~150).  A block whose shard has run dry reads the other seven heads (seven loads in flight together) and pulls from
+// the first one with items left; when none has, it retires.  The block that retires last zeroes the slot for the next launch
+// of the stream — every other block has consumed the result of every atomic it issued before it counted itself out.
+constexpr uint32_t SHADE_NO_ITEM = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t q_pull(uint32_t* q, uint32_t shard) {
+    return __hip_atomic_fetch_add(q + shard * pbr::SHADE_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the shard of `shard` is dry: an item of another shard (and that shard in `shard`), or SHADE_NO_ITEM
+__device__ __noinline__ uint32_t q_steal(uint32_t* q, uint32_t& shard, uint32_t total) {
+    for (;;) {   // ends: heads only grow, and a round that finds no head below its limit returns
+        uint32_t h[pbr::SHADE_Q_SHARDS];
+#pragma unroll
+        for (int j = 1; j < pbr::SHADE_Q_SHARDS; j++)
+            h[j] = __hip_atomic_load(q + ((shard + j) & 7u) * pbr::SHADE_Q_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int pick = 0;
+#pragma unroll
+        for (int j = pbr::SHADE_Q_SHARDS - 1; j >= 1; j--)
+            if ((uint64_t)h[j] * pbr::SHADE_Q_SHARDS + ((shard + j) & 7u) < total) pick = j;
+        if (pick == 0) return SHADE_NO_ITEM;
+        const uint32_t v = (shard + pick) & 7u;
+        const uint64_t it = (uint64_t)q_pull(q, v) * pbr::SHADE_Q_SHARDS + v;
+        if (it < total) { shard = v; return (uint32_t)it; }
+    }
+}
+
+#ifdef PBR_SHADE_TIMING   // experiment build only (tools/shade_timeline.py): 100 MHz wall-clock stamps of every block and item
+__device__ unsigned long long g_shade_block_stamp[4 * 8192];     // per block: start, light table staged, end, (items << 32 | XCC id)
+__device__ unsigned long long g_shade_item_stamp[4 * 160000];    // per item: start, lists staged, end, (rows << 48 | block)
+extern "C" int pbr_debug_shade_stamps(unsigned long long* blocks, int n_blocks, unsigned long long* items, int n_items) {
+    int e = (int)hipMemcpyFromSymbol(blocks, HIP_SYMBOL(g_shade_block_stamp), sizeof(unsigned long long) * 4 * n_blocks);
+    if (e == 0 && n_items > 0) e = (int)hipMemcpyFromSymbol(items, HIP_SYMBOL(g_shade_item_stamp), sizeof(unsigned long long) * 4 * n_items);
+    return e;
+}
+extern "C" int pbr_debug_shade_stamps_reset() {
+    void *b = nullptr, *i = nullptr;
+    int e = (int)hipGetSymbolAddress(&b, HIP_SYMBOL(g_shade_block_stamp));
+    if (e == 0) e = (int)hipGetSymbolAddress(&i, HIP_SYMBOL(g_shade_item_stamp));
+    if (e == 0) e = (int)hipMemset(b, 0, sizeof(g_shade_block_stamp));
+    if (e == 0) e = (int)hipMemset(i, 0, sizeof(g_shade_item_stamp));
+    return e;
+}
+#define SHADE_BSTAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_shade_block_stamp[blockIdx.x * 4 + (i)] = (v); } while (0)
+#define SHADE_ISTAMP(it, i, v) do { if (threadIdx.x == 0 && (it) < 160000u) g_shade_item_stamp[(it) * 4 + (i)] = (v); } while (0)
+// end stamps: the LAST wave of the block to get there (the arrays are zeroed before the launch)
+#define SHADE_BSTAMP_MAX(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) atomicMax(&g_shade_block_stamp[blockIdx.x * 4 + (i)], (v)); } while (0)
+#define SHADE_ISTAMP_MAX(it, i, v) do { if ((threadIdx.x & 63) == 0 && (it) < 160000u) atomicMax(&g_shade_item_stamp[(it) * 4 + (i)], (v)); } while (0)
+#define SHADE_NOW() wall_clock64()
+#else
+#define SHADE_BSTAMP(i, v) do {} while (0)
+#define SHADE_ISTAMP(it, i, v) do {} while (0)
+#define SHADE_BSTAMP_MAX(i, v) do {} while (0)
+#define SHADE_ISTAMP_MAX(it, i, v) do {} while (0)
+#define SHADE_NOW() 0ull
 #endif
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
-    extern __shared__ float4 lds_raw[];
-    __shared__ uint32_t s_mip_off[16];
-    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
-    float* llds = reinterpret_cast<float*>(lds_raw);
-    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));   // 8-byte aligned
-    int my_safe = 1, my_same = 1;
+
+// the block's light table: nine SoA planes + the null light; my_safe / my_same: this thread's lights keep the fast paths open
+template <int LSTRIDE>
+__device__ __forceinline__ void stage_lights(const ShadeParams& p, float* llds, int n_lights, int& my_safe, int& my_same) {
     const float att0 = n_lights > 0 ? p.lights[0].C0 : 1.0f, att1 = n_lights > 0 ? p.lights[0].C1 : 0.0f, att2 = n_lights > 0 ? p.lights[0].C2 : 0.0f;
     if (threadIdx.x == 0) {   // the null light: pads odd lists; black, so its pair lane contributes exactly 0
         llds[0 * LSTRIDE + n_lights] = 1.0e15f; llds[1 * LSTRIDE + n_lights] = 1.0e15f; llds[2 * LSTRIDE + n_lights] = 1.0e15f;
@@ -530,63 +588,162 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         llds[7 * LSTRIDE + i] = l.C1;
         llds[8 * LSTRIDE + i] = l.C2;
     }
-    // block -> rectangle -> (column block, row block); wave-uniform scalar arithmetic
-    uint32_t r = 0;
-    while (r + 1 < rc.n && blockIdx.x >= rc.first[r + 1]) r++;
-    const uint32_t lb = blockIdx.x - rc.first[r];
-    const uint32_t bx0 = rc.x0[r] + (lb % rc.cols[r]) * SHADE_BLOCK, x_end = rc.x0[r] + rc.w[r];
-    // two-zone schedule: the first nb_big block rows walk SHADE_ROWS rows each, the rest rows_small — the short
-    // blocks are dispatched last and fill the tail of the launch (a 4K frame is only ~3.2 waves of resident blocks)
-    const uint32_t by = lb / rc.cols[r], nb_big = rc.nb_big[r], rows_small = rc.rows_small;
-    const uint32_t y_begin = rc.y0[r] + (by < nb_big ? by * SHADE_ROWS : nb_big * SHADE_ROWS + (by - nb_big) * rows_small);
-    const uint32_t y_end = min(y_begin + (by < nb_big ? (uint32_t)SHADE_ROWS : rows_small), rc.y0[r] + rc.h[r]);
-    int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
+}
+
+// one work item's pixel rectangle, tile-local: columns [bx0, x_end) of rows [y_begin, y_end)
+struct ShadeItem { uint32_t bx0, x_end, y_begin, y_end; };
+__device__ __forceinline__ ShadeItem item_rect(const ShadeRects& rc, uint32_t item) {
+    uint32_t r = 0;   // item -> rectangle -> (column block, item row); wave-uniform scalar arithmetic
+    while (r + 1 < rc.n && item >= rc.first[r + 1]) r++;
+    const uint32_t lb = item - rc.first[r];
+    const uint32_t by = lb / rc.cols[r], nb_big = rc.nb_big[r];
+    ShadeItem it;
+    it.bx0 = rc.x0[r] + (lb - by * rc.cols[r]) * SHADE_BLOCK;
+    it.x_end = rc.x0[r] + rc.w[r];
+    it.y_begin = rc.y0[r] + (by < nb_big ? by * rc.rows_big : nb_big * rc.rows_big + (by - nb_big) * rc.rows_small);
+    it.y_end = min(it.y_begin + (by < nb_big ? rc.rows_big : rc.rows_small), rc.y0[r] + rc.h[r]);
+    return it;
+}
+
+// The light lists of the clusters an item's pixels can fall into, as LDS byte addresses of the lights (one dword each) — same
+// arithmetic as the per-pixel ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners
+// bound it.  A thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry.
+__device__ __forceinline__ void stage_lists(const ShadeParams& p, const ShadeItem& it, uint32_t* lists, uint32_t lds_base, int n_lights, int max_clusters,
+                                            int& tile_x0, int& tile_y0, int& tiles_x) {
+    static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
+    const uint32_t bx1 = min(it.bx0 + SHADE_BLOCK, it.x_end) - 1;
+    auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
+    auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
+    tile_x0 = tx(it.bx0);
+    const int tile_x1 = tx(bx1);
+    const int ty_a = ty(it.y_begin), ty_b = ty(it.y_end - 1);
+    tile_y0 = min(ty_a, ty_b);
+    const int tile_y1 = max(ty_a, ty_b);
+    tiles_x = tile_x1 - tile_x0 + 1;
+    const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
+    const int j = threadIdx.x & 31;
+    for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
+        const int z = c & 7, t = c >> 3;
+        const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
+        const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+        const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
+        uint32_t* l = lists + c * LIST_STRIDE;
+        const int li = j < cnt ? min(max(cl->LightIndex[j], 0), n_lights - 1) : n_lights;   // never index past the staged table
+        l[2 + j] = lds_base + 4u * (uint32_t)li;
+        if (j < 2) l[j] = j == 0 ? (uint32_t)max((cnt + 1) & ~1, 2) : 0u;
+    }
+}
+
+// per-row terms of an item's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
+__device__ __forceinline__ float4 row_terms(const ShadeParams& p, uint32_t y) {
+    const float v = ((float)(p.y0 + y) + 0.5f) / (float)p.full_h;
+    const float ndc_y = 1.0f - 2.0f * v;
+    return make_float4(v, ndc_y * 0.5f * p.near_height, (float)clampi((int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1), 0.0f);
+}
+
+#ifndef SHADE_MIN_WAVES
+#define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
+#endif
+
+// grid = min(items, compute units x resident blocks), block 256.
+// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) 2 x max_clusters * 136 B of light lists: the lists of
+// item k + 1 are staged while the block's slower waves may still walk those of item k, so ONE barrier per item orders everything.
+template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc, uint32_t* q) {
+    extern __shared__ float4 lds_raw[];
+    __shared__ uint32_t s_mip_off[16];
+    __shared__ uint32_t s_item[2];
+    __shared__ float4 s_row[2][SHADE_ROWS];
+    const unsigned long long t_start = SHADE_NOW();
+    (void)t_start;
+    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
+    float* llds = reinterpret_cast<float*>(lds_raw);
+    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));   // 8-byte aligned
+    const uint32_t total = rc.first[rc.n];
+    // thread 0 is the block's puller: `pend` = the head value of a pull in flight on `shard`
+    uint32_t shard = blockIdx.x & 7u, pend = 0;
+    if (threadIdx.x == 0) {
+        const uint64_t it = (uint64_t)q_pull(q, shard) * pbr::SHADE_Q_SHARDS + shard;
+        const uint32_t first = it < total ? (uint32_t)it : q_steal(q, shard, total);
+        s_item[0] = first;
+        if (first != SHADE_NO_ITEM) pend = q_pull(q, shard);   // issued only where the loop below consumes its result
+    }
+    int my_safe = 1, my_same = 1;
+    stage_lights<LSTRIDE>(p, llds, n_lights, my_safe, my_same);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;   // < 64 KiB: the whole light table (<= 9 x 1025 floats) stays addressable in 16 bits
-    if (STAGED_LISTS) {
-        // cluster (x,y) tiles the block's pixel rectangle can fall into — same arithmetic as the per-pixel
-        // ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners bound it
-        const uint32_t bx1 = min(bx0 + SHADE_BLOCK, x_end) - 1;
-        auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
-        auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
-        tile_x0 = tx(bx0);
-        const int tile_x1 = tx(bx1);
-        const int ty_a = ty(y_begin), ty_b = ty(y_end - 1);
-        tile_y0 = min(ty_a, ty_b);
-        const int tile_y1 = max(ty_a, ty_b);
-        tiles_x = tile_x1 - tile_x0 + 1;
-        const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
-        // a thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry (round 5:
-        // ~170 instructions per thread and block less than the entry-major loop it replaces; shade in frame -0.4 %, profiles/r05_ac_stage_fast.txt)
-        {
-            static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
-            const int j = threadIdx.x & 31;
-            for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
-                const int z = c & 7, t = c >> 3;
-                const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
-                const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
-                const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-                uint32_t* l = lists + c * LIST_STRIDE;
-                const int li = j < cnt ? min(max(cl->LightIndex[j], 0), n_lights - 1) : n_lights;   // never index past the staged table
-                l[2 + j] = lds_base + 4u * (uint32_t)li;
-                if (j < 2) l[j] = j == 0 ? (uint32_t)max((cnt + 1) & ~1, 2) : 0u;
-            }
-        }
-    }
-    // per-row terms of the block's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
-    __shared__ float4 s_row[SHADE_ROWS];
-    if (threadIdx.x < (uint32_t)SHADE_ROWS) {
-        const float v = ((float)(p.y0 + y_begin + threadIdx.x) + 0.5f) / (float)p.full_h;
-        const float ndc_y = 1.0f - 2.0f * v;
-        s_row[threadIdx.x] = make_float4(v, ndc_y * 0.5f * p.near_height, (float)clampi((int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1), 0.0f);
-    }
     // bit 0: the attenuation floor cannot bind; bit 1: every staged light has the SAME attenuation polynomial (one radius for the
     // whole scene is common), so its three coefficients are per-kernel constants and a trip reads 13 LDS dwords instead of 19
     const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
-    const uint32_t px = bx0 + threadIdx.x;
-    if (px >= x_end) return;
-    for (uint32_t py = y_begin; py < y_end; py++)
-        shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin]);
+    SHADE_BSTAMP(0, t_start);
+    SHADE_BSTAMP(1, SHADE_NOW());
+    uint32_t n_done = 0;
+    (void)n_done;
+    for (uint32_t par = 0;; par ^= 1u) {
+        const uint32_t item = s_item[par];   // written before the last barrier
+        if (item == SHADE_NO_ITEM) break;
+        SHADE_ISTAMP(item, 0, SHADE_NOW());
+        const ShadeItem it = item_rect(rc, item);
+        if (threadIdx.x == 0) {   // the item after this one: the pull issued one item ago has had that item's time to return
+            const uint64_t nx = (uint64_t)pend * pbr::SHADE_Q_SHARDS + shard;
+            const uint32_t next = nx < total ? (uint32_t)nx : q_steal(q, shard, total);
+            s_item[par ^ 1u] = next;
+            if (next != SHADE_NO_ITEM) pend = q_pull(q, shard);
+        }
+        int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
+        uint32_t* my_lists = lists + par * (uint32_t)(max_clusters * LIST_STRIDE);
+        if (STAGED_LISTS) stage_lists(p, it, my_lists, lds_base, n_lights, max_clusters, tile_x0, tile_y0, tiles_x);
+        if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[par][threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
+        __syncthreads();
+        SHADE_ISTAMP(item, 1, SHADE_NOW());
+        const uint32_t px = it.bx0 + threadIdx.x;
+        if (px < it.x_end)
+            for (uint32_t py = it.y_begin; py < it.y_end; py++)
+                shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, my_lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[par][py - it.y_begin]);
+        SHADE_ISTAMP_MAX(item, 2, SHADE_NOW());
+        SHADE_ISTAMP(item, 3, ((unsigned long long)(it.y_end - it.y_begin) << 48) | blockIdx.x);
+        n_done++;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* done = q + pbr::SHADE_Q_SHARDS * pbr::SHADE_Q_STRIDE;
+        if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            for (int x = 0; x <= pbr::SHADE_Q_SHARDS; x++) __hip_atomic_store(q + x * pbr::SHADE_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    SHADE_BSTAMP_MAX(2, SHADE_NOW());
+    SHADE_BSTAMP(3, ((unsigned long long)n_done << 32) | (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u));   // hwreg(HW_REG_XCC_ID, 0, 4)
 }
+
+#ifdef PBR_DEBUG_KNOBS
+// The static schedule this kernel had through round 5, kept in the knobs build for A/B (PBR_SHADE_SCHED=grid): one block per work
+// item, dispatched in item order — grid = items, every block stages the light table and its lists for itself.
+template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade_grid(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
+    extern __shared__ float4 lds_raw[];
+    __shared__ uint32_t s_mip_off[16];
+    __shared__ float4 s_row[SHADE_ROWS];
+    const unsigned long long t_start = SHADE_NOW();
+    (void)t_start;
+    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
+    float* llds = reinterpret_cast<float*>(lds_raw);
+    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));
+    int my_safe = 1, my_same = 1;
+    stage_lights<LSTRIDE>(p, llds, n_lights, my_safe, my_same);
+    const ShadeItem it = item_rect(rc, blockIdx.x);
+    int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;
+    if (STAGED_LISTS) stage_lists(p, it, lists, lds_base, n_lights, max_clusters, tile_x0, tile_y0, tiles_x);
+    if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
+    const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
+    SHADE_ISTAMP(blockIdx.x, 0, t_start);
+    SHADE_ISTAMP(blockIdx.x, 1, SHADE_NOW());
+    const uint32_t px = it.bx0 + threadIdx.x;
+    if (px < it.x_end)
+        for (uint32_t py = it.y_begin; py < it.y_end; py++)
+            shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - it.y_begin]);
+    SHADE_ISTAMP_MAX(blockIdx.x, 2, SHADE_NOW());
+    SHADE_ISTAMP(blockIdx.x, 3, ((unsigned long long)(it.y_end - it.y_begin) << 48) | blockIdx.x);
+}
+#endif
 
 extern "C" {
 
@@ -646,44 +803,101 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
     for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)env_padded_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
     p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch; p.hdr_f32 = hdr_f32;
-    // schedule (see the kernel): long blocks first, short ones for the tail
-    static const float big_frac = pbr::knob_float("PBR_SHADE_BIGFRAC", 0.92f);   // re-swept after the per-pixel trims (the knobs build): 0.9-0.95 with 1-row tail blocks beats 0.85 / 2 by ~0.4 %
-    static const uint32_t rows_small_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_SMALL", 1);
-    const uint32_t rows_small = rows_small_cfg >= 1 && rows_small_cfg <= (uint32_t)SHADE_ROWS ? rows_small_cfg : 1u;
-    const uint32_t whole[1][4] = {{0, 0, tile->w, tile->h}};
-    if (!rects) { rects = whole; n_rects = 1; }
-    PBR_REQUIRE(ctx, n_rects >= 1 && n_rects <= (uint32_t)SHADE_MAX_RECTS, "pbr_deferred_shade: 1 .. 5 rectangles");
-    ShadeRects rc{};
-    rc.n = n_rects; rc.rows_small = rows_small;
-    uint32_t blocks = 0;
-    for (uint32_t r = 0; r < n_rects; r++) {
-        const uint32_t* q = rects[r];
-        PBR_REQUIRE(ctx, q[2] >= 1 && q[3] >= 1 && q[0] + q[2] <= tile->w && q[1] + q[3] <= tile->h, "pbr_deferred_shade: rectangle outside the tile");
-        rc.x0[r] = q[0]; rc.y0[r] = q[1]; rc.w[r] = q[2]; rc.h[r] = q[3];
-        rc.cols[r] = (q[2] + SHADE_BLOCK - 1) / SHADE_BLOCK;
-        rc.nb_big[r] = (uint32_t)((float)(q[3] / SHADE_ROWS) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
-        const uint32_t rest = q[3] - rc.nb_big[r] * SHADE_ROWS;
-        rc.first[r] = blocks;
-        blocks += rc.cols[r] * (rc.nb_big[r] + (rest + rows_small - 1) / rows_small);
-    }
-    rc.first[n_rects] = blocks;
-    dim3 grid(blocks);
-    // A block covers 256 x 8 pixels.  It can stage its cluster lists when that rectangle spans at most
+    // A block's item covers 256 x <= 8 pixels.  It can stage its cluster lists when that rectangle spans at most
     // MAX_STAGED_TILES cluster tiles: a tile is full_w/24 x full_h/16 pixels, +1 per axis for straddling.
     const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
     const uint32_t span_y = (uint32_t)((uint64_t)(SHADE_ROWS - 1) * PBR_CLUSTER_Y / tile->full_h) + 2;
     const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
     const size_t plane_bytes = (size_t)((LIGHT_PLANES * lstride + 1) & ~1) * sizeof(float);
-    // staged lists must also fit the 64 KiB a block may ask for (1 024 lights: 36 KiB of planes leave room for 8 tiles)
+#ifdef PBR_DEBUG_KNOBS
+    static const bool sched_grid = pbr::knob_text("PBR_SHADE_SCHED") && pbr::knob_text("PBR_SHADE_SCHED")[0] == 'g';   // the round-5 static grid, for A/B
+#else
+    constexpr bool sched_grid = false;
+#endif
+    const uint32_t list_bufs = sched_grid ? 1u : 2u;   // the queue kernel stages an item's lists while the previous item's are still read
+    // staged lists must also fit the 64 KiB a block may ask for (1 024 lights: 36 KiB of planes leave room for 2 x 6 tiles)
     const bool staged = span_x * span_y <= (uint32_t)MAX_STAGED_TILES &&   // (no lights at all: every list is one null pair)
-                        plane_bytes + (size_t)span_x * span_y * PBR_CLUSTER_Z * LIST_STRIDE * sizeof(uint32_t) <= 65536;
+                        plane_bytes + (size_t)list_bufs * span_x * span_y * PBR_CLUSTER_Z * LIST_STRIDE * sizeof(uint32_t) <= 65536;
     const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
-    const size_t lds = plane_bytes + (size_t)max_clusters * LIST_STRIDE * sizeof(uint32_t);
+    const size_t lds = plane_bytes + (size_t)list_bufs * max_clusters * LIST_STRIDE * sizeof(uint32_t);
+    const bool small_table = lstride == 257;
+    // resident blocks of the device for this instantiation and LDS size (asked once per combination)
+    uint32_t resident = 0;
+    {
+        static uint32_t cache_key[8] = {}, cache_val[8] = {};
+        const uint32_t key = (uint32_t)lds << 3 | (staged ? 4u : 0u) | (small_table ? 2u : 0u) | (F32OUT ? 1u : 0u) | 0x80000000u;
+        for (int i = 0; i < 8 && !resident; i++) if (cache_key[i] == key) resident = cache_val[i];
+        if (!resident) {
+            int per_cu = 0;
+            const void* fn = staged ? (small_table ? (const void*)k_deferred_shade<true, 257, F32OUT> : (const void*)k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>)
+                                    : (small_table ? (const void*)k_deferred_shade<false, 257, F32OUT> : (const void*)k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>);
+            PBR_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SHADE_BLOCK, lds));
+            PBR_REQUIRE(ctx, per_cu >= 1, "pbr_deferred_shade: the kernel does not fit a compute unit");
+            resident = (uint32_t)per_cu * (uint32_t)ctx->cu_count;
+            static uint32_t next_slot = 0;
+            cache_key[next_slot & 7u] = key; cache_val[next_slot & 7u] = resident; next_slot++;
+        }
+    }
+    // Work items (see the kernel): long items first, one-row items for the tail.  rows_big follows the frame: about eight
+    // long items per resident block — 1 row at 1080p, 3 at 4K, 8 at 8K
+    static const float big_frac = pbr::knob_float("PBR_SHADE_BIGFRAC", 0.92f);
+    static const uint32_t rows_small_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_SMALL", 1);
+    static const uint32_t rows_big_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_BIG", 0);       // 0: by frame size
+    static const uint32_t items_per_block = (uint32_t)pbr::knob_int("PBR_SHADE_ITEMS_PER_BLOCK", 8);
+    const uint32_t rows_small = rows_small_cfg >= 1 && rows_small_cfg <= (uint32_t)SHADE_ROWS ? rows_small_cfg : 1u;
+    const uint32_t whole[1][4] = {{0, 0, tile->w, tile->h}};
+    if (!rects) { rects = whole; n_rects = 1; }
+    PBR_REQUIRE(ctx, n_rects >= 1 && n_rects <= (uint32_t)SHADE_MAX_RECTS, "pbr_deferred_shade: 1 .. 5 rectangles");
+    uint64_t row_segments = 0;
+    for (uint32_t r = 0; r < n_rects; r++) {
+        const uint32_t* q = rects[r];
+        PBR_REQUIRE(ctx, q[2] >= 1 && q[3] >= 1 && q[0] + q[2] <= tile->w && q[1] + q[3] <= tile->h, "pbr_deferred_shade: rectangle outside the tile");
+        row_segments += (uint64_t)((q[2] + SHADE_BLOCK - 1) / SHADE_BLOCK) * q[3];
+    }
+    uint32_t rows_big = sched_grid ? (uint32_t)SHADE_ROWS : (uint32_t)(row_segments / ((uint64_t)resident * (items_per_block ? items_per_block : 8u)));
+    if (rows_big_cfg) rows_big = rows_big_cfg;
+    rows_big = rows_big < 1 ? 1u : (rows_big > (uint32_t)SHADE_ROWS ? (uint32_t)SHADE_ROWS : rows_big);
+    ShadeRects rc{};
+    rc.n = n_rects; rc.rows_big = rows_big; rc.rows_small = rows_small < rows_big ? rows_small : rows_big;
+    uint32_t items = 0;
+    for (uint32_t r = 0; r < n_rects; r++) {
+        const uint32_t* q = rects[r];
+        rc.x0[r] = q[0]; rc.y0[r] = q[1]; rc.w[r] = q[2]; rc.h[r] = q[3];
+        rc.cols[r] = (q[2] + SHADE_BLOCK - 1) / SHADE_BLOCK;
+        rc.nb_big[r] = (uint32_t)((float)(q[3] / rows_big) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
+        const uint32_t rest = q[3] - rc.nb_big[r] * rows_big;
+        rc.first[r] = items;
+        items += rc.cols[r] * (rc.nb_big[r] + (rest + rc.rows_small - 1) / rc.rows_small);
+    }
+    rc.first[n_rects] = items;
     const dim3 blk(SHADE_BLOCK);
-    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
-    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
-    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
-    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
+#ifdef PBR_DEBUG_KNOBS
+    if (sched_grid) {
+        const dim3 grid(items);
+        if (staged && small_table) hipLaunchKernelGGL((k_deferred_shade_grid<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
+        else if (staged) hipLaunchKernelGGL((k_deferred_shade_grid<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
+        else if (small_table) hipLaunchKernelGGL((k_deferred_shade_grid<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
+        else hipLaunchKernelGGL((k_deferred_shade_grid<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
+        return launched(ctx, "k_deferred_shade_grid");
+    }
+#endif
+    // the queue slot of this stream (pbr_internal.hpp)
+    uint32_t slot = 0;
+    while (slot < ctx->shade_q_streams.size() && ctx->shade_q_streams[slot] != ctx->stream) slot++;
+    if (slot == ctx->shade_q_streams.size()) {
+        if (slot == (uint32_t)pbr::SHADE_Q_SLOTS) {   // more streams than slots: start over once nothing is in flight any more
+            PBR_HIP(ctx, hipDeviceSynchronize());
+            ctx->shade_q_streams.clear();
+            slot = 0;
+        }
+        ctx->shade_q_streams.push_back(ctx->stream);
+    }
+    uint32_t* q = ctx->shade_q + (size_t)slot * pbr::SHADE_Q_DWORDS;
+    const dim3 grid(items < resident ? items : resident);
+    if (staged && small_table) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc, q);
+    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc, q);
+    else if (small_table) hipLaunchKernelGGL((k_deferred_shade<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc, q);
+    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc, q);
     return launched(ctx, "k_deferred_shade");
 }
 
