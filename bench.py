@@ -982,10 +982,13 @@ def main():
                 kern[name] = {"ms": round(ms, 4), "GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1) if nbytes else None}
                 frame.hist.zero_()
             hbm_meas = measure_hbm_read(ctx)
-            try:
-                valu_meas = measure_valu(ctx)
-            except Exception as e:   # noqa: BLE001 — reporting only
-                valu_meas = {"error": str(e)}
+            if rehearsal:   # ranks sharing one card would measure each other's load: the normalisers mean nothing there
+                valu_meas = {"skipped": "rehearsal: all ranks share one device"}
+            else:
+                try:
+                    valu_meas = measure_valu(ctx)
+                except Exception as e:   # noqa: BLE001 — reporting only
+                    valu_meas = {"error": str(e)}
     if rank == 0 and not a.no_kernel_timing:
         # dominant kernel: the shade.  Its launch duration is the mean over the frames of the timed region; the
         # per-stage figures below come from separate isolated launches after it

@@ -91,14 +91,15 @@ class PbrContext:
         of the polyphase form (<= 1 fp16 ULP per stage)"""
         self._check(self.lib.pbr_ctx_set_bloom_shader_order(self.h, 1 if on else 0))
 
-    def partition_cus(self, side_cus, total_cus=None, layout="low"):
+    def partition_cus(self, side_cus, total_cus=None, layout="low", allow_uneven=False):
         """pbr_ctx_set_cu_masks with `side_cus` compute units, spread evenly over the device, for the side stream and the rest for the
         context's private stream (0: no partition, every CU for both).  The context must be on its private stream (use_own_stream).
         Masked streams synchronise with the legacy null stream (hipExtStreamCreateWithCUMask takes no flags): default-stream torch work
         (.zero_(), event records) or a hipMemset inside a partitioned frame makes the two partitions take turns.
         layout="low" needs side_cus to be a multiple of 32 (the same number of CUs from every XCD): anything else runs at the pace of
-        the poorest XCD and is refused — the uneven layouts exist as "strided" / "per_xcd", for the measurement of exactly that."""
-        if side_cus and layout == "low" and int(side_cus) % 32:
+        the poorest XCD and is refused — the uneven layouts exist as "strided" / "per_xcd", for the measurement of exactly that;
+        allow_uneven=True (tools/cu_partition.py, which measures that effect with layout "low" too) lifts the refusal."""
+        if side_cus and layout == "low" and int(side_cus) % 32 and not allow_uneven:
             raise PbrError(f"partition_cus: layout 'low' takes a multiple of 32 compute units (got {side_cus}): an uneven share per XCD runs at the poorest XCD's pace")
         if not side_cus:
             self._check(self.lib.pbr_ctx_set_cu_masks(self.h, None, None, 0))
@@ -315,6 +316,10 @@ class PbrContext:
     def valubench(self, op, blocks, iters, stamps):
         """pbr_valubench: blocks x 4 waves issue iters x 8 instructions of class op (0 v_mul_f32, 1 v_fma_f32, 2 v_pk_fma_f32,
         3 v_rcp_f32); stamps: int64 [blocks * 4, 4] device tensor = {shader cycles start, end, 100 MHz ticks start, end} per wave"""
+        # the kernel writes blocks * 4 * 4 uint64 through the raw pointer: a short or mistyped tensor would be a silent out-of-bounds write
+        if not (isinstance(stamps, torch.Tensor) and stamps.is_cuda and stamps.dtype == torch.int64 and stamps.is_contiguous()
+                and stamps.numel() >= int(blocks) * 16):
+            raise PbrError(f"valubench: stamps must be a contiguous int64 device tensor of at least {int(blocks) * 16} elements")
         self._check(self.lib.pbr_valubench(self.h, int(op), int(blocks), int(iters), _ptr(stamps)))
 
     # ---- multi-GPU --------------------------------------------------------------------------------

@@ -4,15 +4,17 @@
 #include <dlfcn.h>
 // RCCL: declarations only — the library is bound with dlopen (section "RCCL"), so a one-GPU process never needs librccl.  A build box
 // without the development header still builds: the handful of types, enum values and signatures the calls need are restated below
-// (RCCL >= 2.18 ABI) and the static_asserts that pin them to the header are skipped.
-#if __has_include(<rccl/rccl.h>)
+// (RCCL >= 2.18 ABI) and the static_asserts that pin them to the header are compiled out.  -DPBR_NO_RCCL_HEADER forces that branch:
+// tests/test_build.py compiles this file host-only with it, so the branch stays buildable on boxes that do have the header.
+#if __has_include(<rccl/rccl.h>) && !defined(PBR_NO_RCCL_HEADER)
 #include <rccl/rccl.h>
 #define PBR_HAVE_RCCL_HEADER 1
 #else
 #define PBR_HAVE_RCCL_HEADER 0
 extern "C" {
+#define NCCL_UNIQUE_ID_BYTES 128
 typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
 typedef enum { ncclInt8 = 0, ncclUint32 = 3 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
@@ -174,9 +176,11 @@ pbr_status pbr_sync(pbr_ctx* ctx) {
 // Types, enum values and signatures come from <rccl/rccl.h> (included at the top of this file); the library itself is still
 // bound with dlopen so that a one-GPU process never needs librccl.  Every dlsym'd pointer is typed with decltype(&ncclXxx):
 // a signature drift between the header and this file fails the build instead of the first 8-GPU run.
+#if PBR_HAVE_RCCL_HEADER   // pin the header to what this file (and its restated fallback declarations) assume
 static_assert(sizeof(ncclUniqueId) == 128 && NCCL_UNIQUE_ID_BYTES == 128, "pbr_comm_unique_id / pbr_comm_init hand the id over as 128 opaque bytes (pbr_hip.h)");
 static_assert(ncclInt8 == 0 && ncclUint32 == 3 && ncclSum == 0 && ncclSuccess == 0, "RCCL enum values this file was written against");
-static_assert(sizeof(ncclComm_t) == sizeof(void*), "pbr_ctx keeps the communicators as opaque pointers");
+#endif
+static_assert(sizeof(ncclComm_t) == sizeof(void*) && sizeof(ncclUniqueId) == 128, "pbr_ctx keeps the communicators as opaque pointers, the id travels as 128 bytes");
 
 #define RCCL_FN(lib, name) ((lib) ? reinterpret_cast<decltype(&name)>(dlsym((lib), #name)) : nullptr)
 
@@ -228,7 +232,9 @@ pbr_status pbr_comm_init(pbr_ctx* ctx, int world, int rank, const void* unique_i
     // then FAILS inside RCCL keeps the world / rank the caller asked for, with no communicator: both collectives refuse from then on
     // (comm_teardown), the context never falls back to single-GPU behaviour silently.
     PBR_REQUIRE(ctx, world == 1 || unique_id_128_bytes != nullptr, "pbr_comm_init: null unique id");
-    PBR_REQUIRE(ctx, unique_id_128_bytes == nullptr || ctx->comm == nullptr, "pbr_comm_init: the context already has a communicator");
+    // (any init, also a world-1 one with no id: it would set world / rank to 1 / 0 and leave the old communicators attached,
+    //  and pbr_allreduce_hist would go on reducing over them — ADVICE r05)
+    PBR_REQUIRE(ctx, ctx->comm == nullptr && ctx->comm_hist == nullptr, "pbr_comm_init: the context already has a communicator");
     ctx->world = world;
     ctx->rank = rank;
     // world 1 needs no communicator; with a unique id one is created all the same (a 1-rank RCCL communicator is

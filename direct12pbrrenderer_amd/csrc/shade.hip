@@ -125,6 +125,7 @@ struct ShadeRects {
     uint32_t n, rows_big, rows_small;
     uint32_t x0[SHADE_MAX_RECTS], y0[SHADE_MAX_RECTS], w[SHADE_MAX_RECTS], h[SHADE_MAX_RECTS];
     uint32_t cols[SHADE_MAX_RECTS], nb_big[SHADE_MAX_RECTS], first[SHADE_MAX_RECTS + 1];   // first item of rect r; [n] = total
+    uint32_t cols_magic[SHADE_MAX_RECTS];   // ceil(2^32 / cols): item / cols = mulhi(item, magic) for item < 2^32 / cols (host-checked); cols = 1: unused
 };
 
 constexpr int SHADE_BLOCK = 256;
@@ -596,7 +597,7 @@ __device__ __forceinline__ ShadeItem item_rect(const ShadeRects& rc, uint32_t it
     uint32_t r = 0;   // item -> rectangle -> (column block, item row); wave-uniform scalar arithmetic
     while (r + 1 < rc.n && item >= rc.first[r + 1]) r++;
     const uint32_t lb = item - rc.first[r];
-    const uint32_t by = lb / rc.cols[r], nb_big = rc.nb_big[r];
+    const uint32_t by = rc.cols[r] == 1 ? lb : __umulhi(lb, rc.cols_magic[r]), nb_big = rc.nb_big[r];
     ShadeItem it;
     it.bx0 = rc.x0[r] + (lb - by * rc.cols[r]) * SHADE_BLOCK;
     it.x_end = rc.x0[r] + rc.w[r];
@@ -605,34 +606,99 @@ __device__ __forceinline__ ShadeItem item_rect(const ShadeRects& rc, uint32_t it
     return it;
 }
 
-// The light lists of the clusters an item's pixels can fall into, as LDS byte addresses of the lights (one dword each) — same
-// arithmetic as the per-pixel ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners
-// bound it.  A thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry.
-__device__ __forceinline__ void stage_lists(const ShadeParams& p, const ShadeItem& it, uint32_t* lists, uint32_t lds_base, int n_lights, int max_clusters,
-                                            int& tile_x0, int& tile_y0, int& tiles_x) {
-    static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
+// The cluster (x,y) tiles an item's pixels can fall into — same arithmetic as the per-pixel ClusterIndex (floor(u*24),
+// floor((1-v)*16)); monotone in the pixel coordinate, so the corners bound it.  n_cl = clusters to stage (8 z-slices per tile).
+struct ItemTiles { int tile_x0, tile_y0, tiles_x, n_cl; };
+__device__ __forceinline__ ItemTiles item_tiles(const ShadeParams& p, const ShadeItem& it, int max_clusters) {
     const uint32_t bx1 = min(it.bx0 + SHADE_BLOCK, it.x_end) - 1;
     auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
     auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
-    tile_x0 = tx(it.bx0);
+    ItemTiles tl;
+    tl.tile_x0 = tx(it.bx0);
     const int tile_x1 = tx(bx1);
-    const int ty_a = ty(it.y_begin), ty_b = ty(it.y_end - 1);
-    tile_y0 = min(ty_a, ty_b);
-    const int tile_y1 = max(ty_a, ty_b);
-    tiles_x = tile_x1 - tile_x0 + 1;
-    const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
-    const int j = threadIdx.x & 31;
-    for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
-        const int z = c & 7, t = c >> 3;
-        const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
-        const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
-        const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-        uint32_t* l = lists + c * LIST_STRIDE;
-        const int li = j < cnt ? min(max(cl->LightIndex[j], 0), n_lights - 1) : n_lights;   // never index past the staged table
-        l[2 + j] = lds_base + 4u * (uint32_t)li;
-        if (j < 2) l[j] = j == 0 ? (uint32_t)max((cnt + 1) & ~1, 2) : 0u;
+    const int ty_a = ty(it.y_begin), ty_b = it.y_end - it.y_begin > 1 ? ty(it.y_end - 1) : ty_a;
+    tl.tile_y0 = min(ty_a, ty_b);
+    tl.tiles_x = tile_x1 - tl.tile_x0 + 1;
+    tl.n_cl = min(tl.tiles_x * (max(ty_a, ty_b) - tl.tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
+    return tl;
+}
+// staged cluster c of an item -> its record: c = (tile row * tiles_x + tile column) * 8 + z
+__device__ __forceinline__ const pbr_cluster* staged_cluster(const ShadeParams& p, const ItemTiles& tl, int c) {
+    const int z = c & 7, t = c >> 3;
+    // t / tiles_x, both <= MAX_STAGED_TILES: (t + 1/2) / tiles_x is never within 0.04 of an integer, so the approximate reciprocal is exact enough
+    const int ty_ = (int)(((float)t + 0.5f) * rcp((float)tl.tiles_x));
+    const int cx = tl.tile_x0 + (t - ty_ * tl.tiles_x), cy = tl.tile_y0 + ty_;
+    return p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+}
+// one staged list entry: the LDS byte address of light `raw_index` (the null light from entry `cn` on)
+__device__ __forceinline__ uint32_t list_entry(int j, int cn, int raw_index, int n_lights, uint32_t lds_base) {
+    const int li = j < cn ? min(max(raw_index, 0), n_lights - 1) : n_lights;   // never index past the staged table
+    return lds_base + 4u * (uint32_t)li;
+}
+
+// ---- LDS-DMA: global -> LDS without a register in between (global_load_lds_*; M0 = the wave's LDS destination, lane l lands at
+// M0 + l * size; inactive lanes are skipped).  The statements follow cdna_hip_programming.md's recipe (M0 saved and restored inside
+// the statement that uses it).  hipcc does not count these loads: their data needs dma_wait() by the ISSUING wave, then a barrier,
+// before anyone reads it.  (tools/debug/dma_probe.hip: 4-byte-aligned 16-byte sources are fine.)
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// threadIdx.x as a value the compiler must rebuild here: nothing derived from it is hoisted out of the item loop into registers
+// that then live (spilled) across the pixel code
+__device__ __forceinline__ uint32_t tid_here() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+
+constexpr int FETCH_ROUNDS = MAX_STAGED_TILES * PBR_CLUSTER_Z / (SHADE_BLOCK / 8);   // 3: a round = 32 clusters, 8 lanes x 16 bytes per cluster
+static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32 && FETCH_ROUNDS * (SHADE_BLOCK / 8) == MAX_STAGED_TILES * PBR_CLUSTER_Z, "staging map");
+// [A] the raw index lists (128 bytes each, record offset 28) and counts of an item's clusters -> raw[c][32], cnt[c]: asynchronous.
+// n_cl is a multiple of 8 and a wave covers 8 clusters per round: the `c < n_cl` branches are wave-uniform.
+__device__ __forceinline__ void lists_fetch(const ShadeParams& p, const ItemTiles& tl, uint32_t raw_b, uint32_t cnt_b, uint32_t tid) {
+    const uint32_t w = tid >> 6;
+#pragma unroll
+    for (int r = 0; r < FETCH_ROUNDS; r++) {
+        const int c = (int)(tid >> 3) + r * (SHADE_BLOCK / 8);
+        if (c < tl.n_cl)
+            dma16(reinterpret_cast<const char*>(staged_cluster(p, tl, c)->LightIndex) + 16u * (tid & 7u),
+                  __builtin_amdgcn_readfirstlane(raw_b + ((uint32_t)r * (SHADE_BLOCK / 8) + 8u * w) * 128u));
+    }
+    if ((int)tid < tl.n_cl) dma4(&staged_cluster(p, tl, (int)tid)->NumLights, __builtin_amdgcn_readfirstlane(cnt_b + w * 256u));
+}
+// [B] raw -> the walk's format (count padded to even, entries = LDS addresses of lights): LDS to LDS, 4 entries per thread and round
+__device__ __forceinline__ void lists_finish(int n_cl, const uint32_t* raw, const uint32_t* cnt, uint32_t* lists, uint32_t lds_base, int n_lights, uint32_t tid) {
+#pragma unroll
+    for (int r = 0; r < FETCH_ROUNDS; r++) {
+        const int c = (int)(tid >> 3) + r * (SHADE_BLOCK / 8);
+        if (c < n_cl) {
+            const int part = tid & 7;
+            const uint4 v = reinterpret_cast<const uint4*>(raw)[tid + r * SHADE_BLOCK];
+            const int cn = n_lights > 0 ? min(max((int)cnt[c], 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
+            uint32_t* l = lists + c * LIST_STRIDE;
+            uint2* e = reinterpret_cast<uint2*>(l + 2 + 4 * part);   // 136 c + 8 + 16 part bytes: 8-byte aligned
+            e[0] = make_uint2(list_entry(4 * part + 0, cn, (int)v.x, n_lights, lds_base), list_entry(4 * part + 1, cn, (int)v.y, n_lights, lds_base));
+            e[1] = make_uint2(list_entry(4 * part + 2, cn, (int)v.z, n_lights, lds_base), list_entry(4 * part + 3, cn, (int)v.w, n_lights, lds_base));
+            if (part == 0) *reinterpret_cast<uint2*>(l) = make_uint2((uint32_t)max((cn + 1) & ~1, 2), 0u);
+        }
     }
 }
+
+#ifdef PBR_DEBUG_KNOBS
+// the static-grid kernel's staging (knobs build): a thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k, plain loads
+__device__ __forceinline__ void stage_lists(const ShadeParams& p, const ItemTiles& tl, uint32_t* lists, uint32_t lds_base, int n_lights) {
+    const int j = threadIdx.x & 31;
+    for (int c = threadIdx.x >> 5; c < tl.n_cl; c += SHADE_BLOCK / 32) {
+        const pbr_cluster* cl = staged_cluster(p, tl, c);
+        const int cn = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
+        uint32_t* l = lists + c * LIST_STRIDE;
+        l[2 + j] = list_entry(j, cn, cl->LightIndex[j], n_lights, lds_base);
+        if (j < 2) l[j] = j == 0 ? (uint32_t)max((cn + 1) & ~1, 2) : 0u;
+    }
+}
+#endif
 
 // per-row terms of an item's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
 __device__ __forceinline__ float4 row_terms(const ShadeParams& p, uint32_t y) {
@@ -645,65 +711,123 @@ __device__ __forceinline__ float4 row_terms(const ShadeParams& p, uint32_t y) {
 #define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
 #endif
 
-// grid = min(items, compute units x resident blocks), block 256.
-// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) 2 x max_clusters * 136 B of light lists: the lists of
-// item k + 1 are staged while the block's slower waves may still walk those of item k, so ONE barrier per item orders everything.
+// grid = min(items, compute units x resident blocks), block 256.  Item b is block b's first; the queue hands out the rest.
+// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) per staged cluster 136 B of list, 128 B of raw
+// indices and a raw count.  While a block shades item k, the lists of item k + 1 arrive in `raw` by LDS-DMA (no register, no
+// wait); between items: barrier (every wave done with k, every wave's DMA landed), raw -> lists (LDS to LDS), barrier.
+// The item after next is pulled by whichever wave of the block finishes its part of item k FIRST — it would otherwise wait at
+// the barrier for the slower ones, so the atomic's round trip (1 - 3 us) costs nothing unless all four waves arrive together.
+// Nothing of the schedule lives in a vector register across the pixel code (the puller's state is in LDS, block-uniform values
+// are scalar, thread-index-derived values are rebuilt per phase: the pixel code has no register to spare, and what hipcc spills
+// it reloads with a full vmcnt(0) wait each).
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc, uint32_t* q) {
     extern __shared__ float4 lds_raw[];
     __shared__ uint32_t s_mip_off[16];
-    __shared__ uint32_t s_item[2];
-    __shared__ float4 s_row[2][SHADE_ROWS];
+    __shared__ uint32_t s_item;              // the item after next
+    __shared__ uint32_t s_arrive;            // waves that have finished the current item
+    __shared__ uint32_t s_shard, s_live;     // the puller's state: the shard the block pulls from; 0 once every shard has run dry
+    __shared__ int4 s_desc[2][2];            // an item's {bx0, x_end, y_begin, y_end}, {tile_x0, tile_y0, tiles_x, n_cl}; [k & 1]
+    __shared__ float4 s_row[SHADE_ROWS];
+    __shared__ ShadeRects s_rc;              // the item table is read once per item: from LDS, not from 42 scalar registers held across the pixel code
     const unsigned long long t_start = SHADE_NOW();
     (void)t_start;
-    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
     float* llds = reinterpret_cast<float*>(lds_raw);
-    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));   // 8-byte aligned
-    const uint32_t total = rc.first[rc.n];
-    // thread 0 is the block's puller: `pend` = the head value of a pull in flight on `shard`
-    uint32_t shard = blockIdx.x & 7u, pend = 0;
-    if (threadIdx.x == 0) {
-        const uint64_t it = (uint64_t)q_pull(q, shard) * pbr::SHADE_Q_SHARDS + shard;
-        const uint32_t first = it < total ? (uint32_t)it : q_steal(q, shard, total);
-        s_item[0] = first;
-        if (first != SHADE_NO_ITEM) pend = q_pull(q, shard);   // issued only where the loop below consumes its result
+    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 3) & ~3));   // 16-byte aligned
+    uint32_t* raw = lists + max_clusters * LIST_STRIDE;                                           // max_clusters is a multiple of 8: 16-byte aligned
+    uint32_t* cntraw = raw + max_clusters * PBR_MAX_LIGHTS_PER_CLUSTER;
+    const uint32_t raw_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)raw;
+    const uint32_t cnt_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cntraw;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;   // < 64 KiB: the whole light table (<= 9 x 1025 floats) stays addressable in 16 bits
+    const uint32_t total_q = rc.first[rc.n] - gridDim.x;   // items the queue hands out: gridDim.x + (pull * 8 + shard)
+    // one synchronous pull (called by ONE lane): the next item, or SHADE_NO_ITEM for good
+    auto take = [&]() -> uint32_t {
+        if (!s_live) return SHADE_NO_ITEM;
+        uint32_t shard = s_shard;
+        const uint64_t nx = (uint64_t)q_pull(q, shard) * pbr::SHADE_Q_SHARDS + shard;
+        const uint32_t it = nx < total_q ? (uint32_t)nx : q_steal(q, shard, total_q);
+        if (it == SHADE_NO_ITEM) { s_live = 0; return it; }
+        s_shard = shard;
+        return it + gridDim.x;
+    };
+    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
+    if (threadIdx.x < sizeof(ShadeRects) / 4) reinterpret_cast<uint32_t*>(&s_rc)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&rc)[threadIdx.x];
+    // the block's first item: its lists' DMA and the light table's loads travel together
+    {
+        const ShadeItem it = item_rect(rc, blockIdx.x);
+        const ItemTiles tl = item_tiles(p, it, max_clusters);
+        if (threadIdx.x == 0) {
+            s_desc[0][0] = make_int4((int)it.bx0, (int)it.x_end, (int)it.y_begin, (int)it.y_end);
+            s_desc[0][1] = make_int4(tl.tile_x0, tl.tile_y0, tl.tiles_x, tl.n_cl);
+            s_arrive = 0;
+        }
+        if (STAGED_LISTS) lists_fetch(p, tl, raw_b, cnt_b, threadIdx.x);
+        if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
     }
     int my_safe = 1, my_same = 1;
     stage_lights<LSTRIDE>(p, llds, n_lights, my_safe, my_same);
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;   // < 64 KiB: the whole light table (<= 9 x 1025 floats) stays addressable in 16 bits
+    if (threadIdx.x == SHADE_BLOCK - 1) {   // (a lane of the last wave: the first three have a light each to convert meanwhile)
+        s_shard = blockIdx.x & 7u;
+        s_live = 1;
+        s_item = take();
+    }
+    dma_wait();
     // bit 0: the attenuation floor cannot bind; bit 1: every staged light has the SAME attenuation polynomial (one radius for the
     // whole scene is common), so its three coefficients are per-kernel constants and a trip reads 13 LDS dwords instead of 19
     const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
+    uint32_t cur = blockIdx.x, nxt = __builtin_amdgcn_readfirstlane(s_item);
+    (void)cur;
+    if (STAGED_LISTS) lists_finish(s_desc[0][1].w, raw, cntraw, lists, lds_base, n_lights, threadIdx.x);
+    __syncthreads();
     SHADE_BSTAMP(0, t_start);
     SHADE_BSTAMP(1, SHADE_NOW());
     uint32_t n_done = 0;
     (void)n_done;
     for (uint32_t par = 0;; par ^= 1u) {
-        const uint32_t item = s_item[par];   // written before the last barrier
-        if (item == SHADE_NO_ITEM) break;
-        SHADE_ISTAMP(item, 0, SHADE_NOW());
-        const ShadeItem it = item_rect(rc, item);
-        if (threadIdx.x == 0) {   // the item after this one: the pull issued one item ago has had that item's time to return
-            const uint64_t nx = (uint64_t)pend * pbr::SHADE_Q_SHARDS + shard;
-            const uint32_t next = nx < total ? (uint32_t)nx : q_steal(q, shard, total);
-            s_item[par ^ 1u] = next;
-            if (next != SHADE_NO_ITEM) pend = q_pull(q, shard);
+        SHADE_ISTAMP(cur, 0, SHADE_NOW());
+        // [A] the next item's lists set out
+        if (nxt != SHADE_NO_ITEM) {
+            const uint32_t tid = tid_here();
+            const ShadeItem nit = item_rect(s_rc, nxt);
+            const ItemTiles ntl = item_tiles(p, nit, max_clusters);
+            if (tid == 0) {
+                s_desc[par ^ 1u][0] = make_int4((int)nit.bx0, (int)nit.x_end, (int)nit.y_begin, (int)nit.y_end);
+                s_desc[par ^ 1u][1] = make_int4(ntl.tile_x0, ntl.tile_y0, ntl.tiles_x, ntl.n_cl);
+            }
+            if (STAGED_LISTS) lists_fetch(p, ntl, raw_b, cnt_b, tid);
         }
-        int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
-        uint32_t* my_lists = lists + par * (uint32_t)(max_clusters * LIST_STRIDE);
-        if (STAGED_LISTS) stage_lists(p, it, my_lists, lds_base, n_lights, max_clusters, tile_x0, tile_y0, tiles_x);
-        if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[par][threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
-        __syncthreads();
-        SHADE_ISTAMP(item, 1, SHADE_NOW());
-        const uint32_t px = it.bx0 + threadIdx.x;
-        if (px < it.x_end)
-            for (uint32_t py = it.y_begin; py < it.y_end; py++)
-                shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, my_lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[par][py - it.y_begin]);
-        SHADE_ISTAMP_MAX(item, 2, SHADE_NOW());
-        SHADE_ISTAMP(item, 3, ((unsigned long long)(it.y_end - it.y_begin) << 48) | blockIdx.x);
+        SHADE_ISTAMP(cur, 1, SHADE_NOW());
+        // this item (block-uniform values in scalar registers)
+        {
+            const int4 d0 = s_desc[par][0], d1 = s_desc[par][1];
+            const uint32_t bx0 = __builtin_amdgcn_readfirstlane(d0.x), x_end = __builtin_amdgcn_readfirstlane(d0.y);
+            const uint32_t y_begin = __builtin_amdgcn_readfirstlane(d0.z), y_end = __builtin_amdgcn_readfirstlane(d0.w);
+            const int tile_x0 = __builtin_amdgcn_readfirstlane(d1.x), tile_y0 = __builtin_amdgcn_readfirstlane(d1.y), tiles_x = __builtin_amdgcn_readfirstlane(d1.z);
+            const uint32_t px = bx0 + tid_here();
+            if (px < x_end)
+                for (uint32_t py = y_begin; py < y_end; py++)
+                    shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin]);
+            SHADE_ISTAMP_MAX(cur, 2, SHADE_NOW());
+            SHADE_ISTAMP(cur, 3, ((unsigned long long)(y_end - y_begin) << 48) | blockIdx.x);
+        }
         n_done++;
+        if (nxt == SHADE_NO_ITEM) break;
+        // [B] between items.  The first wave to get here pulls the item after next.
+        if (__lane_id() == 0 && atomicAdd(&s_arrive, 1u) == 0) s_item = take();
+        dma_wait();
+        __syncthreads();                         // every wave is done with `lists` and `s_row`; every wave's DMA has landed; s_item is written
+        {
+            const uint32_t tid = tid_here();
+            const int4 n0 = s_desc[par ^ 1u][0], n1 = s_desc[par ^ 1u][1];
+            if (STAGED_LISTS) lists_finish(n1.w, raw, cntraw, lists, lds_base, n_lights, tid);
+            if (tid < (uint32_t)SHADE_ROWS) s_row[tid] = row_terms(p, (uint32_t)n0.z + tid);
+            if (tid == 0) s_arrive = 0;
+        }
+        cur = nxt;
+        nxt = __builtin_amdgcn_readfirstlane(s_item);
+        __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {   // (no pull of this block is in flight: every one was waited for where it was made)
         uint32_t* done = q + pbr::SHADE_Q_SHARDS * pbr::SHADE_Q_STRIDE;
         if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
             for (int x = 0; x <= pbr::SHADE_Q_SHARDS; x++) __hip_atomic_store(q + x * pbr::SHADE_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -725,13 +849,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
     (void)t_start;
     if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
     float* llds = reinterpret_cast<float*>(lds_raw);
-    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));
+    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 3) & ~3));
     int my_safe = 1, my_same = 1;
     stage_lights<LSTRIDE>(p, llds, n_lights, my_safe, my_same);
     const ShadeItem it = item_rect(rc, blockIdx.x);
-    int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
+    const ItemTiles tl = item_tiles(p, it, max_clusters);
+    const int tile_x0 = tl.tile_x0, tile_y0 = tl.tile_y0, tiles_x = tl.tiles_x;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;
-    if (STAGED_LISTS) stage_lists(p, it, lists, lds_base, n_lights, max_clusters, tile_x0, tile_y0, tiles_x);
+    if (STAGED_LISTS) stage_lists(p, tl, lists, lds_base, n_lights);
     if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
     const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
     SHADE_ISTAMP(blockIdx.x, 0, t_start);
@@ -808,18 +933,19 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
     const uint32_t span_y = (uint32_t)((uint64_t)(SHADE_ROWS - 1) * PBR_CLUSTER_Y / tile->full_h) + 2;
     const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
-    const size_t plane_bytes = (size_t)((LIGHT_PLANES * lstride + 1) & ~1) * sizeof(float);
+    const size_t plane_bytes = (size_t)((LIGHT_PLANES * lstride + 3) & ~3) * sizeof(float);
 #ifdef PBR_DEBUG_KNOBS
     static const bool sched_grid = pbr::knob_text("PBR_SHADE_SCHED") && pbr::knob_text("PBR_SHADE_SCHED")[0] == 'g';   // the round-5 static grid, for A/B
 #else
     constexpr bool sched_grid = false;
 #endif
-    const uint32_t list_bufs = sched_grid ? 1u : 2u;   // the queue kernel stages an item's lists while the previous item's are still read
-    // staged lists must also fit the 64 KiB a block may ask for (1 024 lights: 36 KiB of planes leave room for 2 x 6 tiles)
+    // per staged cluster: its list (136 B) + in the queue kernel the landing area of the next item's raw indices (128 B) and count
+    const size_t cluster_bytes = LIST_STRIDE * sizeof(uint32_t) + (sched_grid ? 0 : (PBR_MAX_LIGHTS_PER_CLUSTER + 1) * sizeof(uint32_t));
+    // staged lists must also fit the 64 KiB a block may ask for (1 024 lights: 36 KiB of planes leave room for 12 tiles)
     const bool staged = span_x * span_y <= (uint32_t)MAX_STAGED_TILES &&   // (no lights at all: every list is one null pair)
-                        plane_bytes + (size_t)list_bufs * span_x * span_y * PBR_CLUSTER_Z * LIST_STRIDE * sizeof(uint32_t) <= 65536;
+                        plane_bytes + (size_t)span_x * span_y * PBR_CLUSTER_Z * cluster_bytes <= 65536;
     const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
-    const size_t lds = plane_bytes + (size_t)list_bufs * max_clusters * LIST_STRIDE * sizeof(uint32_t);
+    const size_t lds = plane_bytes + (size_t)max_clusters * cluster_bytes;
     const bool small_table = lstride == 257;
     // resident blocks of the device for this instantiation and LDS size (asked once per combination)
     uint32_t resident = 0;
@@ -864,12 +990,14 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
         const uint32_t* q = rects[r];
         rc.x0[r] = q[0]; rc.y0[r] = q[1]; rc.w[r] = q[2]; rc.h[r] = q[3];
         rc.cols[r] = (q[2] + SHADE_BLOCK - 1) / SHADE_BLOCK;
+        rc.cols_magic[r] = rc.cols[r] > 1 ? (uint32_t)(((1ull << 32) + rc.cols[r] - 1) / rc.cols[r]) : 0u;
         rc.nb_big[r] = (uint32_t)((float)(q[3] / rows_big) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
         const uint32_t rest = q[3] - rc.nb_big[r] * rows_big;
         rc.first[r] = items;
         items += rc.cols[r] * (rc.nb_big[r] + (rest + rc.rows_small - 1) / rc.rows_small);
     }
     rc.first[n_rects] = items;
+    PBR_REQUIRE(ctx, (uint64_t)items * 256u < (1ull << 32), "pbr_deferred_shade: too many work items");   // cols <= 256: item / cols by multiply-high is exact
     const dim3 blk(SHADE_BLOCK);
 #ifdef PBR_DEBUG_KNOBS
     if (sched_grid) {

@@ -89,8 +89,9 @@ public:
     void Present(DeviceTexture2D* tex) { mPresented = tex; }
 
     // Pass-level entry points (not in the reference): a pass whose Execute body is a fixed sequence of dispatches can
-    // hand the whole sequence over in one call — same results, fewer launches, intermediates kept on chip.  Passes use
-    // them when FusedPasses() is on; off (default) every reference dispatch is issued one by one.
+    // hand the whole sequence over in one call — fewer launches, intermediates kept on chip; the per-frame passes (Clustered,
+    // Bloom) bit for bit the same frame, the one-shot env prefilter within 1 fp16 ULP (below).  Passes use them when
+    // FusedPasses() is on; off (default) every reference dispatch is issued one by one.
     void SetFusedPasses(bool on) { mFusedPasses = on; }
     bool FusedPasses() const { return mFusedPasses; }
     // PreFilterEnvMapPass::Execute's five env_map_gen.hlsl dispatches (DeferredPipeline.cpp:97-113) as ONE pbr_prefilter_env:

@@ -74,8 +74,10 @@ int pbrh_comm_init(pbrh_renderer* r, int world, int rank, const void* unique_id_
 int pbrh_set_external_histogram(pbrh_renderer* r, const uint32_t* counts256);
 int pbrh_capture_histogram(pbrh_renderer* r, int on);
 int pbrh_captured_histogram(pbrh_renderer* r, uint32_t* dst256);
-/* on: ClusteredPass and BloomPass hand their fixed dispatch sequences over as one call each (pbr_clustered, pbr_bloom);
- * off (default): every reference dispatch is issued one by one.  Same results. */
+/* on: ClusteredPass, BloomPass and the one-shot PreFilterEnvMapPass hand their fixed dispatch sequences over as one call each
+ * (pbr_clustered, pbr_bloom[_histogram], pbr_prefilter_env); off (default): every reference dispatch is issued one by one.
+ * The per-frame passes give the same frame bit for bit either way; the fused env chain is within 1 fp16 ULP of the five
+ * dispatches (tests/test_host_graph.py).  May be switched between frames. */
 int pbrh_set_fused(pbrh_renderer* r, int on);
 /* n frames; *ms_per_frame = average wall time per frame (every frame ends with the per-frame fence wait) */
 int pbrh_render_n(pbrh_renderer* r, int n, float delta_time, double* ms_per_frame);

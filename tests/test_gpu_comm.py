@@ -51,6 +51,18 @@ hist = torch.arange(256, dtype=torch.int32, device="cuda")
 ctx.allreduce_hist(hist)                        # ncclAllReduce(sum, uint32, 256) over one rank = identity
 ctx.sync()
 assert torch.equal(hist.cpu(), torch.arange(256, dtype=torch.int32))
+# a second init of a context that holds a communicator is refused whatever its arguments — also the world-1 / no-id form, which
+# would have left world / rank at 1 / 0 with the old communicators still attached (ADVICE r05) — and changes nothing
+from direct12pbrrenderer_amd.api import PbrError
+for args in ((1, 0, None), (1, 0, comm_unique_id()), (2, 1, comm_unique_id())):
+    try:
+        ctx.comm_init(*args)
+        raise SystemExit("a second pbr_comm_init was accepted: " + repr(args[:2]))
+    except PbrError as e:
+        assert "already has a communicator" in str(e), str(e)
+ctx.allreduce_hist(hist)                        # still the 1-rank communicator
+ctx.sync()
+assert torch.equal(hist.cpu(), torch.arange(256, dtype=torch.int32))
 # halo exchange with itself: rect A travels to rect B through pack -> ncclSend/ncclRecv -> unpack
 W, H = 96, 40
 plane = torch.from_numpy(np.random.default_rng(1).integers(0, 30000, (H, W, 4)).astype(np.int16)).cuda()

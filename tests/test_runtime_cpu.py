@@ -122,3 +122,14 @@ def test_product_library_never_reads_the_environment():
     und = lambda path: subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in und(lib)
     assert "getenv" in und(knobs)
+
+
+def test_ctx_builds_without_the_rccl_development_header(tmp_path):
+    """ctx.hip restates the few RCCL declarations it needs for build boxes without <rccl/rccl.h>; -DPBR_NO_RCCL_HEADER forces that
+    branch (it had never been compiled and did not compile).  Host-only syntax pass: no GPU, no link."""
+    src = os.path.join(ROOT, "direct12pbrrenderer_amd", "csrc", "ctx.hip")
+    for extra in (["-DPBR_NO_RCCL_HEADER"], []):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "--offload-arch=gfx950", "--cuda-host-only", "-fsyntax-only", "-Wall",
+                            "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")] + extra + [src],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]

@@ -63,7 +63,7 @@ if args and args[0] in ("low", "strided", "per_xcd"):
 counts = [int(v) for v in args] or [0, 16, 24, 32, 40, 48, 64]
 ref = None
 for side in counts:
-    ctx.partition_cus(side, layout=layout)
+    ctx.partition_cus(side, layout=layout, allow_uneven=True)   # this tool measures the uneven shares too
     a, b = make(False), make(True)
     sa, sb = signature(a), signature(b)
     ref = ref or sa
