@@ -109,15 +109,6 @@ pbr_status pbr_ctx_create(int hip_device, pbr_ctx** out) {
         return PBR_ERR_NOMEM;
     }
     c->scratch_bytes = pbr::SCRATCH_BYTES;
-    const size_t q_bytes = (size_t)pbr::SHADE_Q_SLOTS * pbr::SHADE_Q_DWORDS * sizeof(uint32_t);
-    if (hipMalloc((void**)&c->shade_q, q_bytes) != hipSuccess || hipMemset(c->shade_q, 0, q_bytes) != hipSuccess ||
-        hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, hip_device) != hipSuccess || c->cu_count < 1) {
-        if (c->shade_q) (void)hipFree(c->shade_q);
-        (void)hipFree(c->scratch);
-        (void)hipStreamDestroy(c->own_stream);
-        delete c;
-        return PBR_ERR_NOMEM;
-    }
     *out = c;
     return PBR_OK;
 }
@@ -133,7 +124,6 @@ void pbr_ctx_destroy(pbr_ctx* ctx) {
     if (ctx->ev_side_fork) (void)hipEventDestroy(ctx->ev_side_fork);
     if (ctx->ev_side_join) (void)hipEventDestroy(ctx->ev_side_join);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->shade_q) (void)hipFree(ctx->shade_q);
     if (ctx->pf_dev) (void)hipFree(ctx->pf_dev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

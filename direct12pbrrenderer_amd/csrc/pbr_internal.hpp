@@ -32,11 +32,6 @@ struct pbr_ctx {
     bool on_side = false, side_pending = false, main_was_null = false;
     std::vector<uint32_t> side_cu_mask;   // pbr_ctx_set_cu_masks: the side stream's CUs (empty: all, high priority)
     bool bloom_shader_order = false;      // pbr_ctx_set_bloom_shader_order: large 2x-up bloom levels in the shader's operation order (bit-exact)
-    // k_deferred_shade's work queues (shade.hip): one slot per stream the context has launched a shade on — launches of one stream
-    // are ordered, so they share a slot (the last block of a launch leaves it zeroed); concurrent launches sit on different streams
-    uint32_t* shade_q = nullptr;          // SHADE_Q_SLOTS x SHADE_Q_DWORDS, zeroed at creation
-    std::vector<hipStream_t> shade_q_streams;
-    int cu_count = 0;                     // compute units of the device (grid of the persistent shade)
 };
 
 namespace pbr {
@@ -59,8 +54,6 @@ inline pbr_status launched(pbr_ctx* ctx, const char* where) {
 }
 
 constexpr size_t SCRATCH_BYTES = 1u << 20;
-// shade work queue: 8 head words (one per XCD shard) + the retired-block count, each on a 128-byte line of its own
-constexpr int SHADE_Q_SHARDS = 8, SHADE_Q_STRIDE = 32, SHADE_Q_DWORDS = (SHADE_Q_SHARDS + 1) * SHADE_Q_STRIDE, SHADE_Q_SLOTS = 64;
 
 // Tuning / A-B switches of the launch code.  The PRODUCT library takes every one at its built-in value and never reads the
 // environment: a drop-in must not change its kernel choice on an environment variable.  A build with -DPBR_DEBUG_KNOBS

@@ -116,21 +116,19 @@ __global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ sr
 // moves; the plane stride is a compile-time constant so the plane offset rides in the DS offset field.
 constexpr int LIGHT_PLANES = 9;
 
-// Which pixels of the tile a launch shades: up to SHADE_MAX_RECTS rectangles (tile-local) — a whole tile is one
-// rectangle; the overlapped multi-GPU frame shades the tile's border ring (<= 4 rectangles) in one launch and its core
-// in another.  A rectangle is cut into WORK ITEMS of 256 columns x rows_big rows (its first nb_big item rows) or
-// x rows_small rows (the rest: short items, handed out last, fill the tail of the launch).
+// Which pixels of the tile a launch shades: up to SHADE_MAX_RECTS rectangles (tile-local), walked by ONE 1-D grid — a
+// whole tile is one rectangle; the overlapped multi-GPU frame shades the tile's border ring (<= 4 rectangles) in one
+// launch and its core in another.  Per rectangle the schedule described at the kernel applies.
 constexpr int SHADE_MAX_RECTS = 5;
 struct ShadeRects {
-    uint32_t n, rows_big, rows_small;
+    uint32_t n, parts, rows_small;   // parts: 1, 2 or 4 — the pieces a long block's SHADE_ROWS rows come in
     uint32_t x0[SHADE_MAX_RECTS], y0[SHADE_MAX_RECTS], w[SHADE_MAX_RECTS], h[SHADE_MAX_RECTS];
-    uint32_t cols[SHADE_MAX_RECTS], nb_big[SHADE_MAX_RECTS], first[SHADE_MAX_RECTS + 1];   // first item of rect r; [n] = total
-    uint32_t cols_magic[SHADE_MAX_RECTS];   // ceil(2^32 / cols): item / cols = mulhi(item, magic) for item < 2^32 / cols (host-checked); cols = 1: unused
+    uint32_t cols[SHADE_MAX_RECTS], nb_big[SHADE_MAX_RECTS], first[SHADE_MAX_RECTS + 1];   // first block of rect r; [n] = total
 };
 
 constexpr int SHADE_BLOCK = 256;
-constexpr int SHADE_ROWS = 8;          // most rows of 256 pixels one work item may hold
-constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per item
+constexpr int SHADE_ROWS = 8;          // rows of 256 pixels a long block walks after staging the light table once (12: no change, 16: +3 %, round 5)
+constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per piece
 // staged list: count, pad, 32 entries
 constexpr int LIST_STRIDE = 34;         // dwords per staged cluster list: count, pad, 32 entries (8-byte aligned pairs)
 
@@ -500,68 +498,35 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
 }
 
 // ------------------------------------------------------------------------------------------------
-// Launch schedule.  Blocks are PERSISTENT: the grid is what the device holds at once (compute units x resident blocks),
-// a block stages the 9-plane light table ONCE and then pulls work items — 256 columns x 1..8 rows — from a queue until it is
-// dry.  One schedule for every render-target size: a 1080p frame (1.3 Mpixel per 1 280 resident blocks) is cut into
-// one-row items and keeps every compute unit busy to the end, where a static grid of 256 x 8-pixel blocks was 0.84 of ONE
-// generation; an 8K frame takes 8-row items.  Per-pixel arithmetic does not depend on the schedule: the output is the same
-// to the bit whichever block shades a pixel.
-//
-// Queue (pbr_ctx::shade_q, one slot per stream): 8 head words on 128-byte lines of their own + a retired-block count.
-// Item i belongs to shard i % 8 and is the (i / 8)-th pull of that shard's head; a block pulls from shard blockIdx % 8 (the
-// dispatcher deals consecutive blocks to consecutive XCDs) with ONE returning agent-scope atomic add, issued a whole item ahead
-// of its use (one head word saturates at ~90 pulls per microsecond: MI355X_MICROARCH.md, "dequeue"; a 1080p single-light launch
-// wants ~150).  A block whose shard has run dry reads the other seven heads (seven loads in flight together) and pulls from
-// the first one with items left; when none has, it retires.  The block that retires last zeroes the slot for the next launch
-// of the stream — every other block has consumed the result of every atomic it issued before it counted itself out.
-constexpr uint32_t SHADE_NO_ITEM = 0xFFFFFFFFu;
-__device__ __forceinline__ uint32_t q_pull(uint32_t* q, uint32_t shard) {
-    return __hip_atomic_fetch_add(q + shard * pbr::SHADE_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// the shard of `shard` is dry: an item of another shard (and that shard in `shard`), or SHADE_NO_ITEM
-__device__ __noinline__ uint32_t q_steal(uint32_t* q, uint32_t& shard, uint32_t total) {
-    for (;;) {   // ends: heads only grow, and a round that finds no head below its limit returns
-        uint32_t h[pbr::SHADE_Q_SHARDS];
-#pragma unroll
-        for (int j = 1; j < pbr::SHADE_Q_SHARDS; j++)
-            h[j] = __hip_atomic_load(q + ((shard + j) & 7u) * pbr::SHADE_Q_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int pick = 0;
-#pragma unroll
-        for (int j = pbr::SHADE_Q_SHARDS - 1; j >= 1; j--)
-            if ((uint64_t)h[j] * pbr::SHADE_Q_SHARDS + ((shard + j) & 7u) < total) pick = j;
-        if (pick == 0) return SHADE_NO_ITEM;
-        const uint32_t v = (shard + pick) & 7u;
-        const uint64_t it = (uint64_t)q_pull(q, v) * pbr::SHADE_Q_SHARDS + v;
-        if (it < total) { shard = v; return (uint32_t)it; }
-    }
-}
-
-#ifdef PBR_SHADE_TIMING   // experiment build only (tools/shade_timeline.py): 100 MHz wall-clock stamps of every block and item
-__device__ unsigned long long g_shade_block_stamp[4 * 8192];     // per block: start, light table staged, end, (items << 32 | XCC id)
-__device__ unsigned long long g_shade_item_stamp[4 * 160000];    // per item: start, lists staged, end, (rows << 48 | block)
+// Launch schedule.  grid = blocks, dispatched in index order by the hardware (a work queue of its own: a software queue of
+// persistent blocks was built and measured in round 6 — EXPERIMENTS.md — and lost to it at every size).  Per rectangle:
+//  * the first nb_big block rows are LONG blocks of SHADE_ROWS rows, the rest SHORT blocks of rows_small rows, dispatched last:
+//    they fill the tail of the launch (a 4K frame is only ~3.2 generations of resident blocks);
+//  * a long block's rows come in `parts` pieces from DIFFERENT places of the rectangle: piece j is SHADE_ROWS / parts rows of the
+//    j-th horizontal band of the long zone, in a column block shifted by j / parts of the width.  The cost of a pixel row is its
+//    cluster lists' length, which varies across the frame by 2.7x (a block's time: 67 us mean, 119 us at the 99th percentile at
+//    1080p / 256 lights, profiles/r06_a_timeline_*): a block made of the frame's edge AND its centre costs about the average,
+//    where a launch of about one generation (1080p: 0.84) otherwise waits for the blocks of the densest region.  The price is a
+//    re-staging of the cluster lists (not of the light table) per piece.
+// Per-pixel arithmetic does not depend on the schedule: the output is the same to the bit whichever block shades a pixel.
+#ifdef PBR_SHADE_TIMING   // experiment build only (tools/shade_timeline.py): 100 MHz wall-clock stamps of every block
+__device__ unsigned long long g_shade_item_stamp[4 * 160000];    // per block: start, first piece staged, end, (rows << 48 | block)
 extern "C" int pbr_debug_shade_stamps(unsigned long long* blocks, int n_blocks, unsigned long long* items, int n_items) {
-    int e = (int)hipMemcpyFromSymbol(blocks, HIP_SYMBOL(g_shade_block_stamp), sizeof(unsigned long long) * 4 * n_blocks);
-    if (e == 0 && n_items > 0) e = (int)hipMemcpyFromSymbol(items, HIP_SYMBOL(g_shade_item_stamp), sizeof(unsigned long long) * 4 * n_items);
-    return e;
+    (void)blocks; (void)n_blocks;
+    return (int)hipMemcpyFromSymbol(items, HIP_SYMBOL(g_shade_item_stamp), sizeof(unsigned long long) * 4 * n_items);
 }
 extern "C" int pbr_debug_shade_stamps_reset() {
-    void *b = nullptr, *i = nullptr;
-    int e = (int)hipGetSymbolAddress(&b, HIP_SYMBOL(g_shade_block_stamp));
-    if (e == 0) e = (int)hipGetSymbolAddress(&i, HIP_SYMBOL(g_shade_item_stamp));
-    if (e == 0) e = (int)hipMemset(b, 0, sizeof(g_shade_block_stamp));
+    void* i = nullptr;
+    int e = (int)hipGetSymbolAddress(&i, HIP_SYMBOL(g_shade_item_stamp));
     if (e == 0) e = (int)hipMemset(i, 0, sizeof(g_shade_item_stamp));
     return e;
 }
-#define SHADE_BSTAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_shade_block_stamp[blockIdx.x * 4 + (i)] = (v); } while (0)
 #define SHADE_ISTAMP(it, i, v) do { if (threadIdx.x == 0 && (it) < 160000u) g_shade_item_stamp[(it) * 4 + (i)] = (v); } while (0)
-// end stamps: the LAST wave of the block to get there (the arrays are zeroed before the launch)
-#define SHADE_BSTAMP_MAX(i, v) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) atomicMax(&g_shade_block_stamp[blockIdx.x * 4 + (i)], (v)); } while (0)
+// end stamp: the LAST wave of the block to get there (the array is zeroed before the launch)
 #define SHADE_ISTAMP_MAX(it, i, v) do { if ((threadIdx.x & 63) == 0 && (it) < 160000u) atomicMax(&g_shade_item_stamp[(it) * 4 + (i)], (v)); } while (0)
 #define SHADE_NOW() wall_clock64()
 #else
-#define SHADE_BSTAMP(i, v) do {} while (0)
 #define SHADE_ISTAMP(it, i, v) do {} while (0)
-#define SHADE_BSTAMP_MAX(i, v) do {} while (0)
 #define SHADE_ISTAMP_MAX(it, i, v) do {} while (0)
 #define SHADE_NOW() 0ull
 #endif
@@ -591,116 +556,40 @@ __device__ __forceinline__ void stage_lights(const ShadeParams& p, float* llds, 
     }
 }
 
-// one work item's pixel rectangle, tile-local: columns [bx0, x_end) of rows [y_begin, y_end)
+// one piece of a block's pixels, tile-local: columns [bx0, x_end) of rows [y_begin, y_end)
 struct ShadeItem { uint32_t bx0, x_end, y_begin, y_end; };
-__device__ __forceinline__ ShadeItem item_rect(const ShadeRects& rc, uint32_t item) {
-    uint32_t r = 0;   // item -> rectangle -> (column block, item row); wave-uniform scalar arithmetic
-    while (r + 1 < rc.n && item >= rc.first[r + 1]) r++;
-    const uint32_t lb = item - rc.first[r];
-    const uint32_t by = rc.cols[r] == 1 ? lb : __umulhi(lb, rc.cols_magic[r]), nb_big = rc.nb_big[r];
-    ShadeItem it;
-    it.bx0 = rc.x0[r] + (lb - by * rc.cols[r]) * SHADE_BLOCK;
-    it.x_end = rc.x0[r] + rc.w[r];
-    it.y_begin = rc.y0[r] + (by < nb_big ? by * rc.rows_big : nb_big * rc.rows_big + (by - nb_big) * rc.rows_small);
-    it.y_end = min(it.y_begin + (by < nb_big ? rc.rows_big : rc.rows_small), rc.y0[r] + rc.h[r]);
-    return it;
-}
 
-// The cluster (x,y) tiles an item's pixels can fall into — same arithmetic as the per-pixel ClusterIndex (floor(u*24),
-// floor((1-v)*16)); monotone in the pixel coordinate, so the corners bound it.  n_cl = clusters to stage (8 z-slices per tile).
-struct ItemTiles { int tile_x0, tile_y0, tiles_x, n_cl; };
-__device__ __forceinline__ ItemTiles item_tiles(const ShadeParams& p, const ShadeItem& it, int max_clusters) {
+// The light lists of the clusters a piece's pixels can fall into, as LDS byte addresses of the lights (one dword each) — same
+// arithmetic as the per-pixel ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners
+// bound it.  A thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry
+// (round 5: ~170 instructions per thread and block less than the entry-major loop it replaces; shade in frame -0.4 %).
+__device__ __forceinline__ void stage_lists(const ShadeParams& p, const ShadeItem& it, uint32_t* lists, uint32_t lds_base, int n_lights, int max_clusters,
+                                            int& tile_x0, int& tile_y0, int& tiles_x) {
+    static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
     const uint32_t bx1 = min(it.bx0 + SHADE_BLOCK, it.x_end) - 1;
     auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
     auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
-    ItemTiles tl;
-    tl.tile_x0 = tx(it.bx0);
+    tile_x0 = tx(it.bx0);
     const int tile_x1 = tx(bx1);
-    const int ty_a = ty(it.y_begin), ty_b = it.y_end - it.y_begin > 1 ? ty(it.y_end - 1) : ty_a;
-    tl.tile_y0 = min(ty_a, ty_b);
-    tl.tiles_x = tile_x1 - tl.tile_x0 + 1;
-    tl.n_cl = min(tl.tiles_x * (max(ty_a, ty_b) - tl.tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
-    return tl;
-}
-// staged cluster c of an item -> its record: c = (tile row * tiles_x + tile column) * 8 + z
-__device__ __forceinline__ const pbr_cluster* staged_cluster(const ShadeParams& p, const ItemTiles& tl, int c) {
-    const int z = c & 7, t = c >> 3;
-    // t / tiles_x, both <= MAX_STAGED_TILES: (t + 1/2) / tiles_x is never within 0.04 of an integer, so the approximate reciprocal is exact enough
-    const int ty_ = (int)(((float)t + 0.5f) * rcp((float)tl.tiles_x));
-    const int cx = tl.tile_x0 + (t - ty_ * tl.tiles_x), cy = tl.tile_y0 + ty_;
-    return p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
-}
-// one staged list entry: the LDS byte address of light `raw_index` (the null light from entry `cn` on)
-__device__ __forceinline__ uint32_t list_entry(int j, int cn, int raw_index, int n_lights, uint32_t lds_base) {
-    const int li = j < cn ? min(max(raw_index, 0), n_lights - 1) : n_lights;   // never index past the staged table
-    return lds_base + 4u * (uint32_t)li;
-}
-
-// ---- LDS-DMA: global -> LDS without a register in between (global_load_lds_*; M0 = the wave's LDS destination, lane l lands at
-// M0 + l * size; inactive lanes are skipped).  The statements follow cdna_hip_programming.md's recipe (M0 saved and restored inside
-// the statement that uses it).  hipcc does not count these loads: their data needs dma_wait() by the ISSUING wave, then a barrier,
-// before anyone reads it.  (tools/debug/dma_probe.hip: 4-byte-aligned 16-byte sources are fine.)
-__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// threadIdx.x as a value the compiler must rebuild here: nothing derived from it is hoisted out of the item loop into registers
-// that then live (spilled) across the pixel code
-__device__ __forceinline__ uint32_t tid_here() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
-
-constexpr int FETCH_ROUNDS = MAX_STAGED_TILES * PBR_CLUSTER_Z / (SHADE_BLOCK / 8);   // 3: a round = 32 clusters, 8 lanes x 16 bytes per cluster
-static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32 && FETCH_ROUNDS * (SHADE_BLOCK / 8) == MAX_STAGED_TILES * PBR_CLUSTER_Z, "staging map");
-// [A] the raw index lists (128 bytes each, record offset 28) and counts of an item's clusters -> raw[c][32], cnt[c]: asynchronous.
-// n_cl is a multiple of 8 and a wave covers 8 clusters per round: the `c < n_cl` branches are wave-uniform.
-__device__ __forceinline__ void lists_fetch(const ShadeParams& p, const ItemTiles& tl, uint32_t raw_b, uint32_t cnt_b, uint32_t tid) {
-    const uint32_t w = tid >> 6;
-#pragma unroll
-    for (int r = 0; r < FETCH_ROUNDS; r++) {
-        const int c = (int)(tid >> 3) + r * (SHADE_BLOCK / 8);
-        if (c < tl.n_cl)
-            dma16(reinterpret_cast<const char*>(staged_cluster(p, tl, c)->LightIndex) + 16u * (tid & 7u),
-                  __builtin_amdgcn_readfirstlane(raw_b + ((uint32_t)r * (SHADE_BLOCK / 8) + 8u * w) * 128u));
-    }
-    if ((int)tid < tl.n_cl) dma4(&staged_cluster(p, tl, (int)tid)->NumLights, __builtin_amdgcn_readfirstlane(cnt_b + w * 256u));
-}
-// [B] raw -> the walk's format (count padded to even, entries = LDS addresses of lights): LDS to LDS, 4 entries per thread and round
-__device__ __forceinline__ void lists_finish(int n_cl, const uint32_t* raw, const uint32_t* cnt, uint32_t* lists, uint32_t lds_base, int n_lights, uint32_t tid) {
-#pragma unroll
-    for (int r = 0; r < FETCH_ROUNDS; r++) {
-        const int c = (int)(tid >> 3) + r * (SHADE_BLOCK / 8);
-        if (c < n_cl) {
-            const int part = tid & 7;
-            const uint4 v = reinterpret_cast<const uint4*>(raw)[tid + r * SHADE_BLOCK];
-            const int cn = n_lights > 0 ? min(max((int)cnt[c], 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-            uint32_t* l = lists + c * LIST_STRIDE;
-            uint2* e = reinterpret_cast<uint2*>(l + 2 + 4 * part);   // 136 c + 8 + 16 part bytes: 8-byte aligned
-            e[0] = make_uint2(list_entry(4 * part + 0, cn, (int)v.x, n_lights, lds_base), list_entry(4 * part + 1, cn, (int)v.y, n_lights, lds_base));
-            e[1] = make_uint2(list_entry(4 * part + 2, cn, (int)v.z, n_lights, lds_base), list_entry(4 * part + 3, cn, (int)v.w, n_lights, lds_base));
-            if (part == 0) *reinterpret_cast<uint2*>(l) = make_uint2((uint32_t)max((cn + 1) & ~1, 2), 0u);
-        }
-    }
-}
-
-#ifdef PBR_DEBUG_KNOBS
-// the static-grid kernel's staging (knobs build): a thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k, plain loads
-__device__ __forceinline__ void stage_lists(const ShadeParams& p, const ItemTiles& tl, uint32_t* lists, uint32_t lds_base, int n_lights) {
+    const int ty_a = ty(it.y_begin), ty_b = ty(it.y_end - 1);
+    tile_y0 = min(ty_a, ty_b);
+    const int tile_y1 = max(ty_a, ty_b);
+    tiles_x = tile_x1 - tile_x0 + 1;
+    const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
     const int j = threadIdx.x & 31;
-    for (int c = threadIdx.x >> 5; c < tl.n_cl; c += SHADE_BLOCK / 32) {
-        const pbr_cluster* cl = staged_cluster(p, tl, c);
-        const int cn = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
+    for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
+        const int z = c & 7, t = c >> 3;
+        const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
+        const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+        const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
         uint32_t* l = lists + c * LIST_STRIDE;
-        l[2 + j] = list_entry(j, cn, cl->LightIndex[j], n_lights, lds_base);
-        if (j < 2) l[j] = j == 0 ? (uint32_t)max((cn + 1) & ~1, 2) : 0u;
+        const int li = j < cnt ? min(max(cl->LightIndex[j], 0), n_lights - 1) : n_lights;   // never index past the staged table
+        l[2 + j] = lds_base + 4u * (uint32_t)li;
+        if (j < 2) l[j] = j == 0 ? (uint32_t)max((cnt + 1) & ~1, 2) : 0u;
     }
 }
-#endif
 
-// per-row terms of an item's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
+// per-row terms of a piece's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
 __device__ __forceinline__ float4 row_terms(const ShadeParams& p, uint32_t y) {
     const float v = ((float)(p.y0 + y) + 0.5f) / (float)p.full_h;
     const float ndc_y = 1.0f - 2.0f * v;
@@ -711,164 +600,66 @@ __device__ __forceinline__ float4 row_terms(const ShadeParams& p, uint32_t y) {
 #define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
 #endif
 
-// grid = min(items, compute units x resident blocks), block 256.  Item b is block b's first; the queue hands out the rest.
-// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) per staged cluster 136 B of list, 128 B of raw
-// indices and a raw count.  While a block shades item k, the lists of item k + 1 arrive in `raw` by LDS-DMA (no register, no
-// wait); between items: barrier (every wave done with k, every wave's DMA landed), raw -> lists (LDS to LDS), barrier.
-// The item after next is pulled by whichever wave of the block finishes its part of item k FIRST — it would otherwise wait at
-// the barrier for the slower ones, so the atomic's round trip (1 - 3 us) costs nothing unless all four waves arrive together.
-// Nothing of the schedule lives in a vector register across the pixel code (the puller's state is in LDS, block-uniform values
-// are scalar, thread-index-derived values are rebuilt per phase: the pixel code has no register to spare, and what hipcc spills
-// it reloads with a full vmcnt(0) wait each).
+// grid = rc.first[rc.n] blocks of 256 threads.
+// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 136 B of light lists.
 template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc, uint32_t* q) {
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
     extern __shared__ float4 lds_raw[];
     __shared__ uint32_t s_mip_off[16];
-    __shared__ uint32_t s_item;              // the item after next
-    __shared__ uint32_t s_arrive;            // waves that have finished the current item
-    __shared__ uint32_t s_shard, s_live;     // the puller's state: the shard the block pulls from; 0 once every shard has run dry
-    __shared__ int4 s_desc[2][2];            // an item's {bx0, x_end, y_begin, y_end}, {tile_x0, tile_y0, tiles_x, n_cl}; [k & 1]
     __shared__ float4 s_row[SHADE_ROWS];
-    __shared__ ShadeRects s_rc;              // the item table is read once per item: from LDS, not from 42 scalar registers held across the pixel code
     const unsigned long long t_start = SHADE_NOW();
     (void)t_start;
-    float* llds = reinterpret_cast<float*>(lds_raw);
-    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 3) & ~3));   // 16-byte aligned
-    uint32_t* raw = lists + max_clusters * LIST_STRIDE;                                           // max_clusters is a multiple of 8: 16-byte aligned
-    uint32_t* cntraw = raw + max_clusters * PBR_MAX_LIGHTS_PER_CLUSTER;
-    const uint32_t raw_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)raw;
-    const uint32_t cnt_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)cntraw;
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;   // < 64 KiB: the whole light table (<= 9 x 1025 floats) stays addressable in 16 bits
-    const uint32_t total_q = rc.first[rc.n] - gridDim.x;   // items the queue hands out: gridDim.x + (pull * 8 + shard)
-    // one synchronous pull (called by ONE lane): the next item, or SHADE_NO_ITEM for good
-    auto take = [&]() -> uint32_t {
-        if (!s_live) return SHADE_NO_ITEM;
-        uint32_t shard = s_shard;
-        const uint64_t nx = (uint64_t)q_pull(q, shard) * pbr::SHADE_Q_SHARDS + shard;
-        const uint32_t it = nx < total_q ? (uint32_t)nx : q_steal(q, shard, total_q);
-        if (it == SHADE_NO_ITEM) { s_live = 0; return it; }
-        s_shard = shard;
-        return it + gridDim.x;
-    };
     if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
-    if (threadIdx.x < sizeof(ShadeRects) / 4) reinterpret_cast<uint32_t*>(&s_rc)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&rc)[threadIdx.x];
-    // the block's first item: its lists' DMA and the light table's loads travel together
-    {
-        const ShadeItem it = item_rect(rc, blockIdx.x);
-        const ItemTiles tl = item_tiles(p, it, max_clusters);
-        if (threadIdx.x == 0) {
-            s_desc[0][0] = make_int4((int)it.bx0, (int)it.x_end, (int)it.y_begin, (int)it.y_end);
-            s_desc[0][1] = make_int4(tl.tile_x0, tl.tile_y0, tl.tiles_x, tl.n_cl);
-            s_arrive = 0;
-        }
-        if (STAGED_LISTS) lists_fetch(p, tl, raw_b, cnt_b, threadIdx.x);
-        if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
-    }
+    float* llds = reinterpret_cast<float*>(lds_raw);
+    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));   // 8-byte aligned
     int my_safe = 1, my_same = 1;
     stage_lights<LSTRIDE>(p, llds, n_lights, my_safe, my_same);
-    if (threadIdx.x == SHADE_BLOCK - 1) {   // (a lane of the last wave: the first three have a light each to convert meanwhile)
-        s_shard = blockIdx.x & 7u;
-        s_live = 1;
-        s_item = take();
+    // block -> rectangle -> (column block, block row) -> its pieces {bx0, x_end, y_begin, y_end}, written to LDS by one lane each: nothing
+    // of the schedule stays in registers across the pixel code but the piece counter (the pixel code has no register to spare)
+    __shared__ int4 s_piece[4];
+    __shared__ uint32_t s_parts;
+    if (threadIdx.x < 4) {
+        uint32_t r = 0;
+        while (r + 1 < rc.n && blockIdx.x >= rc.first[r + 1]) r++;
+        const uint32_t lb = blockIdx.x - rc.first[r];
+        const uint32_t cols = rc.cols[r], by = lb / cols, cx = lb - by * cols, nb_big = rc.nb_big[r];
+        const bool big = by < nb_big;
+        const uint32_t parts = big ? rc.parts : 1u, rows = big ? (uint32_t)SHADE_ROWS / rc.parts : rc.rows_small, j = threadIdx.x;
+        // piece j of a long block: row (by + j nb_big) of the long zone cut into pieces of `rows` rows, column block shifted by j / parts of the width
+        const uint32_t pc = big ? cx + (j * cols) / parts : cx;
+        const uint32_t y_begin = rc.y0[r] + (big ? (by + j * nb_big) * rows : nb_big * SHADE_ROWS + (by - nb_big) * rows);
+        s_piece[j] = make_int4((int)(rc.x0[r] + (pc >= cols ? pc - cols : pc) * SHADE_BLOCK), (int)(rc.x0[r] + rc.w[r]), (int)y_begin, (int)min(y_begin + rows, rc.y0[r] + rc.h[r]));
+        if (j == 0) s_parts = parts;
     }
-    dma_wait();
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;   // < 64 KiB: the whole light table (<= 9 x 1025 floats) stays addressable in 16 bits
     // bit 0: the attenuation floor cannot bind; bit 1: every staged light has the SAME attenuation polynomial (one radius for the
     // whole scene is common), so its three coefficients are per-kernel constants and a trip reads 13 LDS dwords instead of 19
     const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
-    uint32_t cur = blockIdx.x, nxt = __builtin_amdgcn_readfirstlane(s_item);
-    (void)cur;
-    if (STAGED_LISTS) lists_finish(s_desc[0][1].w, raw, cntraw, lists, lds_base, n_lights, threadIdx.x);
-    __syncthreads();
-    SHADE_BSTAMP(0, t_start);
-    SHADE_BSTAMP(1, SHADE_NOW());
-    uint32_t n_done = 0;
-    (void)n_done;
-    for (uint32_t par = 0;; par ^= 1u) {
-        SHADE_ISTAMP(cur, 0, SHADE_NOW());
-        // [A] the next item's lists set out
-        if (nxt != SHADE_NO_ITEM) {
-            const uint32_t tid = tid_here();
-            const ShadeItem nit = item_rect(s_rc, nxt);
-            const ItemTiles ntl = item_tiles(p, nit, max_clusters);
-            if (tid == 0) {
-                s_desc[par ^ 1u][0] = make_int4((int)nit.bx0, (int)nit.x_end, (int)nit.y_begin, (int)nit.y_end);
-                s_desc[par ^ 1u][1] = make_int4(ntl.tile_x0, ntl.tile_y0, ntl.tiles_x, ntl.n_cl);
-            }
-            if (STAGED_LISTS) lists_fetch(p, ntl, raw_b, cnt_b, tid);
-        }
-        SHADE_ISTAMP(cur, 1, SHADE_NOW());
-        // this item (block-uniform values in scalar registers)
+    const uint32_t parts = __builtin_amdgcn_readfirstlane(s_parts);
+    uint32_t rows_done = 0;
+    (void)rows_done;
+    for (uint32_t j = 0; j < parts; j++) {
+        ShadeItem it;
         {
-            const int4 d0 = s_desc[par][0], d1 = s_desc[par][1];
-            const uint32_t bx0 = __builtin_amdgcn_readfirstlane(d0.x), x_end = __builtin_amdgcn_readfirstlane(d0.y);
-            const uint32_t y_begin = __builtin_amdgcn_readfirstlane(d0.z), y_end = __builtin_amdgcn_readfirstlane(d0.w);
-            const int tile_x0 = __builtin_amdgcn_readfirstlane(d1.x), tile_y0 = __builtin_amdgcn_readfirstlane(d1.y), tiles_x = __builtin_amdgcn_readfirstlane(d1.z);
-            const uint32_t px = bx0 + tid_here();
-            if (px < x_end)
-                for (uint32_t py = y_begin; py < y_end; py++)
-                    shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin]);
-            SHADE_ISTAMP_MAX(cur, 2, SHADE_NOW());
-            SHADE_ISTAMP(cur, 3, ((unsigned long long)(y_end - y_begin) << 48) | blockIdx.x);
+            const int4 d = s_piece[j];
+            it.bx0 = __builtin_amdgcn_readfirstlane(d.x); it.x_end = __builtin_amdgcn_readfirstlane(d.y);
+            it.y_begin = __builtin_amdgcn_readfirstlane(d.z); it.y_end = __builtin_amdgcn_readfirstlane(d.w);
         }
-        n_done++;
-        if (nxt == SHADE_NO_ITEM) break;
-        // [B] between items.  The first wave to get here pulls the item after next.
-        if (__lane_id() == 0 && atomicAdd(&s_arrive, 1u) == 0) s_item = take();
-        dma_wait();
-        __syncthreads();                         // every wave is done with `lists` and `s_row`; every wave's DMA has landed; s_item is written
-        {
-            const uint32_t tid = tid_here();
-            const int4 n0 = s_desc[par ^ 1u][0], n1 = s_desc[par ^ 1u][1];
-            if (STAGED_LISTS) lists_finish(n1.w, raw, cntraw, lists, lds_base, n_lights, tid);
-            if (tid < (uint32_t)SHADE_ROWS) s_row[tid] = row_terms(p, (uint32_t)n0.z + tid);
-            if (tid == 0) s_arrive = 0;
-        }
-        cur = nxt;
-        nxt = __builtin_amdgcn_readfirstlane(s_item);
+        if (j) __syncthreads();   // every wave is done with the previous piece's lists and row terms
+        int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
+        if (STAGED_LISTS) stage_lists(p, it, lists, lds_base, n_lights, max_clusters, tile_x0, tile_y0, tiles_x);
+        if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
         __syncthreads();
+        if (j == 0) { SHADE_ISTAMP(blockIdx.x, 0, t_start); SHADE_ISTAMP(blockIdx.x, 1, SHADE_NOW()); }
+        const uint32_t px = it.bx0 + threadIdx.x;
+        if (px < it.x_end)
+            for (uint32_t py = it.y_begin; py < it.y_end; py++)
+                shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - it.y_begin]);
+        rows_done += it.y_end - it.y_begin;
     }
-    if (threadIdx.x == 0) {   // (no pull of this block is in flight: every one was waited for where it was made)
-        uint32_t* done = q + pbr::SHADE_Q_SHARDS * pbr::SHADE_Q_STRIDE;
-        if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            for (int x = 0; x <= pbr::SHADE_Q_SHARDS; x++) __hip_atomic_store(q + x * pbr::SHADE_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    SHADE_BSTAMP_MAX(2, SHADE_NOW());
-    SHADE_BSTAMP(3, ((unsigned long long)n_done << 32) | (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u));   // hwreg(HW_REG_XCC_ID, 0, 4)
-}
-
-#ifdef PBR_DEBUG_KNOBS
-// The static schedule this kernel had through round 5, kept in the knobs build for A/B (PBR_SHADE_SCHED=grid): one block per work
-// item, dispatched in item order — grid = items, every block stages the light table and its lists for itself.
-template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade_grid(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
-    extern __shared__ float4 lds_raw[];
-    __shared__ uint32_t s_mip_off[16];
-    __shared__ float4 s_row[SHADE_ROWS];
-    const unsigned long long t_start = SHADE_NOW();
-    (void)t_start;
-    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
-    float* llds = reinterpret_cast<float*>(lds_raw);
-    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 3) & ~3));
-    int my_safe = 1, my_same = 1;
-    stage_lights<LSTRIDE>(p, llds, n_lights, my_safe, my_same);
-    const ShadeItem it = item_rect(rc, blockIdx.x);
-    const ItemTiles tl = item_tiles(p, it, max_clusters);
-    const int tile_x0 = tl.tile_x0, tile_y0 = tl.tile_y0, tiles_x = tl.tiles_x;
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;
-    if (STAGED_LISTS) stage_lists(p, tl, lists, lds_base, n_lights);
-    if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
-    const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
-    SHADE_ISTAMP(blockIdx.x, 0, t_start);
-    SHADE_ISTAMP(blockIdx.x, 1, SHADE_NOW());
-    const uint32_t px = it.bx0 + threadIdx.x;
-    if (px < it.x_end)
-        for (uint32_t py = it.y_begin; py < it.y_end; py++)
-            shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - it.y_begin]);
     SHADE_ISTAMP_MAX(blockIdx.x, 2, SHADE_NOW());
-    SHADE_ISTAMP(blockIdx.x, 3, ((unsigned long long)(it.y_end - it.y_begin) << 48) | blockIdx.x);
+    SHADE_ISTAMP(blockIdx.x, 3, ((unsigned long long)rows_done << 48) | blockIdx.x);
 }
-#endif
 
 extern "C" {
 
@@ -928,104 +719,46 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
     for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)env_padded_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
     p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch; p.hdr_f32 = hdr_f32;
-    // A block's item covers 256 x <= 8 pixels.  It can stage its cluster lists when that rectangle spans at most
-    // MAX_STAGED_TILES cluster tiles: a tile is full_w/24 x full_h/16 pixels, +1 per axis for straddling.
-    const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
-    const uint32_t span_y = (uint32_t)((uint64_t)(SHADE_ROWS - 1) * PBR_CLUSTER_Y / tile->full_h) + 2;
-    const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
-    const size_t plane_bytes = (size_t)((LIGHT_PLANES * lstride + 3) & ~3) * sizeof(float);
-#ifdef PBR_DEBUG_KNOBS
-    static const bool sched_grid = pbr::knob_text("PBR_SHADE_SCHED") && pbr::knob_text("PBR_SHADE_SCHED")[0] == 'g';   // the round-5 static grid, for A/B
-#else
-    constexpr bool sched_grid = false;
-#endif
-    // per staged cluster: its list (136 B) + in the queue kernel the landing area of the next item's raw indices (128 B) and count
-    const size_t cluster_bytes = LIST_STRIDE * sizeof(uint32_t) + (sched_grid ? 0 : (PBR_MAX_LIGHTS_PER_CLUSTER + 1) * sizeof(uint32_t));
-    // staged lists must also fit the 64 KiB a block may ask for (1 024 lights: 36 KiB of planes leave room for 12 tiles)
-    const bool staged = span_x * span_y <= (uint32_t)MAX_STAGED_TILES &&   // (no lights at all: every list is one null pair)
-                        plane_bytes + (size_t)span_x * span_y * PBR_CLUSTER_Z * cluster_bytes <= 65536;
-    const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
-    const size_t lds = plane_bytes + (size_t)max_clusters * cluster_bytes;
-    const bool small_table = lstride == 257;
-    // resident blocks of the device for this instantiation and LDS size (asked once per combination)
-    uint32_t resident = 0;
-    {
-        static uint32_t cache_key[8] = {}, cache_val[8] = {};
-        const uint32_t key = (uint32_t)lds << 3 | (staged ? 4u : 0u) | (small_table ? 2u : 0u) | (F32OUT ? 1u : 0u) | 0x80000000u;
-        for (int i = 0; i < 8 && !resident; i++) if (cache_key[i] == key) resident = cache_val[i];
-        if (!resident) {
-            int per_cu = 0;
-            const void* fn = staged ? (small_table ? (const void*)k_deferred_shade<true, 257, F32OUT> : (const void*)k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>)
-                                    : (small_table ? (const void*)k_deferred_shade<false, 257, F32OUT> : (const void*)k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>);
-            PBR_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SHADE_BLOCK, lds));
-            PBR_REQUIRE(ctx, per_cu >= 1, "pbr_deferred_shade: the kernel does not fit a compute unit");
-            resident = (uint32_t)per_cu * (uint32_t)ctx->cu_count;
-            static uint32_t next_slot = 0;
-            cache_key[next_slot & 7u] = key; cache_val[next_slot & 7u] = resident; next_slot++;
-        }
-    }
-    // Work items (see the kernel): long items first, one-row items for the tail.  rows_big follows the frame: about eight
-    // long items per resident block — 1 row at 1080p, 3 at 4K, 8 at 8K
-    static const float big_frac = pbr::knob_float("PBR_SHADE_BIGFRAC", 0.92f);
+    // schedule (see the kernel): long blocks first — their rows in `parts` pieces from different bands of the rectangle — short ones for the tail
+    static const float big_frac = pbr::knob_float("PBR_SHADE_BIGFRAC", 0.92f);   // re-swept after the per-pixel trims (the knobs build): 0.9-0.95 with 1-row tail blocks beats 0.85 / 2 by ~0.4 %
     static const uint32_t rows_small_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_SMALL", 1);
-    static const uint32_t rows_big_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_BIG", 0);       // 0: by frame size
-    static const uint32_t items_per_block = (uint32_t)pbr::knob_int("PBR_SHADE_ITEMS_PER_BLOCK", 8);
+    static const uint32_t parts_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_PARTS", 2);
     const uint32_t rows_small = rows_small_cfg >= 1 && rows_small_cfg <= (uint32_t)SHADE_ROWS ? rows_small_cfg : 1u;
     const uint32_t whole[1][4] = {{0, 0, tile->w, tile->h}};
     if (!rects) { rects = whole; n_rects = 1; }
     PBR_REQUIRE(ctx, n_rects >= 1 && n_rects <= (uint32_t)SHADE_MAX_RECTS, "pbr_deferred_shade: 1 .. 5 rectangles");
-    uint64_t row_segments = 0;
+    ShadeRects rc{};
+    rc.n = n_rects; rc.rows_small = rows_small;
+    rc.parts = parts_cfg == 4 ? 4u : (parts_cfg == 1 ? 1u : 2u);
+    uint32_t blocks = 0;
     for (uint32_t r = 0; r < n_rects; r++) {
         const uint32_t* q = rects[r];
         PBR_REQUIRE(ctx, q[2] >= 1 && q[3] >= 1 && q[0] + q[2] <= tile->w && q[1] + q[3] <= tile->h, "pbr_deferred_shade: rectangle outside the tile");
-        row_segments += (uint64_t)((q[2] + SHADE_BLOCK - 1) / SHADE_BLOCK) * q[3];
-    }
-    uint32_t rows_big = sched_grid ? (uint32_t)SHADE_ROWS : (uint32_t)(row_segments / ((uint64_t)resident * (items_per_block ? items_per_block : 8u)));
-    if (rows_big_cfg) rows_big = rows_big_cfg;
-    rows_big = rows_big < 1 ? 1u : (rows_big > (uint32_t)SHADE_ROWS ? (uint32_t)SHADE_ROWS : rows_big);
-    ShadeRects rc{};
-    rc.n = n_rects; rc.rows_big = rows_big; rc.rows_small = rows_small < rows_big ? rows_small : rows_big;
-    uint32_t items = 0;
-    for (uint32_t r = 0; r < n_rects; r++) {
-        const uint32_t* q = rects[r];
         rc.x0[r] = q[0]; rc.y0[r] = q[1]; rc.w[r] = q[2]; rc.h[r] = q[3];
         rc.cols[r] = (q[2] + SHADE_BLOCK - 1) / SHADE_BLOCK;
-        rc.cols_magic[r] = rc.cols[r] > 1 ? (uint32_t)(((1ull << 32) + rc.cols[r] - 1) / rc.cols[r]) : 0u;
-        rc.nb_big[r] = (uint32_t)((float)(q[3] / rows_big) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
-        const uint32_t rest = q[3] - rc.nb_big[r] * rows_big;
-        rc.first[r] = items;
-        items += rc.cols[r] * (rc.nb_big[r] + (rest + rc.rows_small - 1) / rc.rows_small);
+        rc.nb_big[r] = (uint32_t)((float)(q[3] / SHADE_ROWS) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
+        const uint32_t rest = q[3] - rc.nb_big[r] * SHADE_ROWS;
+        rc.first[r] = blocks;
+        blocks += rc.cols[r] * (rc.nb_big[r] + (rest + rows_small - 1) / rows_small);
     }
-    rc.first[n_rects] = items;
-    PBR_REQUIRE(ctx, (uint64_t)items * 256u < (1ull << 32), "pbr_deferred_shade: too many work items");   // cols <= 256: item / cols by multiply-high is exact
+    rc.first[n_rects] = blocks;
+    dim3 grid(blocks);
+    // A piece covers 256 x <= 8 pixels.  Its cluster lists can be staged when that rectangle spans at most
+    // MAX_STAGED_TILES cluster tiles: a tile is full_w/24 x full_h/16 pixels, +1 per axis for straddling.
+    const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
+    const uint32_t span_y = (uint32_t)((uint64_t)(SHADE_ROWS - 1) * PBR_CLUSTER_Y / tile->full_h) + 2;
+    const int lstride = num_lights <= 256 ? 257 : PBR_MAX_SCENE_LIGHTS + 1;   // odd strides: no ds_read2 merging of two planes of one light, conflict-free planes
+    const size_t plane_bytes = (size_t)((LIGHT_PLANES * lstride + 1) & ~1) * sizeof(float);
+    // staged lists must also fit the 64 KiB a block may ask for (1 024 lights: 36 KiB of planes leave room for 8 tiles)
+    const bool staged = span_x * span_y <= (uint32_t)MAX_STAGED_TILES &&   // (no lights at all: every list is one null pair)
+                        plane_bytes + (size_t)span_x * span_y * PBR_CLUSTER_Z * LIST_STRIDE * sizeof(uint32_t) <= 65536;
+    const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
+    const size_t lds = plane_bytes + (size_t)max_clusters * LIST_STRIDE * sizeof(uint32_t);
     const dim3 blk(SHADE_BLOCK);
-#ifdef PBR_DEBUG_KNOBS
-    if (sched_grid) {
-        const dim3 grid(items);
-        if (staged && small_table) hipLaunchKernelGGL((k_deferred_shade_grid<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
-        else if (staged) hipLaunchKernelGGL((k_deferred_shade_grid<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
-        else if (small_table) hipLaunchKernelGGL((k_deferred_shade_grid<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
-        else hipLaunchKernelGGL((k_deferred_shade_grid<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
-        return launched(ctx, "k_deferred_shade_grid");
-    }
-#endif
-    // the queue slot of this stream (pbr_internal.hpp)
-    uint32_t slot = 0;
-    while (slot < ctx->shade_q_streams.size() && ctx->shade_q_streams[slot] != ctx->stream) slot++;
-    if (slot == ctx->shade_q_streams.size()) {
-        if (slot == (uint32_t)pbr::SHADE_Q_SLOTS) {   // more streams than slots: start over once nothing is in flight any more
-            PBR_HIP(ctx, hipDeviceSynchronize());
-            ctx->shade_q_streams.clear();
-            slot = 0;
-        }
-        ctx->shade_q_streams.push_back(ctx->stream);
-    }
-    uint32_t* q = ctx->shade_q + (size_t)slot * pbr::SHADE_Q_DWORDS;
-    const dim3 grid(items < resident ? items : resident);
-    if (staged && small_table) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc, q);
-    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc, q);
-    else if (small_table) hipLaunchKernelGGL((k_deferred_shade<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc, q);
-    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc, q);
+    if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
+    else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
+    else if (lstride == 257) hipLaunchKernelGGL((k_deferred_shade<false, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
+    else hipLaunchKernelGGL((k_deferred_shade<false, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, 0, rc);
     return launched(ctx, "k_deferred_shade");
 }
 

@@ -51,7 +51,7 @@ for sz in sizes:
         blocks = np.zeros((NB, 4), dtype=np.uint64)
         items = np.zeros((NI, 4), dtype=np.uint64)
         assert raw.pbr_debug_shade_stamps(blocks.ctypes.data, NB, items.ctypes.data, NI) == 0
-        it = items[items[:, 0] > 0].astype(np.int64)
+        it = items[items[:, 2] > 0].astype(np.int64)
         t0 = it[:, 0].min()
         st, lg, en = (it[:, 0] - t0) * 0.01, (it[:, 1] - t0) * 0.01, (it[:, 2] - t0) * 0.01   # microseconds
         span = en.max()
