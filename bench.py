@@ -62,6 +62,19 @@ CFG5_FRAME = (7680, 4320)       # BASELINE.json configs[4]
 CFG5_GRID = {8: (4, 2)}         # (cols, rows): "tiled 2x4" = 2 rows of 4 tiles; other N: the most square grid
 
 
+DRY = False   # --dry-run: no device call is made anywhere below (bench_dryrun.py)
+
+
+def dev_sync():
+    if not DRY:
+        torch.cuda.synchronize()
+
+
+def dev_empty_cache():
+    if not DRY:
+        torch.cuda.empty_cache()
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -89,6 +102,11 @@ def parse():
     p.add_argument("--no-host-graph", action="store_true", help="skip the C++ pass-graph leg (host_graph block)")
     p.add_argument("--no-shade-paths", action="store_true", help="skip the shade_ms_by_path A/B (N = 1)")
     p.add_argument("--deadline", type=float, default=240.0, help="seconds a collective phase may take before the rank gives up (N > 1)")
+    p.add_argument("--dry-run", action="store_true",
+                   help="N > 1 on a box without N GPUs (or without any): the real rank processes, rendezvous (gloo), tile / halo plans, candidate "
+                        "fall-back, verification frames, timed loops, cfg5 record and JSON assembly with every device call replaced by a host "
+                        "stand-in (bench_dryrun.py) — the orchestration of the 8-GPU launch, rehearsed where 8 processes are allowed.  Not a measurement")
+    p.add_argument("--dry-fail", default=None, help="dry run only: '<rank>:<mode>/<transport>' — that rank's set-up of that candidate raises (fall-back test)")
     return p.parse_args()
 
 
@@ -98,7 +116,9 @@ def spawn_ranks(a):
     box the ranks share cuda:0 in rehearsal mode (gloo + host copies): a functional run, not a measurement."""
     n_dev = torch.cuda.device_count()   # does not initialise the GPU (and, measured, does not count as a holder of the device either)
     env = dict(os.environ)
-    if n_dev < a.gpus:
+    if a.dry_run:
+        pass                            # no rank touches a device
+    elif n_dev < a.gpus:
         if n_dev < 1 or a.gpus > 5:
             # (the GPU pool this was developed on kills a job with more than 6 processes holding one card open — its "process guard" — and
             #  torch.distributed.run's agent is one of them (measured: 6 ranks = 7 holders), so the N = 8 launch itself cannot
@@ -213,7 +233,7 @@ def time_stage(fn, iters, pre=None):
     if pre:
         pre()
     fn()
-    torch.cuda.synchronize()
+    dev_sync()
     total = 0.0
     for _ in range(iters):
         if pre:
@@ -413,10 +433,10 @@ class Job:
         return float(t.item())
 
     def barrier(self):
-        torch.cuda.synchronize()
+        dev_sync()
         if self.dist:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     def make_allreduce(self, kind):
         if self.world == 1:
@@ -452,7 +472,12 @@ def build_frame(job, make_spec, g, lights, mode, transport, overlap):
                     raise RuntimeError(f"halo rectangle {q} of peer {peer} leaves the {pitch}x{rows} level-1 plane")
             if not (0 <= peer < world) or peer == rank:
                 raise RuntimeError(f"bad halo peer {peer}")
-    gb_np = synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h)
+    if DRY:
+        if job.a.dry_fail == f"{rank}:{mode}/{transport}":
+            raise RuntimeError("injected set-up failure (--dry-fail)")
+        gb_np = {k: np.zeros((spec.sh, spec.sw), dtype=d) for k, d in (("A", np.uint32), ("B", np.uint32), ("C", np.uint32), ("depth", np.float32), ("stencil", np.uint8))}
+    else:
+        gb_np = synth.gbuffer_tile(spec.sx0, spec.sy0, spec.sw, spec.sh, spec.full_w, spec.full_h)
     fr.upload_gbuffer(gb_np)
     fr.set_prev_luminance(0.18)
     return fr, gb_np
@@ -549,12 +574,12 @@ def run_workload(job, name, scaling, make_spec, full_w, full_h, cols, rows, step
                 break
         notes.append(err or f"{label} failed on another rank")
         frame = None
-        torch.cuda.synchronize()
+        dev_sync()
     if frame is None:
         raise SystemExit(f"bench.py: no configuration of '{name}' passed its verification frame: " + "; ".join(notes))
     spec = frame.spec
-    lights_px = mean_lights_per_pixel(g, gb_np, spec, frame.clusters)
-    torch.cuda.synchronize()
+    lights_px = 0.0 if DRY else mean_lights_per_pixel(g, gb_np, spec, frame.clusters)
+    dev_sync()
 
     def timed(n_settle, n_warm, n_steps, shade_events=None):
         with job.wd.phase(a.deadline, f"{name}: timed frames"):
@@ -566,10 +591,10 @@ def run_workload(job, name, scaling, make_spec, full_w, full_h, cols, rows, step
             for i in range(n_steps):
                 frame.render(shade_events if (shade_events is not None and i % 5 == 0) else None)
             frame.finish()
-            torch.cuda.synchronize()
+            dev_sync()
             if dist:
                 dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
             return job.max_over_ranks(time.perf_counter() - t0)
 
     # ---- the headline: frames in order (at N = 1 there is nothing else)
@@ -591,7 +616,7 @@ def run_workload(job, name, scaling, make_spec, full_w, full_h, cols, rows, step
                     for _ in range(3):
                         frame.render()
                     frame.finish()
-                    torch.cuda.synchronize()
+                    dev_sync()
                     return float(frame.avg.cpu()[0]), int(frame.ldr.to(torch.int64).sum().item())
                 plain = three_frames()
                 ok = True
@@ -608,7 +633,7 @@ def run_workload(job, name, scaling, make_spec, full_w, full_h, cols, rows, step
             frame._tail_overlap = False
             frame.set_prev_luminance(0.18)
             frame.hist.zero_()
-            torch.cuda.synchronize()
+            dev_sync()
         except Exception as e:   # noqa: BLE001 — the in-order figure above stands; this variant is an extra
             notes.append(f"overlapped frame tail failed on rank {rank}: {type(e).__name__}: {e}")
             ms_overlapped = None
@@ -688,18 +713,18 @@ def shade_paths_ab(job, res, frames=30):
         fr.set_prev_luminance(0.18)
         for _ in range(60):
             fr.render()
-        torch.cuda.synchronize()
+        dev_sync()
         ev = []
         t0 = time.perf_counter()
         for i in range(frames):
             fr.render(ev if i % 3 == 0 else None)
-        torch.cuda.synchronize()
+        dev_sync()
         frame_ms = (time.perf_counter() - t0) / frames * 1e3
         shade_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         out[name] = {"shade_ms": round(shade_ms, 4), "frame_ms": round(frame_ms, 4),
                      "mean_lights_per_pixel": round(mean_lights_per_pixel(g, gb_np, spec, fr.clusters), 3)}
         del fr, gb_np
-        torch.cuda.empty_cache()
+        dev_empty_cache()
     base = out["as_shipped"]["shade_ms"]
     for v in out.values():
         v["shade_vs_as_shipped"] = round(v["shade_ms"] / base, 4)
@@ -729,7 +754,7 @@ def workload_config(job, r, settle):
            "tile": [spec.x0, spec.y0, spec.w, spec.h], "shaded_rect": [spec.sx0, spec.sy0, spec.sw, spec.sh],
            "bloom_rect": [spec.ex0, spec.ey0, spec.ew, spec.eh],
            "bloom_borders": "none" if world == 1 else (r["mode"] + (" (ring first: exchange overlaps the core's shade)" if fr.split is not None else "")),
-           "collectives": "none" if world == 1 else ("gloo-rehearsal" if job.rehearsal else f"rccl-{r['transport']}"
+           "collectives": "none" if world == 1 else ("gloo-rehearsal" if job.rehearsal else ("dry run: gloo stand-in for " if DRY else "") + f"rccl-{r['transport']}"
                                                      + (" (halo exchange and histogram all-reduce on separate communicators)" if r["transport"] == "capi" else "")),
            "mean_lights_per_pixel_by_rank": r["lights_px"], "clock_settle_frames": settle,
            "frame_tail": "in order (value, ms_per_step)"}
@@ -854,7 +879,15 @@ def main():
     # PBR_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives + host copies — exercises this file's
     # multi-rank path on a one-GPU box; not a measurement
     rehearsal = os.environ.get("PBR_BENCH_REHEARSAL", "0") == "1"
-    if world > 1 and not rehearsal and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+    global DRY
+    DRY = bool(a.dry_run)
+    if DRY:
+        if world < 2:
+            print("bench.py: --dry-run rehearses the multi-rank launch: use it with --gpus N > 1", file=sys.stderr)
+            sys.exit(2)
+        rehearsal = False
+        a.no_kernel_timing = a.no_host_graph = a.no_cpu_baseline = a.no_shade_paths = True   # legs that are nothing but device work
+    if world > 1 and not rehearsal and not DRY and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
         # started as ranks by torch.distributed.run itself (the driver's launch form) on a box with fewer devices than ranks: the same
         # rehearsal mode spawn_ranks() would have chosen, instead of a crash in set_device
         if torch.cuda.device_count() < 1 or world > 5:
@@ -864,7 +897,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
+        if DRY:
+            dist.init_process_group("gloo")
+        elif rehearsal:
             local_rank = 0
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
@@ -876,8 +911,12 @@ def main():
         torch.cuda.set_device(0)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = local_rank if world > 1 else 0
-    ctx = PbrContext(dev)
-    flag_dev = "cpu" if rehearsal else f"cuda:{dev}"
+    if DRY:
+        from bench_dryrun import DryContext
+        ctx = DryContext(dist, rank, world)
+    else:
+        ctx = PbrContext(dev)
+    flag_dev = "cpu" if (rehearsal or DRY) else f"cuda:{dev}"
 
     # ---- the record so far, for a rank that has to give up in a later (optional) phase
     state = {"out": None}
@@ -907,6 +946,8 @@ def main():
         with wd.phase(a.deadline, "pbr_comm_init"):
             try:
                 from direct12pbrrenderer_amd.api import comm_unique_id
+                if DRY:
+                    comm_unique_id = ctx.comm_unique_id   # noqa: F811 — 128 bytes from rank 0, broadcast and checked like the real id
                 ids = [comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 ctx.comm_init(world, rank, ids[0])
@@ -944,6 +985,9 @@ def main():
     }
     if rehearsal:
         out["rehearsal"] = "all ranks share cuda:0 (gloo + host copies): functional run, not a measurement"
+    if DRY:
+        out["dry_run"] = True
+        out["data"] = "none (dry run: no device call, frames are no-ops; `value` counts them and measures nothing)"
     state["out"] = out     # complete as a contract line from here on; what follows adds blocks
 
     shaded_px = spec.sw * spec.sh
@@ -1103,7 +1147,7 @@ def main():
     if world > 1 and not a.frame and not a.no_cfg5:
         del frame
         res["frame_obj"] = None
-        torch.cuda.empty_cache()
+        dev_empty_cache()
         # (a rehearsal with a reduced tile budget exercises this leg on a reduced frame: it is a functional run either way)
         cfg5_frame = (1920, 1088) if (rehearsal and a.width < 3840) else CFG5_FRAME
         s5 = strong(cfg5_frame[0], cfg5_frame[1], CFG5_GRID.get(world))
@@ -1118,7 +1162,7 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     hg5 = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
             r5["frame_obj"] = None
-            torch.cuda.empty_cache()
+            dev_empty_cache()
             # the denominator: the same 8K frame on ONE GPU (rank 0, the others wait), so that the x-factor comes from one record
             single_ms = None
             with wd.phase(max(a.deadline, 600.0), "cfg5: single-GPU 8K frame on rank 0"):
@@ -1126,15 +1170,18 @@ def main():
                     fw, fh = cfg5_frame
                     from direct12pbrrenderer_amd.pipeline import TileSpec
                     fr1 = DeferredFrame(ctx, TileSpec(0, 0, fw, fh, fw, fh, 0), r5["g"], r5["lights"], job.lut, LUT_RES, job.env, ENV_SIZE, ENV_MIPS)
-                    fr1.upload_gbuffer(synth.gbuffer_tile(0, 0, fw, fh, fw, fh))
+                    if DRY:
+                        fr1.upload_gbuffer({k: np.zeros((fh, fw), dtype=d) for k, d in (("A", np.uint32), ("B", np.uint32), ("C", np.uint32), ("depth", np.float32), ("stencil", np.uint8))})
+                    else:
+                        fr1.upload_gbuffer(synth.gbuffer_tile(0, 0, fw, fh, fw, fh))
                     fr1.set_prev_luminance(0.18)
                     for _ in range(30 + a.warmup):
                         fr1.render()
-                    torch.cuda.synchronize()
+                    dev_sync()
                     t0 = time.perf_counter()
                     for _ in range(a.steps):
                         fr1.render()
-                    torch.cuda.synchronize()
+                    dev_sync()
                     single_ms = (time.perf_counter() - t0) / a.steps * 1e3
                     del fr1
                 if dist:

@@ -5,7 +5,7 @@
 // RCCL: declarations only — the library is bound with dlopen (section "RCCL"), so a one-GPU process never needs librccl.  A build box
 // without the development header still builds: the handful of types, enum values and signatures the calls need are restated below
 // (RCCL >= 2.18 ABI) and the static_asserts that pin them to the header are compiled out.  -DPBR_NO_RCCL_HEADER forces that branch:
-// tests/test_build.py compiles this file host-only with it, so the branch stays buildable on boxes that do have the header.
+// tests/test_runtime_cpu.py compiles this file host-only with it, so the branch stays buildable on boxes that do have the header.
 #if __has_include(<rccl/rccl.h>) && !defined(PBR_NO_RCCL_HEADER)
 #include <rccl/rccl.h>
 #define PBR_HAVE_RCCL_HEADER 1

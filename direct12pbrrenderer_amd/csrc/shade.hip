@@ -118,18 +118,18 @@ constexpr int LIGHT_PLANES = 9;
 
 // Which pixels of the tile a launch shades: up to SHADE_MAX_RECTS rectangles (tile-local), walked by ONE 1-D grid — a
 // whole tile is one rectangle; the overlapped multi-GPU frame shades the tile's border ring (<= 4 rectangles) in one
-// launch and its core in another.  Per rectangle the schedule described at the kernel applies.
+// launch and its core in another.  Per rectangle the two-zone schedule of the kernel applies.
 constexpr int SHADE_MAX_RECTS = 5;
 struct ShadeRects {
-    uint32_t n, parts, rows_small;   // parts: 1, 2 or 4 — the pieces a long block's SHADE_ROWS rows come in
+    uint32_t n, rows_big, rows_small;   // rows of a long / of a short block (<= SHADE_ROWS)
     uint32_t x0[SHADE_MAX_RECTS], y0[SHADE_MAX_RECTS], w[SHADE_MAX_RECTS], h[SHADE_MAX_RECTS];
     uint32_t cols[SHADE_MAX_RECTS], nb_big[SHADE_MAX_RECTS], first[SHADE_MAX_RECTS + 1];   // first block of rect r; [n] = total
 };
 
 constexpr int SHADE_BLOCK = 256;
-constexpr int SHADE_ROWS = 8;          // rows of 256 pixels a long block walks after staging the light table once (12: no change, 16: +3 %, round 5)
-constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per piece
-// staged list: count, pad, 32 entries
+constexpr int SHADE_ROWS = 8;          // most rows of 256 pixels one block walks after staging its tables (12: no change, 16: +3 %, round 5)
+constexpr int MAX_STAGED_TILES = 12;   // cluster (x,y) tiles whose 8 z-slices may be staged per block
+// staged list: count, pad, 32 u16 indices = 34 halfwords (68 B) per cluster
 constexpr int LIST_STRIDE = 34;         // dwords per staged cluster list: count, pad, 32 entries (8-byte aligned pairs)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -497,20 +497,8 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
     else store_h4(reinterpret_cast<pbr_half*>(reinterpret_cast<char*>(p.hdr) + ho * 8u), f4(out.x, out.y, out.z, 1.0f));
 }
 
-// ------------------------------------------------------------------------------------------------
-// Launch schedule.  grid = blocks, dispatched in index order by the hardware (a work queue of its own: a software queue of
-// persistent blocks was built and measured in round 6 — EXPERIMENTS.md — and lost to it at every size).  Per rectangle:
-//  * the first nb_big block rows are LONG blocks of SHADE_ROWS rows, the rest SHORT blocks of rows_small rows, dispatched last:
-//    they fill the tail of the launch (a 4K frame is only ~3.2 generations of resident blocks);
-//  * a long block's rows come in `parts` pieces from DIFFERENT places of the rectangle: piece j is SHADE_ROWS / parts rows of the
-//    j-th horizontal band of the long zone, in a column block shifted by j / parts of the width.  The cost of a pixel row is its
-//    cluster lists' length, which varies across the frame by 2.7x (a block's time: 67 us mean, 119 us at the 99th percentile at
-//    1080p / 256 lights, profiles/r06_a_timeline_*): a block made of the frame's edge AND its centre costs about the average,
-//    where a launch of about one generation (1080p: 0.84) otherwise waits for the blocks of the densest region.  The price is a
-//    re-staging of the cluster lists (not of the light table) per piece.
-// Per-pixel arithmetic does not depend on the schedule: the output is the same to the bit whichever block shades a pixel.
 #ifdef PBR_SHADE_TIMING   // experiment build only (tools/shade_timeline.py): 100 MHz wall-clock stamps of every block
-__device__ unsigned long long g_shade_item_stamp[4 * 160000];    // per block: start, first piece staged, end, (rows << 48 | block)
+__device__ unsigned long long g_shade_item_stamp[4 * 160000];    // per block: start, tables staged, end (last wave), (rows << 48 | block)
 extern "C" int pbr_debug_shade_stamps(unsigned long long* blocks, int n_blocks, unsigned long long* items, int n_items) {
     (void)blocks; (void)n_blocks;
     return (int)hipMemcpyFromSymbol(items, HIP_SYMBOL(g_shade_item_stamp), sizeof(unsigned long long) * 4 * n_items);
@@ -531,9 +519,22 @@ extern "C" int pbr_debug_shade_stamps_reset() {
 #define SHADE_NOW() 0ull
 #endif
 
-// the block's light table: nine SoA planes + the null light; my_safe / my_same: this thread's lights keep the fast paths open
-template <int LSTRIDE>
-__device__ __forceinline__ void stage_lights(const ShadeParams& p, float* llds, int n_lights, int& my_safe, int& my_same) {
+// grid: rc.first[rc.n] blocks of 256 threads, dispatched in index order (the hardware's dispatcher is the work queue: a software queue
+// of persistent blocks was built and measured in round 6 and lost to it at every size — EXPERIMENTS.md).
+// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 136 B of light lists.
+template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
+#ifndef SHADE_MIN_WAVES
+#define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
+#endif
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
+    extern __shared__ float4 lds_raw[];
+    __shared__ uint32_t s_mip_off[16];
+    const unsigned long long t_start = SHADE_NOW();
+    (void)t_start;
+    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
+    float* llds = reinterpret_cast<float*>(lds_raw);
+    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));   // 8-byte aligned
+    int my_safe = 1, my_same = 1;
     const float att0 = n_lights > 0 ? p.lights[0].C0 : 1.0f, att1 = n_lights > 0 ? p.lights[0].C1 : 0.0f, att2 = n_lights > 0 ? p.lights[0].C2 : 0.0f;
     if (threadIdx.x == 0) {   // the null light: pads odd lists; black, so its pair lane contributes exactly 0
         llds[0 * LSTRIDE + n_lights] = 1.0e15f; llds[1 * LSTRIDE + n_lights] = 1.0e15f; llds[2 * LSTRIDE + n_lights] = 1.0e15f;
@@ -554,111 +555,100 @@ __device__ __forceinline__ void stage_lights(const ShadeParams& p, float* llds, 
         llds[7 * LSTRIDE + i] = l.C1;
         llds[8 * LSTRIDE + i] = l.C2;
     }
-}
-
-// one piece of a block's pixels, tile-local: columns [bx0, x_end) of rows [y_begin, y_end)
-struct ShadeItem { uint32_t bx0, x_end, y_begin, y_end; };
-
-// The light lists of the clusters a piece's pixels can fall into, as LDS byte addresses of the lights (one dword each) — same
-// arithmetic as the per-pixel ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners
-// bound it.  A thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry
-// (round 5: ~170 instructions per thread and block less than the entry-major loop it replaces; shade in frame -0.4 %).
-__device__ __forceinline__ void stage_lists(const ShadeParams& p, const ShadeItem& it, uint32_t* lists, uint32_t lds_base, int n_lights, int max_clusters,
-                                            int& tile_x0, int& tile_y0, int& tiles_x) {
-    static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
-    const uint32_t bx1 = min(it.bx0 + SHADE_BLOCK, it.x_end) - 1;
-    auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
-    auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
-    tile_x0 = tx(it.bx0);
-    const int tile_x1 = tx(bx1);
-    const int ty_a = ty(it.y_begin), ty_b = ty(it.y_end - 1);
-    tile_y0 = min(ty_a, ty_b);
-    const int tile_y1 = max(ty_a, ty_b);
-    tiles_x = tile_x1 - tile_x0 + 1;
-    const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
-    const int j = threadIdx.x & 31;
-    for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
-        const int z = c & 7, t = c >> 3;
-        const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
-        const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
-        const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-        uint32_t* l = lists + c * LIST_STRIDE;
-        const int li = j < cnt ? min(max(cl->LightIndex[j], 0), n_lights - 1) : n_lights;   // never index past the staged table
-        l[2 + j] = lds_base + 4u * (uint32_t)li;
-        if (j < 2) l[j] = j == 0 ? (uint32_t)max((cnt + 1) & ~1, 2) : 0u;
-    }
-}
-
-// per-row terms of a piece's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
-__device__ __forceinline__ float4 row_terms(const ShadeParams& p, uint32_t y) {
-    const float v = ((float)(p.y0 + y) + 0.5f) / (float)p.full_h;
-    const float ndc_y = 1.0f - 2.0f * v;
-    return make_float4(v, ndc_y * 0.5f * p.near_height, (float)clampi((int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1), 0.0f);
-}
-
-#ifndef SHADE_MIN_WAVES
-#define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
-#endif
-
-// grid = rc.first[rc.n] blocks of 256 threads.
-// dynamic LDS: 9 planes * LSTRIDE floats of light data, then (STAGED_LISTS) max_clusters * 136 B of light lists.
-template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
-    extern __shared__ float4 lds_raw[];
-    __shared__ uint32_t s_mip_off[16];
-    __shared__ float4 s_row[SHADE_ROWS];
-    const unsigned long long t_start = SHADE_NOW();
-    (void)t_start;
-    if (threadIdx.x < 16) s_mip_off[threadIdx.x] = p.env_mip_off[threadIdx.x];
-    float* llds = reinterpret_cast<float*>(lds_raw);
-    uint32_t* lists = reinterpret_cast<uint32_t*>(llds + ((LIGHT_PLANES * LSTRIDE + 1) & ~1));   // 8-byte aligned
-    int my_safe = 1, my_same = 1;
-    stage_lights<LSTRIDE>(p, llds, n_lights, my_safe, my_same);
-    // block -> rectangle -> (column block, block row) -> its pieces {bx0, x_end, y_begin, y_end}, written to LDS by one lane each: nothing
-    // of the schedule stays in registers across the pixel code but the piece counter (the pixel code has no register to spare)
-    __shared__ int4 s_piece[4];
-    __shared__ uint32_t s_parts;
-    if (threadIdx.x < 4) {
-        uint32_t r = 0;
-        while (r + 1 < rc.n && blockIdx.x >= rc.first[r + 1]) r++;
-        const uint32_t lb = blockIdx.x - rc.first[r];
-        const uint32_t cols = rc.cols[r], by = lb / cols, cx = lb - by * cols, nb_big = rc.nb_big[r];
-        const bool big = by < nb_big;
-        const uint32_t parts = big ? rc.parts : 1u, rows = big ? (uint32_t)SHADE_ROWS / rc.parts : rc.rows_small, j = threadIdx.x;
-        // piece j of a long block: row (by + j nb_big) of the long zone cut into pieces of `rows` rows, column block shifted by j / parts of the width
-        const uint32_t pc = big ? cx + (j * cols) / parts : cx;
-        const uint32_t y_begin = rc.y0[r] + (big ? (by + j * nb_big) * rows : nb_big * SHADE_ROWS + (by - nb_big) * rows);
-        s_piece[j] = make_int4((int)(rc.x0[r] + (pc >= cols ? pc - cols : pc) * SHADE_BLOCK), (int)(rc.x0[r] + rc.w[r]), (int)y_begin, (int)min(y_begin + rows, rc.y0[r] + rc.h[r]));
-        if (j == 0) s_parts = parts;
-    }
+    // block -> rectangle -> (column block, row block); wave-uniform scalar arithmetic
+    uint32_t r = 0;
+    while (r + 1 < rc.n && blockIdx.x >= rc.first[r + 1]) r++;
+    const uint32_t lb = blockIdx.x - rc.first[r];
+    const uint32_t bx0 = rc.x0[r] + (lb % rc.cols[r]) * SHADE_BLOCK, x_end = rc.x0[r] + rc.w[r];
+    // two-zone schedule: the first nb_big block rows walk rows_big rows each, the rest rows_small — the short
+    // blocks are dispatched last and fill the tail of the launch (a 4K frame is only ~3.2 waves of resident blocks)
+    const uint32_t by = lb / rc.cols[r], nb_big = rc.nb_big[r], rows_big = rc.rows_big, rows_small = rc.rows_small;
+    const uint32_t y_begin = rc.y0[r] + (by < nb_big ? by * rows_big : nb_big * rows_big + (by - nb_big) * rows_small);
+    const uint32_t y_end = min(y_begin + (by < nb_big ? rows_big : rows_small), rc.y0[r] + rc.h[r]);
+    int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_cf*)llds;   // < 64 KiB: the whole light table (<= 9 x 1025 floats) stays addressable in 16 bits
+    if (STAGED_LISTS) {
+        // cluster (x,y) tiles the block's pixel rectangle can fall into — same arithmetic as the per-pixel
+        // ClusterIndex (floor(u*24), floor((1-v)*16)); monotone in the pixel coordinate, so the corners bound it
+        const uint32_t bx1 = min(bx0 + SHADE_BLOCK, x_end) - 1;
+        auto tx = [&](uint32_t x) { return clampi((int)floorf((((float)(p.x0 + x) + 0.5f) / (float)p.full_w) * (float)PBR_CLUSTER_X), 0, PBR_CLUSTER_X - 1); };
+        auto ty = [&](uint32_t y) { return clampi((int)floorf((1.0f - ((float)(p.y0 + y) + 0.5f) / (float)p.full_h) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1); };
+        tile_x0 = tx(bx0);
+        const int tile_x1 = tx(bx1);
+        const int ty_a = ty(y_begin), ty_b = ty(y_end - 1);
+        tile_y0 = min(ty_a, ty_b);
+        const int tile_y1 = max(ty_a, ty_b);
+        tiles_x = tile_x1 - tile_x0 + 1;
+        const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
+        // a thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry (round 5:
+        // ~170 instructions per thread and block less than the entry-major loop it replaces; shade in frame -0.4 %, profiles/r05_ac_stage_fast.txt)
+        {
+            static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
+            const int j = threadIdx.x & 31;
+#ifdef PBR_EXP_BATCH_STAGE   // experiment (round 6): every list load of the block issued before the first is used — one trip to L2 instead of n_cl / 8
+            constexpr int ROUNDS = MAX_STAGED_TILES * PBR_CLUSTER_Z / (SHADE_BLOCK / 32);
+            const int rounds = (n_cl + SHADE_BLOCK / 32 - 1) / (SHADE_BLOCK / 32);   // block-uniform
+            int cnt[ROUNDS], idx[ROUNDS];
+#pragma unroll
+            for (int k = 0; k < ROUNDS; k++) {
+                if (k < rounds) {
+                    const int c = min((int)(threadIdx.x >> 5) + k * (SHADE_BLOCK / 32), n_cl - 1);
+                    const int z = c & 7, t = c >> 3;
+                    const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
+                    const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+                    cnt[k] = cl->NumLights;
+                    idx[k] = cl->LightIndex[j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ROUNDS; k++) {
+                const int c = (int)(threadIdx.x >> 5) + k * (SHADE_BLOCK / 32);
+                if (k < rounds && c < n_cl) {
+                    const int cn = n_lights > 0 ? min(max(cnt[k], 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
+                    uint32_t* l = lists + c * LIST_STRIDE;
+                    const int li = j < cn ? min(max(idx[k], 0), n_lights - 1) : n_lights;
+                    l[2 + j] = lds_base + 4u * (uint32_t)li;
+                    if (j < 2) l[j] = j == 0 ? (uint32_t)max((cn + 1) & ~1, 2) : 0u;
+                }
+            }
+#else
+            for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
+                const int z = c & 7, t = c >> 3;
+                const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
+                const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+                const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
+                uint32_t* l = lists + c * LIST_STRIDE;
+                const int li = j < cnt ? min(max(cl->LightIndex[j], 0), n_lights - 1) : n_lights;   // never index past the staged table
+                l[2 + j] = lds_base + 4u * (uint32_t)li;
+                if (j < 2) l[j] = j == 0 ? (uint32_t)max((cnt + 1) & ~1, 2) : 0u;
+            }
+#endif
+        }
+    }
+    // per-row terms of the block's <= SHADE_ROWS rows (vs_main :91-95, ClusterIndex clustered.hlsli:47): {v, cvv.y, cluster row}
+    __shared__ float4 s_row[SHADE_ROWS];
+    if (threadIdx.x < (uint32_t)SHADE_ROWS) {
+        const float v = ((float)(p.y0 + y_begin + threadIdx.x) + 0.5f) / (float)p.full_h;
+        const float ndc_y = 1.0f - 2.0f * v;
+        s_row[threadIdx.x] = make_float4(v, ndc_y * 0.5f * p.near_height, (float)clampi((int)floorf((1.0f - v) * (float)PBR_CLUSTER_Y), 0, PBR_CLUSTER_Y - 1), 0.0f);
+    }
     // bit 0: the attenuation floor cannot bind; bit 1: every staged light has the SAME attenuation polynomial (one radius for the
     // whole scene is common), so its three coefficients are per-kernel constants and a trip reads 13 LDS dwords instead of 19
     const int q_safe = (__syncthreads_and(my_safe) != 0 ? 1 : 0) | (__syncthreads_and(my_same) != 0 ? 2 : 0);
-    const uint32_t parts = __builtin_amdgcn_readfirstlane(s_parts);
-    uint32_t rows_done = 0;
-    (void)rows_done;
-    for (uint32_t j = 0; j < parts; j++) {
-        ShadeItem it;
-        {
-            const int4 d = s_piece[j];
-            it.bx0 = __builtin_amdgcn_readfirstlane(d.x); it.x_end = __builtin_amdgcn_readfirstlane(d.y);
-            it.y_begin = __builtin_amdgcn_readfirstlane(d.z); it.y_end = __builtin_amdgcn_readfirstlane(d.w);
-        }
-        if (j) __syncthreads();   // every wave is done with the previous piece's lists and row terms
-        int tile_x0 = 0, tile_y0 = 0, tiles_x = 1;
-        if (STAGED_LISTS) stage_lists(p, it, lists, lds_base, n_lights, max_clusters, tile_x0, tile_y0, tiles_x);
-        if (threadIdx.x < (uint32_t)SHADE_ROWS) s_row[threadIdx.x] = row_terms(p, it.y_begin + threadIdx.x);
-        __syncthreads();
-        if (j == 0) { SHADE_ISTAMP(blockIdx.x, 0, t_start); SHADE_ISTAMP(blockIdx.x, 1, SHADE_NOW()); }
-        const uint32_t px = it.bx0 + threadIdx.x;
-        if (px < it.x_end)
-            for (uint32_t py = it.y_begin; py < it.y_end; py++)
-                shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - it.y_begin]);
-        rows_done += it.y_end - it.y_begin;
-    }
+    SHADE_ISTAMP(blockIdx.x, 0, t_start);
+    SHADE_ISTAMP(blockIdx.x, 1, SHADE_NOW());
+    SHADE_ISTAMP(blockIdx.x, 3, ((unsigned long long)(y_end - y_begin) << 48) | blockIdx.x);
+    const uint32_t px = bx0 + threadIdx.x;
+#ifndef PBR_SHADE_TIMING
+    if (px >= x_end) return;
+    for (uint32_t py = y_begin; py < y_end; py++)
+        shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin]);
+#else
+    if (px < x_end)
+        for (uint32_t py = y_begin; py < y_end; py++)
+            shade_pixel<STAGED_LISTS, LSTRIDE, F32OUT>(p, llds, lists, s_mip_off, tile_x0, tile_y0, tiles_x, n_lights, q_safe, px, py, s_row[py - y_begin]);
     SHADE_ISTAMP_MAX(blockIdx.x, 2, SHADE_NOW());
-    SHADE_ISTAMP(blockIdx.x, 3, ((unsigned long long)rows_done << 48) | blockIdx.x);
+#endif
 }
 
 extern "C" {
@@ -719,31 +709,31 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
     for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)env_padded_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
     p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch; p.hdr_f32 = hdr_f32;
-    // schedule (see the kernel): long blocks first — their rows in `parts` pieces from different bands of the rectangle — short ones for the tail
+    // schedule (see the kernel): long blocks first, short ones for the tail
     static const float big_frac = pbr::knob_float("PBR_SHADE_BIGFRAC", 0.92f);   // re-swept after the per-pixel trims (the knobs build): 0.9-0.95 with 1-row tail blocks beats 0.85 / 2 by ~0.4 %
     static const uint32_t rows_small_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_SMALL", 1);
-    static const uint32_t parts_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_PARTS", 2);
+    static const uint32_t rows_big_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_BIG", 0);   // 0: by target size (below)
     const uint32_t rows_small = rows_small_cfg >= 1 && rows_small_cfg <= (uint32_t)SHADE_ROWS ? rows_small_cfg : 1u;
+    const uint32_t rows_big = rows_big_cfg >= 1 && rows_big_cfg <= (uint32_t)SHADE_ROWS ? rows_big_cfg : (uint32_t)SHADE_ROWS;
     const uint32_t whole[1][4] = {{0, 0, tile->w, tile->h}};
     if (!rects) { rects = whole; n_rects = 1; }
     PBR_REQUIRE(ctx, n_rects >= 1 && n_rects <= (uint32_t)SHADE_MAX_RECTS, "pbr_deferred_shade: 1 .. 5 rectangles");
     ShadeRects rc{};
-    rc.n = n_rects; rc.rows_small = rows_small;
-    rc.parts = parts_cfg == 4 ? 4u : (parts_cfg == 1 ? 1u : 2u);
+    rc.n = n_rects; rc.rows_big = rows_big; rc.rows_small = rows_small < rows_big ? rows_small : rows_big;
     uint32_t blocks = 0;
     for (uint32_t r = 0; r < n_rects; r++) {
         const uint32_t* q = rects[r];
         PBR_REQUIRE(ctx, q[2] >= 1 && q[3] >= 1 && q[0] + q[2] <= tile->w && q[1] + q[3] <= tile->h, "pbr_deferred_shade: rectangle outside the tile");
         rc.x0[r] = q[0]; rc.y0[r] = q[1]; rc.w[r] = q[2]; rc.h[r] = q[3];
         rc.cols[r] = (q[2] + SHADE_BLOCK - 1) / SHADE_BLOCK;
-        rc.nb_big[r] = (uint32_t)((float)(q[3] / SHADE_ROWS) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
-        const uint32_t rest = q[3] - rc.nb_big[r] * SHADE_ROWS;
+        rc.nb_big[r] = (uint32_t)((float)(q[3] / rows_big) * fminf(fmaxf(big_frac, 0.0f), 1.0f));
+        const uint32_t rest = q[3] - rc.nb_big[r] * rows_big;
         rc.first[r] = blocks;
-        blocks += rc.cols[r] * (rc.nb_big[r] + (rest + rows_small - 1) / rows_small);
+        blocks += rc.cols[r] * (rc.nb_big[r] + (rest + rc.rows_small - 1) / rc.rows_small);
     }
     rc.first[n_rects] = blocks;
     dim3 grid(blocks);
-    // A piece covers 256 x <= 8 pixels.  Its cluster lists can be staged when that rectangle spans at most
+    // A block covers 256 x 8 pixels.  It can stage its cluster lists when that rectangle spans at most
     // MAX_STAGED_TILES cluster tiles: a tile is full_w/24 x full_h/16 pixels, +1 per axis for straddling.
     const uint32_t span_x = (uint32_t)((uint64_t)(SHADE_BLOCK - 1) * PBR_CLUSTER_X / tile->full_w) + 2;
     const uint32_t span_y = (uint32_t)((uint64_t)(SHADE_ROWS - 1) * PBR_CLUSTER_Y / tile->full_h) + 2;

@@ -51,3 +51,46 @@ def test_bench_refuses_a_rehearsal_beyond_five_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], capture_output=True, text=True, cwd=ROOT,
                        env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
     assert r.returncode == 2 and "at most 5 ranks" in r.stderr and r.stdout.strip() == ""
+
+
+def _dry_run(extra, timeout=600):
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--settle", "2",
+                        "--deadline", "120"] + extra, capture_output=True, text=True, cwd=ROOT, timeout=timeout,
+                       env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    return r, lines, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_n8_launch_dry_run_on_cpu():
+    """`bench.py --gpus 8 --dry-run`: the 8-rank launch with every device call replaced by a host stand-in (bench_dryrun.py) — the real
+    spawn_ranks / torch.distributed.run start, rendezvous, unique-id broadcast, 2x4 grids, halo plans through DeferredFrame, verification
+    frames (the all-reduce counts every pixel of the frame once; every level-1 texel of every extended tile arrives with its sender's
+    checksum), timed loops with their barriers, the overlapped-tail check, the cfg5 sub-record with its single-GPU denominator, teardown
+    and the ONE JSON line — everything of the launch that has never run on hardware, but the kernels.  No device is visible."""
+    r, lines, d = _dry_run([])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, lines
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    c = d["config"]
+    assert c["layout_rows_x_cols"] == "2x4" and c["frame"] == [10880, 6112] and c["tile"] == [0, 0, 2720, 3056]
+    assert c["bloom_borders"] == "halo" and "rccl-capi" in c["collectives"] and "dry run" in c["collectives"]
+    assert "ms_per_step_tail_overlapped" in c          # the overlapped-tail variant was checked against the plain order and timed
+    c5 = c["cfg5"]
+    assert "error" not in c5, c5
+    assert c5["frame"] == [7680, 4320] and c5["layout_rows_x_cols"] == "2x4" and c5["tile"] == [0, 0, 1920, 2160] and c5["scaling"] == "strong"
+    assert c5["single_gpu_ms_per_step"] > 0 and "speedup_vs_single_gpu" in c5
+    assert "oracle" not in r.stderr.lower()           # the product path of the launch does not touch the checker
+
+
+def test_bench_n8_dry_run_every_rank_takes_the_next_candidate_when_one_rank_fails_setup():
+    """A rank that cannot set a candidate up (here: rank 3, halo exchange through the C ABI's communicators) must not leave the others
+    inside that candidate's collectives: all eight agree and move to the next one (halo through torch.distributed) — for the headline
+    and for the cfg5 sub-record — and the launch ends with exit code 0 and a note in the record, instead of hanging until a deadline."""
+    r, lines, d = _dry_run(["--dry-fail", "3:halo/capi"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1
+    for c in (d["config"], d["config"]["cfg5"]):
+        assert "rccl-torch" in c["collectives"] and c["bloom_borders"] == "halo" and c["layout_rows_x_cols"] == "2x4"
+        assert any("halo/capi could not be set up" in n for n in c["notes"])
