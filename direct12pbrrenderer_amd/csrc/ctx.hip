@@ -109,6 +109,7 @@ pbr_status pbr_ctx_create(int hip_device, pbr_ctx** out) {
         return PBR_ERR_NOMEM;
     }
     c->scratch_bytes = pbr::SCRATCH_BYTES;
+    if (hipDeviceGetAttribute(&c->cu_count, hipDeviceAttributeMultiprocessorCount, hip_device) != hipSuccess || c->cu_count < 1) c->cu_count = 256;   // MI355X
     *out = c;
     return PBR_OK;
 }

@@ -32,6 +32,7 @@ struct pbr_ctx {
     bool on_side = false, side_pending = false, main_was_null = false;
     std::vector<uint32_t> side_cu_mask;   // pbr_ctx_set_cu_masks: the side stream's CUs (empty: all, high priority)
     bool bloom_shader_order = false;      // pbr_ctx_set_bloom_shader_order: large 2x-up bloom levels in the shader's operation order (bit-exact)
+    int cu_count = 0;                     // compute units of the device (the shade sizes its blocks by the resident-block count)
 };
 
 namespace pbr {

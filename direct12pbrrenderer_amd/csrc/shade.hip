@@ -584,34 +584,33 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade
         // ~170 instructions per thread and block less than the entry-major loop it replaces; shade in frame -0.4 %, profiles/r05_ac_stage_fast.txt)
         {
             static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
-            const int j = threadIdx.x & 31;
-#ifdef PBR_EXP_BATCH_STAGE   // experiment (round 6): every list load of the block issued before the first is used — one trip to L2 instead of n_cl / 8
-            constexpr int ROUNDS = MAX_STAGED_TILES * PBR_CLUSTER_Z / (SHADE_BLOCK / 32);
-            const int rounds = (n_cl + SHADE_BLOCK / 32 - 1) / (SHADE_BLOCK / 32);   // block-uniform
-            int cnt[ROUNDS], idx[ROUNDS];
-#pragma unroll
-            for (int k = 0; k < ROUNDS; k++) {
-                if (k < rounds) {
-                    const int c = min((int)(threadIdx.x >> 5) + k * (SHADE_BLOCK / 32), n_cl - 1);
-                    const int z = c & 7, t = c >> 3;
-                    const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
-                    const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
-                    cnt[k] = cl->NumLights;
-                    idx[k] = cl->LightIndex[j];
+#ifndef PBR_EXP_STAGE_R5   // (round 5's form below: a thread per entry, n_cl / 8 rounds of ~40 instructions; kept for A/B builds)
+            // A thread owns FOUR consecutive entries of cluster (tid >> 3) + 32 k: one 16-byte load of indices per thread and round,
+            // n_cl / 32 rounds.  The prologue is instruction issue, not latency: a new block's waves share their SIMDs with four blocks in
+            // the middle of their pixel work, and ~700 prologue instructions per thread were 6 % of a 256-light block's work, 15 % of a
+            // single-light one's (block timelines, profiles/r06_i_timeline_*: "staging" 5 - 12 us whether or not the loads are batched).
+            // Entries from the list's (even) length on are never read by the walk: their threads skip the conversion.
+            struct __attribute__((packed, aligned(4))) Idx4 { int32_t x, y, z, w; };
+            const int part = threadIdx.x & 7;
+            const float inv_tiles_x = rcp((float)tiles_x);
+            for (int c = threadIdx.x >> 3; c < n_cl; c += SHADE_BLOCK / 8) {
+                const int z = c & 7, t = c >> 3;
+                // t / tiles_x, both <= MAX_STAGED_TILES: (t + 1/2) / tiles_x is never within 0.04 of an integer, the approximate reciprocal is exact enough
+                const int ty_ = (int)(((float)t + 0.5f) * inv_tiles_x), cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
+                const pbr_cluster* cl = p.clusters + (z + cx * PBR_CLUSTER_Z + cy * PBR_CLUSTER_X * PBR_CLUSTER_Z);
+                const int cnt = n_lights > 0 ? min(max(cl->NumLights, 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
+                const Idx4 v = *reinterpret_cast<const Idx4*>(cl->LightIndex + 4 * part);
+                uint32_t* l = lists + c * LIST_STRIDE;
+                if (4 * part < max(cnt, 2)) {
+                    auto entry = [&](int k, int raw) { return lds_base + 4u * (uint32_t)(4 * part + k < cnt ? min(max(raw, 0), n_lights - 1) : n_lights); };   // never index past the staged table
+                    uint2* e = reinterpret_cast<uint2*>(l + 2 + 4 * part);   // 136 c + 8 + 16 part bytes: 8-byte aligned
+                    e[0] = make_uint2(entry(0, v.x), entry(1, v.y));
+                    e[1] = make_uint2(entry(2, v.z), entry(3, v.w));
                 }
-            }
-#pragma unroll
-            for (int k = 0; k < ROUNDS; k++) {
-                const int c = (int)(threadIdx.x >> 5) + k * (SHADE_BLOCK / 32);
-                if (k < rounds && c < n_cl) {
-                    const int cn = n_lights > 0 ? min(max(cnt[k], 0), PBR_MAX_LIGHTS_PER_CLUSTER) : 0;
-                    uint32_t* l = lists + c * LIST_STRIDE;
-                    const int li = j < cn ? min(max(idx[k], 0), n_lights - 1) : n_lights;
-                    l[2 + j] = lds_base + 4u * (uint32_t)li;
-                    if (j < 2) l[j] = j == 0 ? (uint32_t)max((cn + 1) & ~1, 2) : 0u;
-                }
+                if (part == 0) *reinterpret_cast<uint2*>(l) = make_uint2((uint32_t)max((cnt + 1) & ~1, 2), 0u);
             }
 #else
+            const int j = threadIdx.x & 31;
             for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
                 const int z = c & 7, t = c >> 3;
                 const int ty_ = t / tiles_x, cx = tile_x0 + (t - ty_ * tiles_x), cy = tile_y0 + ty_;
@@ -714,10 +713,25 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     static const uint32_t rows_small_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_SMALL", 1);
     static const uint32_t rows_big_cfg = (uint32_t)pbr::knob_int("PBR_SHADE_ROWS_BIG", 0);   // 0: by target size (below)
     const uint32_t rows_small = rows_small_cfg >= 1 && rows_small_cfg <= (uint32_t)SHADE_ROWS ? rows_small_cfg : 1u;
-    const uint32_t rows_big = rows_big_cfg >= 1 && rows_big_cfg <= (uint32_t)SHADE_ROWS ? rows_big_cfg : (uint32_t)SHADE_ROWS;
     const uint32_t whole[1][4] = {{0, 0, tile->w, tile->h}};
     if (!rects) { rects = whole; n_rects = 1; }
     PBR_REQUIRE(ctx, n_rects >= 1 && n_rects <= (uint32_t)SHADE_MAX_RECTS, "pbr_deferred_shade: 1 .. 5 rectangles");
+    // Rows of a long block.  SHADE_ROWS (8) wherever that gives at least ~1.3 generations of the blocks the device holds at once
+    // (compute units x 5): the tables a block stages are amortised best, and 4K (3.2 generations), a cfg5 rank's tile (1.7) and 8K
+    // measure best there.  Smaller targets get the row count that makes ~1.6 generations — one generation and a bit (1.1) is the worst
+    // place to be: the launch then lasts two block lifetimes for one block's worth of work per slot.  Measured (profiles/r06_j_rows_*,
+    // r06_g_*): 1440x960 (the reference's own target, 0.56 generations at 8 rows) 3 rows -10 %; 1920x1080 (0.84) 4 rows -0.5 ... -2.4 %.
+    uint32_t rows_big = (uint32_t)SHADE_ROWS;
+    {
+        uint64_t row_segments = 0;   // 256-pixel row pieces of the launch
+        for (uint32_t r = 0; r < n_rects; r++) row_segments += (uint64_t)((rects[r][2] + SHADE_BLOCK - 1) / SHADE_BLOCK) * rects[r][3];
+        const uint64_t slots = (uint64_t)ctx->cu_count * SHADE_MIN_WAVES;
+        if (row_segments * 10 < slots * 13 * SHADE_ROWS) {
+            const uint32_t rws = (uint32_t)((row_segments * 10 + slots * 8) / (slots * 16));   // round(row_segments / (1.6 slots))
+            rows_big = rws < 2 ? 2u : (rws > (uint32_t)SHADE_ROWS ? (uint32_t)SHADE_ROWS : rws);
+        }
+        if (rows_big_cfg >= 1 && rows_big_cfg <= (uint32_t)SHADE_ROWS) rows_big = rows_big_cfg;
+    }
     ShadeRects rc{};
     rc.n = n_rects; rc.rows_big = rows_big; rc.rows_small = rows_small < rows_big ? rows_small : rows_big;
     uint32_t blocks = 0;

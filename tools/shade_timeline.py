@@ -76,6 +76,18 @@ for sz in sizes:
                "item_us_mean": round(float((en - st).mean()), 2), "item_us_p99": round(float(np.percentile(en - st, 99)), 2),
                "staging_us_mean": round(float((lg - st).mean()), 2), "tail_below_half_peak_us": round(float(tail), 1),
                "busy_item_us_over_span_x_peak": round(float((en - st).sum() / (span * peak)), 3)}
+        if os.environ.get("PBR_TIMELINE_MAP"):   # where the long blocks are: mean block time (us) over a coarse grid of the frame's long zone
+            cols = (W + 255) // 256
+            dur = (it[:, 2] - it[:, 0]) * 0.01
+            rws = it[:, 3] >> 48
+            bid = it[:, 3] & 0xFFFFFFFF
+            big = rws == rws.max()
+            by, cx = bid[big] // cols, bid[big] % cols
+            nby = int(by.max()) + 1
+            grid = np.zeros((8, cols)); cnt = np.zeros((8, cols))
+            np.add.at(grid, (by * 8 // nby, cx), dur[big]); np.add.at(cnt, (by * 8 // nby, cx), 1)
+            rec["mean_block_us_by_eighth_of_height_and_column"] = [[round(float(v), 1) for v in row] for row in grid / np.maximum(cnt, 1)]
+            rec["start_us_by_eighth_of_height"] = [round(float(st[big][(by * 8 // nby) == k].mean()), 1) for k in range(8)]
         bl = blocks[blocks[:, 0] > 0].astype(np.int64)
         if len(bl):   # persistent blocks: prologue, life, items per block, XCD of each block
             rec.update({"blocks": int(len(bl)), "prologue_us_mean": round(float(((bl[:, 1] - bl[:, 0]) * 0.01).mean()), 2),
