@@ -101,6 +101,7 @@ def parse():
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--no-host-graph", action="store_true", help="skip the C++ pass-graph leg (host_graph block)")
     p.add_argument("--no-shade-paths", action="store_true", help="skip the shade_ms_by_path A/B (N = 1)")
+    p.add_argument("--no-configs", action="store_true", help="skip the `configs` block: BASELINE configs[0..2] and the reference's own operating point (N = 1)")
     p.add_argument("--deadline", type=float, default=240.0, help="seconds a collective phase may take before the rank gives up (N > 1)")
     p.add_argument("--dry-run", action="store_true",
                    help="N > 1 on a box without N GPUs (or without any): the real rank processes, rendezvous (gloo), tile / halo plans, candidate "
@@ -735,6 +736,181 @@ def shade_paths_ab(job, res, frames=30):
     return out
 
 
+def time_batch(fn, n=30, reps=3):
+    """ms per call of `fn` over back-to-back batches of n launches (best of reps), HIP events on the kernels' stream."""
+    fn()
+    dev_sync()
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n)
+    return best
+
+
+def cpu_median(fn, reps=3):
+    """median wall time (s) of `fn` over `reps` runs after one warm-up (the oracle runs on every host thread: OpenMP)"""
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def configs_block(job):
+    """`configs`: the single-GPU BASELINE.json configs other than the headline — cfg1 (split-sum LUT), cfg2 (1080p, one point light),
+    cfg3 (GGX prefilter + SH9) — and the reference's own operating point (1440x960, Asset/Scene/main.json's 8 lights, LUT 512^2,
+    fence per frame, through the C++ pass graph), each with its figure of merit and, unless --no-cpu-baseline, the CPU leg of BASELINE.md
+    section 2 (the oracle, kind "port", all host threads, on the whole config or a stated sample).  Outside the timed region; N = 1 only.
+    (The same legs, with the cfg5 tiles, as a stand-alone tool: tools/bench_configs.py.)"""
+    ctx, a = job.ctx, job.a
+    cpu = not a.no_cpu_baseline
+    orc = None
+    if cpu:
+        from oracle import binding as orc   # the checker, timed beside the product: never on the product's path
+    out = {}
+
+    # ---- cfg1: "256x256 split-sum BRDF LUT" (SURVEY D1: the reference's own LUT is 512x512 — both)
+    c1 = {"workload": "split-sum BRDF LUT, 1 024 Hammersley / GGX samples per texel (precompute_brdf.hlsl); 256^2 = BASELINE configs[0], 512^2 = the reference's own size",
+          "bound": "FP32 VALU issue (no input, 256 KiB / 1 MiB out)"}
+    for res in (256, 512):
+        buf = ctx.empty((res, res, 2), torch.float16)
+        ms = time_batch(lambda: ctx.brdf_lut(res, out=buf), 10)
+        r = {"ms": round(ms, 4), "Msamples_per_s": round(res * res * 1024 / ms / 1e3, 1)}
+        if cpu:
+            dt = cpu_median(lambda: orc.brdf_lut(res))
+            r["cpu_baseline"] = {"value": round(res * res * 1024 / dt / 1e6, 1), "unit": "Msamples/s", "ms": round(dt * 1e3, 2), "cores": orc.num_threads(), "kind": "port",
+                                 "sample": f"the whole {res}x{res} plane (orc_brdf_lut, OpenMP), median of 3"}
+        c1[f"lut{res}"] = r
+    out["cfg1_brdf_lut"] = c1
+
+    # ---- cfg2: 1920x1080, 1 point light, deferred shade (headline of cfg2 = the shade alone, SURVEY 8d)
+    W2, H2 = 1920, 1080
+    cam = scene.Camera.reference_default(W2, H2)
+    g2 = scene.make_global(cam, W2, H2, sh_pack=job.sh, delta_time=1.0 / 60.0)
+    light1 = synth.reference_scene_light()
+    from direct12pbrrenderer_amd.pipeline import TileSpec
+    fr = DeferredFrame(ctx, TileSpec(0, 0, W2, H2, W2, H2, 0), g2, light1, job.lut, LUT_RES, job.env, ENV_SIZE, ENV_MIPS)
+    gb2 = synth.gbuffer_tile(0, 0, W2, H2, W2, H2)
+    fr.upload_gbuffer(gb2)
+    fr.set_prev_luminance(0.18)
+    for _ in range(60):
+        fr.render()
+    shade_ms = time_batch(fr.shade)
+    frame_ms = time_batch(fr.render, 20)
+    px2 = W2 * H2
+    algo = BYTES_PER_PX["shade"] * px2
+    prof = load_profile("pmc_cfg2_latest.json", px2)
+    v = kernel_entry(prof, "k_deferred_shade", ("FETCH_SIZE", "WRITE_SIZE"))
+    traffic = int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024) if v else None
+    c2 = {"workload": "1920x1080 synthetic G-buffer (SURVEY 8d, roughness [48,255]), 1 point light (the reference scene's light_1) + IBL: the deferred shade alone",
+          "shade_ms": round(shade_ms, 4), "value": round(px2 / shade_ms / 1e3, 1), "unit": "Mpixel/s", "frame_ms_all_passes": round(frame_ms, 4),
+          "roofline": {"bound": "hbm", "achieved": round(algo / (shade_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(algo / (shade_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(algo), "traffic": traffic,
+                       "traffic_over_algorithmic": round(traffic / algo, 2) if traffic else None,
+                       "traffic_GBps": round(traffic / (shade_ms * 1e-3) / 1e9, 1) if traffic else None,
+                       "traffic_source": "profiles/pmc_cfg2_latest.json (tools/pmc_cfg.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections), stamp-checked against shade.hip"
+                                         if traffic else "no counter profile of this shade.hip committed",
+                       "kernel_limited_by": "texture addresser / L1 (the IBL footprint gathers): DESIGN.md section 4"}}
+    if v and prof:
+        for k in ("TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum", "TCC_HIT_sum", "TCC_MISS_sum", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"):
+            if k in v:
+                c2["roofline"].setdefault("counters", {})[k] = v[k]
+    if cpu:
+        lut_np = job.lut.cpu().view(torch.int16).numpy().view(np.float16)
+        env_np = job.env.cpu().view(torch.int16).numpy().view(np.float16)
+
+        def shade_cpu():
+            cl = orc.cluster_build(g2)
+            orc.cluster_cull(g2, light1, cl)
+            orc.deferred_shade(g2, Tile(0, 0, W2, H2, W2, H2), gb2, lut_np, env_np, ENV_SIZE, ENV_MIPS, cl, light1)
+        dt = cpu_median(shade_cpu)
+        c2["cpu_baseline"] = {"value": round(px2 / dt / 1e6, 2), "unit": "Mpixel/s", "ms": round(dt * 1e3, 1), "cores": orc.num_threads(), "kind": "port",
+                              "sample": "the whole 1920x1080 frame: cluster build + cull + deferred shade (oracle, OpenMP), inputs synthesised outside the clock, median of 3"}
+    out["cfg2_1080p_1_light"] = c2
+    del fr
+    dev_empty_cache()
+
+    # ---- cfg3: 512^2 cube, GGX prefilter (5 mips, 1 024 spp) + SH9
+    sky_mips = int(np.log2(ENV_SIZE)) + 1
+    sky = ctx.upload(job.sky_np)
+    ctx.cube_gen_mips(sky, ENV_SIZE, sky_mips)
+    envbuf = ctx.prefilter_env(sky, ENV_SIZE, sky_mips, ENV_SIZE, ENV_MIPS)
+    texels = 6 * sum((ENV_SIZE >> m) ** 2 for m in range(ENV_MIPS))
+    ms_f = time_batch(lambda: ctx.prefilter_env(sky, ENV_SIZE, sky_mips, ENV_SIZE, ENV_MIPS, out=envbuf), 5)
+    sky_h = sky.half().float()   # what the reference's BC6H_UF16 sky assets decode to: the kernel then samples its exact half copy
+    ms_h = time_batch(lambda: ctx.prefilter_env(sky_h, ENV_SIZE, sky_mips, ENV_SIZE, ENV_MIPS, out=envbuf), 5)
+    shbuf = ctx.empty((28,), torch.float32)
+    ms_sh = time_batch(lambda: ctx.sh9_project(sky, ENV_SIZE, sky_mips, out=shbuf), 10)
+    sh_bytes = 6 * ENV_SIZE * ENV_SIZE * 16
+    c3 = {"workload": "512^2 fp32 RGBA cube (SURVEY 8d sky): GGX prefilter, 5 mips x 1 024 samples per texel (env_map_gen.hlsl), + SH9 projection (deterministic quadrature)",
+          "prefilter_fp32_source": {"ms": round(ms_f, 3), "Gsamples_per_s_reference_equivalent": round(texels * 1024 / ms_f / 1e6, 2), "bound": "texture addresser (L2-resident gathers)"},
+          "prefilter_half_representable_source": {"ms": round(ms_h, 3), "Gsamples_per_s_reference_equivalent": round(texels * 1024 / ms_h / 1e6, 2), "bound": "FP32 VALU issue",
+                                                  "note": "every reference sky asset is BC6H_UF16: its texels are half values"},
+          "reference_samples": texels * 1024,
+          "sh9": {"ms": round(ms_sh, 4), "GBps": round(sh_bytes / ms_sh / 1e6, 1), "frac_of_8TBps": round(sh_bytes / ms_sh / 1e6 / HBM_PEAK_GBS, 4),
+                  "bound": "launch latency (two dependent launches over 25 MB)"}}
+    if cpu:
+        sky_np = sky.cpu().numpy()
+        rng = np.random.default_rng(7)
+        n_s = 1024
+        picks = {m: rng.integers(0, 6 * (ENV_SIZE >> m) ** 2, n_s).astype(np.uint32) for m in range(ENV_MIPS)}
+        orc.prefilter_env_texels(sky_np, ENV_SIZE, sky_mips, ENV_SIZE, ENV_MIPS, 1, picks[1][:256])   # warm-up
+        est = 0.0
+        for m in range(ENV_MIPS):   # each mip's sample scaled to the mip's texel count (the shader loops 1 024 times per texel on every mip)
+            t0 = time.perf_counter()
+            orc.prefilter_env_texels(sky_np, ENV_SIZE, sky_mips, ENV_SIZE, ENV_MIPS, m, picks[m])
+            est += (time.perf_counter() - t0) / n_s * 6 * (ENV_SIZE >> m) ** 2
+        c3["prefilter_fp32_source"]["cpu_baseline"] = {"value": round(texels * 1024 / est / 1e9, 3), "unit": "Gsamples/s (reference-equivalent)",
+                                                       "ms_estimated_whole_config": round(est * 1e3, 1), "cores": orc.num_threads(), "kind": "port",
+                                                       "sample": f"{n_s} random texels of each of the 5 mips (orc_prefilter_env_texels, OpenMP), each mip's time scaled to its texel count"}
+        dt = cpu_median(lambda: orc.sh9_project(sky_np, ENV_SIZE))
+        c3["sh9"]["cpu_baseline"] = {"value": round(sh_bytes / dt / 1e9, 2), "unit": "GB/s", "ms": round(dt * 1e3, 2), "cores": orc.num_threads(), "kind": "port",
+                                     "sample": "the whole 512^2 cube (orc_sh9_project quadrature, OpenMP), median of 3"}
+    out["cfg3_prefilter_sh9"] = c3
+    del sky, sky_h, envbuf
+    dev_empty_cache()
+
+    # ---- the reference's own operating point (App.h:77-78, Asset/Scene/main.json, D3D12Device.cpp:993-1003) through libpbr_host.so
+    try:
+        import tempfile
+        from direct12pbrrenderer_amd.host import HostRenderer
+        WR, HR = 1440, 960
+        recs = np.load(os.path.join(ROOT, "tests", "golden", "scene_lights.npz"))   # the 8 light records of main.json (data; tests/golden/make_scene_lights.py)
+        gbr = synth.gbuffer_tile(0, 0, WR, HR, WR, HR)
+        rp = {"workload": "1440x960 (the reference's default target, App.h:77-78), reference camera, the 8 point lights of Asset/Scene/main.json through the scene-file "
+                          "reader + CPU light cull, LUT 512^2, env 512^2 x 5, synthetic G-buffer; every pass of the frame graph, fence wait per frame (D3D12Device.cpp:993-1003)"}
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "main.json")
+            with open(path, "w") as f:
+                f.write(scene.scene_file_text(recs))
+            for key, fused in (("dispatch_by_dispatch", False), ("fused_passes", True)):
+                r = HostRenderer(ctx.device if hasattr(ctx, "device") else 0, WR, HR, ENV_SIZE, LUT_RES)
+                try:
+                    r.set_fused(fused)
+                    r.set_skybox(job.sky_np, ENV_SIZE)
+                    r.load_scene_lights(path)
+                    r.set_gbuffer(gbr)
+                    r.set_initial_luminance(0.18)
+                    r.render()                      # the one-shot passes (env prefilter, LUT) run here
+                    r.render_n(100)                 # clocks up
+                    n0 = r.dispatch_count()
+                    ms = min(r.render_n(100) for _ in range(3))
+                    rp[key] = {"ms_per_frame": round(ms, 4), "Mpixel_per_s": round(WR * HR / ms / 1e3, 1), "dispatches_per_frame": n0}
+                finally:
+                    r.close()
+        out["reference_operating_point"] = rp
+    except Exception as e:   # noqa: BLE001 — reporting only
+        out["reference_operating_point"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def workload_config(job, r, settle):
     spec, world, rows, cols = r["spec"], job.world, r["rows"], r["cols"]
     if world == 1:
@@ -1131,6 +1307,12 @@ def main():
             out["shade_ms_by_path"] = shade_paths_ab(job, res)
         except Exception as e:   # noqa: BLE001 — reporting only
             out["shade_ms_by_path"] = {"error": f"{type(e).__name__}: {e}"}
+
+    if world == 1 and not a.no_configs and not DRY:
+        try:
+            out["configs"] = configs_block(job)
+        except Exception as e:   # noqa: BLE001 — reporting only
+            out["configs"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- the drop-in path: the same workload driven by the C++ pass graph
     # (optional legs from here on: an exception on this rank is recorded, not raised — the contract line above is complete, and a

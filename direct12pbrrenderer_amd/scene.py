@@ -180,3 +180,23 @@ def sh_pack_struct(arr28):
     a = np.asarray(arr28, dtype=f32).reshape(28)
     C.memmove(C.byref(p), a.ctypes.data, 112)
     return p
+
+
+def scene_file_text(recs, extra_members=True):
+    """A scene file in the reference serializer's shape (Serialization.h:180-236: base class under "@<Base>", Vector3 as {x, y, z})
+    holding these light records (dict-like of arrays: name, translation, rotation, scale, color, radius, intensity) — what
+    pbrh_load_scene_lights reads; generated input, not the reference's asset."""
+    import json
+
+    def v(a):
+        return {"x": float(a[0]), "y": float(a[1]), "z": float(a[2])}
+    lights = [{"@SceneObject": {"mName": str(recs["name"][i]), "mTranslation": v(recs["translation"][i]),
+                                "mRotation": v(recs["rotation"][i]), "mScale": v(recs["scale"][i])},
+               "mColor": v(recs["color"][i]), "mRadius": float(recs["radius"][i]), "mIntensity": float(recs["intensity"][i])}
+              for i in range(len(recs["radius"]))]
+    doc = {"@IResource": None, "mSceneLight": lights}
+    if extra_members:   # members of the file the light path must skip over
+        doc["mSceneModel"] = [{"@SceneObject": {"mName": "m\u00e9sh \"0\"", "mTranslation": v([0, 0, 0]), "mRotation": v([0, 90, 0]),
+                                                "mScale": v([0.1, 0.1, 0.1])}, "mModelFilePath": "Asset/Model/x.json"}]
+        doc["mSkyBoxPath"] = "Asset/SkyBox/none"
+    return json.dumps(doc, indent=1)

@@ -74,19 +74,5 @@ def reference_scene_lights():
 
 
 def scene_json_text(recs, extra_members=True):
-    """A scene file in the reference serializer's shape (Serialization.h:180-236: base class under "@<Base>", Vector3 as
-    {x, y, z}) holding these light records — generated test input, not the reference's asset."""
-    import json
-
-    def v(a):
-        return {"x": float(a[0]), "y": float(a[1]), "z": float(a[2])}
-    lights = [{"@SceneObject": {"mName": str(recs["name"][i]), "mTranslation": v(recs["translation"][i]),
-                                "mRotation": v(recs["rotation"][i]), "mScale": v(recs["scale"][i])},
-               "mColor": v(recs["color"][i]), "mRadius": float(recs["radius"][i]), "mIntensity": float(recs["intensity"][i])}
-              for i in range(len(recs["radius"]))]
-    doc = {"@IResource": None, "mSceneLight": lights}
-    if extra_members:   # members of the file the light path must skip over
-        doc["mSceneModel"] = [{"@SceneObject": {"mName": "mésh \"0\"", "mTranslation": v([0, 0, 0]), "mRotation": v([0, 90, 0]),
-                                                "mScale": v([0.1, 0.1, 0.1])}, "mModelFilePath": "Asset/Model/x.json"}]
-        doc["mSkyBoxPath"] = "Asset/SkyBox/none"
-    return json.dumps(doc, indent=1)
+    """A scene file in the reference serializer's shape holding these light records (direct12pbrrenderer_amd/scene.py)."""
+    return scene.scene_file_text(recs, extra_members)

@@ -213,14 +213,17 @@ def test_host_graph_frame_matches_c_abi_pipeline_and_oracle(host, ctx, orc):
 
 
 @pytest.mark.gpu
-def test_host_graph_renders_the_reference_scene_lights(host, orc, tmp_path):
+@pytest.mark.parametrize("W,H,ENV,LUT", [(640, 360, 32, 64), (1440, 960, 512, 512)])
+def test_host_graph_renders_the_reference_scene_lights(host, orc, tmp_path, W, H, ENV, LUT):
     """the 8 lights of the reference's Asset/Scene/main.json (tests/golden/scene_lights.npz), read from a scene file
-    by the C++ host (pbrh_load_scene_lights -> SceneLight presets -> Scene::CullLight -> ClusteredPass), light a 640x360 frame;
-    the HDR target after shade + bloom, the adapted luminance and the LDR image are compared with the oracle fed the PointLight[]
-    records the CPU test pins (tests/test_host.py::test_reference_scene_lights_reach_the_light_buffer_verbatim)."""
+    by the C++ host (pbrh_load_scene_lights -> SceneLight presets -> Scene::CullLight -> ClusteredPass), light a frame; the HDR
+    target after shade + bloom, the adapted luminance and the LDR image are compared with the oracle fed the PointLight[]
+    records the CPU test pins (tests/test_host.py::test_reference_scene_lights_reach_the_light_buffer_verbatim).
+    1440x960 / env 512^2 / LUT 512^2 = THE REFERENCE'S OWN OPERATING POINT (Engine/Include/App.h:77-78, DeferredPipeline.h:80,85): its
+    default target, its table sizes, its scene's lights, the reference camera, the fence per frame (D3D12Device.cpp:993-1003), every
+    pass dispatch by dispatch through libpbr_host.so — the whole 1.38-Mpixel frame against the oracle."""
     from direct12pbrrenderer_amd import scene
     from direct12pbrrenderer_amd.structs import LIGHT_DTYPE, Tile
-    W, H, ENV, LUT = 640, 360, 32, 64
     recs = common.reference_scene_lights()
     path = tmp_path / "main.json"
     path.write_text(common.scene_json_text(recs))
