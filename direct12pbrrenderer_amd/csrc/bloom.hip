@@ -463,14 +463,17 @@ __global__ __launch_bounds__(NT, 4) void k_blur_hv(const pbr_half* __restrict__ 
         for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += NT) (&sh_hist[0][0])[i] = 0u;
     }
     // the level's constant alpha through the H pass (+ the second input's), its fp16 store, and the V pass
-    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[0].w);
-    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[0].w);
+    // (read at a texel the launch's rectangle depends on: with a rectangle (tiled bloom) the producer of `in` was itself run on a
+    //  rectangle and left texel 0 of the level untouched; M_UP: `in` is the coarser level.  No rectangle: texel 0, as ever)
+    const size_t a_at = MODE == M_UP ? (size_t)min(tr.my0 >> 1, ih - 1) * iw + min(tr.mx0 >> 1, iw - 1) : (size_t)0;
+    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[a_at].w);
+    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[(size_t)min(tr.my0, oh - 1) * ow + min(tr.mx0, ow - 1)].w);
     const h16 alpha_t = to_half_rn(alpha_h);
     const float alpha_v = gauss9_const((float)alpha_t);
     // 1-D grid over tiles; the histogram instance is launched with fewer blocks than tiles (each walks several) so
     // that the per-block flush of 256 global atomics stays rare
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int x0 = (TAIL != 0 ? tr.tx0 + tile % tiles_x : tile % tiles_x) * TW, y0 = (TAIL != 0 ? tr.ty0 + tile / tiles_x : tile / tiles_x) * TH;
+    const int x0 = (tr.tx0 + tile % tiles_x) * TW, y0 = (tr.ty0 + tile / tiles_x) * TH;   // (TAIL 0 without a rectangle: tx0 = ty0 = 0)
     const int x = x0 + lane;
     // the HDR texels the merge will need: in flight from the start
     H4 hdr_in[PER_O];
@@ -684,8 +687,10 @@ __global__ __launch_bounds__(512, TH == 16 ? 6 : 4) void k_blur_up_wide(const pb
     if (TAIL == 2) {
         for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += NT) (&sh_hist[0][0])[i] = 0u;
     }
-    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[0].w);
-    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[0].w);
+    // (read at a texel the launch's rectangle depends on: see k_blur_hv)
+    const size_t a_at = (size_t)min(tr.my0 >> 1, ih - 1) * iw + min(tr.mx0 >> 1, iw - 1);
+    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[a_at].w);
+    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[(size_t)min(tr.my0, oh - 1) * ow + min(tr.mx0, ow - 1)].w);
     const h16 alpha_t = to_half_rn(alpha_h);
     const float alpha_v = gauss9_const((float)alpha_t);
     const float a0w = (float)to_half_rn(alpha_v);   // alpha of the A0 texel the separate V pass would have stored
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(512, TH == 16 ? 6 : 4) void k_blur_up_wide(const pb
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int x0 = (TAIL != 0 ? tr.tx0 + tile % tiles_x : tile % tiles_x) * TW, y0 = (TAIL != 0 ? tr.ty0 + tile / tiles_x : tile / tiles_x) * TH;
+    const int x0 = (tr.tx0 + tile % tiles_x) * TW, y0 = (tr.ty0 + tile / tiles_x) * TH;   // (TAIL 0 without a rectangle: tx0 = ty0 = 0)
     const int xv = x0 + vc, rbase = vg * PER_O;
     TSTAMP(0);
     H4 hdr_in[PER_O];
@@ -914,8 +919,10 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_poly(const pbr_half* __restr
     if (TAIL == 2) {
         for (int i = t; i < NW * PBR_HISTOGRAM_BINS; i += NT) (&sh_hist[0][0])[i] = 0u;
     }
-    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[0].w);
-    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[0].w);
+    // (read at a texel the launch's rectangle depends on: see k_blur_hv)
+    const size_t a_at = (size_t)min(tr.my0 >> 1, ih - 1) * iw + min(tr.mx0 >> 1, iw - 1);
+    float alpha_h = gauss9_const((float)reinterpret_cast<const H4*>(in)[a_at].w);
+    if (DUAL) alpha_h = alpha_h + gauss9_const((float)reinterpret_cast<const H4*>(in2)[(size_t)min(tr.my0, oh - 1) * ow + min(tr.mx0, ow - 1)].w);
     const h16 alpha_t = to_half_rn(alpha_h);
     const float alpha_v = gauss9_const((float)alpha_t);
     const float a0w = (float)to_half_rn(alpha_v);
@@ -925,7 +932,7 @@ __global__ __launch_bounds__(512, 4) void k_blur_up_poly(const pbr_half* __restr
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int x0 = (TAIL != 0 ? tr.tx0 + tile % tiles_x : tile % tiles_x) * TW, y0 = (TAIL != 0 ? tr.ty0 + tile / tiles_x : tile / tiles_x) * TH;
+    const int x0 = (tr.tx0 + tile % tiles_x) * TW, y0 = (tr.ty0 + tile / tiles_x) * TH;   // (TAIL 0 without a rectangle: tx0 = ty0 = 0)
     const int xv = x0 + vc, rbase = vg * PER_O;
     H4 hdr_in[PER_O];
     const bool in_mx = TAIL != 0 && xv >= tr.mx0 && xv < tr.mx1;
@@ -1293,7 +1300,12 @@ static pbr_status bloom_final(pbr_ctx* ctx, const pbr_half* b0, pbr_half* hdr, u
 
 // Levels 1..4 of BloomPass::Execute from a filled level 1 of chain A: the three downsample pairs and the three
 // upsample-add pairs (DeferredPipeline.cpp:428-540).  *res = where the finished level 1 lives (chain A or B).
-static pbr_status bloom_pyramid(pbr_ctx* ctx, uint32_t w, uint32_t h, pbr_half* A, pbr_half* B, const pbr_half** res_out) {
+// need0 (optional): the rectangle {x, y, w, h} of level 0 the caller will merge.  The up-pass of level l is then run only on the tiles
+// of level l the finished image inside need0 depends on — the rectangle shrinks towards need0 / 2^l as the remaining filter support
+// does (a tiled frame's bloom works on the tile +- 256 px, but only the DOWN-pass needs that apron in full: SURVEY 8e's "cheaper
+// apron").  Whole tiles are computed, so every texel inside the rectangles is what the full pass computes: the merged interior is
+// bit-identical.  Texels of the up-levels outside them are left as they were (the chains are scratch).
+static pbr_status bloom_pyramid(pbr_ctx* ctx, uint32_t w, uint32_t h, pbr_half* A, pbr_half* B, const pbr_half** res_out, const uint32_t* need0 = nullptr) {
     auto a = [&](uint32_t l) { return A + 4 * pbr_bloom_level_offset(w, h, l); };
     auto b = [&](uint32_t l) { return B + 4 * pbr_bloom_level_offset(w, h, l); };
     auto W = [&](uint32_t l) { return w >> l; };
@@ -1314,11 +1326,27 @@ static pbr_status bloom_pyramid(pbr_ctx* ctx, uint32_t w, uint32_t h, pbr_half* 
             if ((r = pbr_blur_v(ctx, b(lo), W(lo), H(lo), a(lo), W(lo), H(lo)))) return r;
         }
     }
+    // rectangles of the up-levels (level coordinates): level 1's result is read by the merge within need0 / 2 +- 3 texels (nine taps one
+    // level-0 texel apart + the bilinear footprint); level l's up-pass reads the level below within +- 4 of its own taps, halved, + the
+    // bilinear footprint.  Margins are rounded up: a superset costs a tile at most
+    uint32_t need[PBR_BLOOM_MIPS][4];
+    static const bool shrink = pbr::knob_int("PBR_BLOOM_SHRINK", 1) != 0;
+    const bool use_need = need0 != nullptr && shrink;
+    if (use_need) {
+        int x0 = (int)need0[0], y0 = (int)need0[1], x1 = (int)(need0[0] + need0[2]), y1 = (int)(need0[1] + need0[3]);
+        for (uint32_t l = 1; l < PBR_BLOOM_MIPS; l++) {
+            x0 = (x0 - 4) / 2 - 2; y0 = (y0 - 4) / 2 - 2; x1 = (x1 + 4 + 1) / 2 + 2; y1 = (y1 + 4 + 1) / 2 + 2;   // (C division of a negative numerator rounds towards 0: clipped below anyway)
+            const int cx0 = x0 < 0 ? 0 : x0, cy0 = y0 < 0 ? 0 : y0, cx1 = x1 > (int)W(l) ? (int)W(l) : x1, cy1 = y1 > (int)H(l) ? (int)H(l) : y1;
+            need[l][0] = (uint32_t)cx0; need[l][1] = (uint32_t)cy0; need[l][2] = (uint32_t)(cx1 - cx0); need[l][3] = (uint32_t)(cy1 - cy0);
+            x0 = cx0; y0 = cy0; x1 = cx1; y1 = cy1;
+        }
+    }
     const pbr_half* res = a(PBR_BLOOM_MIPS - 1);
     for (int i = PBR_BLOOM_STEP - 1; i >= 0; i--) {   // upsample: V(H(lower) + H(upper))
         const uint32_t up = (uint32_t)i + 1;
         if (exact(up)) {
-            if ((r = launch_hv<M_UP, true, 0>(ctx, res, W(up + 1), H(up + 1), a(up), b(up), W(up), H(up), W(up), nullptr, 0.0f, 0.0f, nullptr))) return r;
+            if ((r = launch_hv<M_UP, true, 0>(ctx, res, W(up + 1), H(up + 1), a(up), b(up), W(up), H(up), W(up), nullptr, 0.0f, 0.0f, nullptr,
+                                              use_need ? need[up] : nullptr))) return r;
             res = b(up);
         } else {
             if ((r = pbr_bloom_upsample_add(ctx, a(up), W(up), H(up), res, W(up + 1), H(up + 1), b(up)))) return r;
@@ -1387,7 +1415,7 @@ pbr_status pbr_bloom_tiled(pbr_ctx* ctx, pbr_half* hdr, uint32_t hdr_pitch, cons
         return pbr::fail(ctx, PBR_ERR_UNSUPPORTED, "pbr_bloom_tiled: the extended tile must be even and <= 8192 on a side");
     const pbr_half* res = nullptr;
     pbr_status r;
-    if ((r = bloom_pyramid(ctx, ew, eh, A, B, &res))) return r;
+    if ((r = bloom_pyramid(ctx, ew, eh, A, B, &res, merge_rect))) return r;
     const uint32_t origin[2] = {hdr_rect[0], hdr_rect[1]};
     if (hist256) return launch_hv<M_UP, false, 2>(ctx, res, ew >> 1, eh >> 1, nullptr, hdr, ew, eh, hdr_pitch, merge_rect, min_log, inv_range, hist256, merge_rect, origin);
     return launch_hv<M_UP, false, 1>(ctx, res, ew >> 1, eh >> 1, nullptr, hdr, ew, eh, hdr_pitch, nullptr, 0.0f, 0.0f, nullptr, merge_rect, origin);
