@@ -30,7 +30,6 @@ SIGNATURES = {
     "pbr_ctx_side_begin": (_int, [_vp]),
     "pbr_ctx_side_end": (_int, [_vp]),
     "pbr_ctx_side_join": (_int, [_vp]),
-    "pbr_ctx_set_cu_masks": (_int, [_vp, _vp, _vp, _u32]),
     "pbr_last_error": (C.c_char_p, [_vp]),
     "pbr_sync": (_int, [_vp]),
     "pbr_brdf_lut": (_int, [_vp, _u32, _vp]),
@@ -79,6 +78,11 @@ SIGNATURES = {
     "pbr_ctx_set_bloom_shader_order": (_int, [_vp, _int]),
 }
 
+# measurement entry points of the knobs build (PBR_HIP_LIB=.../libpbr_hip_knobs.so); the product library does not export them
+KNOBS_ONLY = {
+    "pbr_ctx_set_cu_masks": (_int, [_vp, _vp, _vp, _u32]),
+}
+
 _lib = None
 
 
@@ -99,5 +103,10 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in KNOBS_ONLY.items():   # present in libpbr_hip_knobs.so only (include/pbr_hip.h, last section)
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib

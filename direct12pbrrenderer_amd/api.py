@@ -99,6 +99,9 @@ class PbrContext:
         layout="low" needs side_cus to be a multiple of 32 (the same number of CUs from every XCD): anything else runs at the pace of
         the poorest XCD and is refused — the uneven layouts exist as "strided" / "per_xcd", for the measurement of exactly that;
         allow_uneven=True (tools/cu_partition.py, which measures that effect with layout "low" too) lifts the refusal."""
+        if not hasattr(self.lib, "pbr_ctx_set_cu_masks"):
+            raise PbrError("partition_cus: pbr_ctx_set_cu_masks is an entry point of the knobs build only (PBR_HIP_LIB=.../libpbr_hip_knobs.so): "
+                           "the CU partition is a measurement aid, not part of the product library (round 6)")
         if side_cus and layout == "low" and int(side_cus) % 32 and not allow_uneven:
             raise PbrError(f"partition_cus: layout 'low' takes a multiple of 32 compute units (got {side_cus}): an uneven share per XCD runs at the poorest XCD's pace")
         if not side_cus:

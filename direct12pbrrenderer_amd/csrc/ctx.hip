@@ -468,6 +468,7 @@ static pbr_status ensure_side(pbr_ctx* ctx) {
     return PBR_OK;
 }
 
+#ifdef PBR_DEBUG_KNOBS   // knobs build only since round 6 (include/pbr_hip.h, last section): tools/cu_partition.py and its test load libpbr_hip_knobs.so
 pbr_status pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const uint32_t* side_mask, uint32_t words) {
     if (!ctx) return PBR_ERR_INVALID;
     PBR_REQUIRE(ctx, !ctx->on_side && !ctx->side_pending, "pbr_ctx_set_cu_masks: side-stream work pending (pbr_ctx_side_end / _join first)");
@@ -487,6 +488,7 @@ pbr_status pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const u
     ctx->side_cu_mask.assign(side_mask ? side_mask : nullptr, side_mask ? side_mask + words : nullptr);
     return ensure_side(ctx);
 }
+#endif
 
 pbr_status pbr_ctx_side_begin(pbr_ctx* ctx) {
     if (!ctx) return PBR_ERR_INVALID;

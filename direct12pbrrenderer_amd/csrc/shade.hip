@@ -526,7 +526,12 @@ template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
 #endif
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
+#ifdef SHADE_NUM_VGPR   // experiment builds: an exact register budget (104 at SHADE_MIN_WAVES 4: four waves per SIMD and a 96-register hole for another kernel)
+#define SHADE_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SHADE_NUM_VGPR)))
+#else
+#define SHADE_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) SHADE_VGPR_ATTR void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
     extern __shared__ float4 lds_raw[];
     __shared__ uint32_t s_mip_off[16];
     const unsigned long long t_start = SHADE_NOW();
@@ -757,7 +762,10 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     const bool staged = span_x * span_y <= (uint32_t)MAX_STAGED_TILES &&   // (no lights at all: every list is one null pair)
                         plane_bytes + (size_t)span_x * span_y * PBR_CLUSTER_Z * LIST_STRIDE * sizeof(uint32_t) <= 65536;
     const int max_clusters = staged ? (int)(span_x * span_y) * PBR_CLUSTER_Z : 0;
-    const size_t lds = plane_bytes + (size_t)max_clusters * LIST_STRIDE * sizeof(uint32_t);
+    // (PBR_SHADE_LDS_PAD, knobs build: KiB of LDS a block asks for beyond its tables — 18 caps a compute unit at four 96-register blocks and leaves
+    //  128 registers per SIMD + 28 KiB of LDS free: the hole of the round-6 co-residency experiment, EXPERIMENTS.md)
+    static const size_t lds_pad = (size_t)pbr::knob_int("PBR_SHADE_LDS_PAD", 0) * 1024;
+    const size_t lds = plane_bytes + (size_t)max_clusters * LIST_STRIDE * sizeof(uint32_t) + (lds_pad <= 40960 ? lds_pad : 0);
     const dim3 blk(SHADE_BLOCK);
     if (staged && lstride == 257) hipLaunchKernelGGL((k_deferred_shade<true, 257, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);
     else if (staged) hipLaunchKernelGGL((k_deferred_shade<true, PBR_MAX_SCENE_LIGHTS + 1, F32OUT>), grid, blk, lds, ctx->stream, p, num_lights, max_clusters, rc);

@@ -157,19 +157,6 @@ void*       pbr_ctx_get_stream(const pbr_ctx* ctx);
 pbr_status  pbr_ctx_side_begin(pbr_ctx* ctx);
 pbr_status  pbr_ctx_side_end(pbr_ctx* ctx);
 pbr_status  pbr_ctx_side_join(pbr_ctx* ctx);
-/* Partition the device's compute units between the context's private stream and its side stream (throughput mode: a frame's bloom +
- * exposure tail on the side stream's CUs while the next frame's shade has the others to itself — two kernels that both want the whole
- * chip only take turns otherwise).  masks: bit i = CU i (hipExtStreamCreateWithCUMask), `words` 32-bit words each; NULL = every CU.
- * On MI355X the bits run XCD by XCD in groups of four (bits 0-3 = four CUs of XCD 0, 4-7 = of XCD 1, ... 32-35 = the next four of XCD 0),
- * and a kernel's workgroups are dealt to the XCDs in equal shares whatever their CU counts: a partition must hold the same number of CUs
- * of every XCD, and a group of four bits is honoured as a whole only — i.e. a multiple of 32 low bits — or its XCD with the fewest sets the
- * pace (measured: profiles/r04_h_cu_partition_*.txt, r04_j_cu_partition_per_xcd.txt).
- * Masked streams are created with hipExtStreamCreateWithCUMask, which takes no flags: unlike the non-blocking streams they replace, they
- * SYNCHRONISE WITH THE LEGACY NULL STREAM — any null-stream work of the process (a hipMemset, a default-stream torch op or event record)
- * serialises both partitions, so no default-stream work belongs inside a partitioned frame.
- * Recreates both streams (the context must be idle on its private stream: pbr_ctx_use_own_stream, no side work pending) and
- * waits for the device.  A context bound to a foreign stream (pbr_ctx_set_stream) keeps that stream: only the side stream is masked. */
-pbr_status  pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const uint32_t* side_mask, uint32_t words);
 /* Bloom, the two large 2x-up levels of frames above ~1.6 Mpixel (levels of >= 400 tiles of 128 x 32): by default they run in polyphase
  * form — not the shader's operation order: <= 1 fp16 ULP per stage, <= 2 for the chain — so a whole frame and a smaller tile of it (which
  * takes the shader-order kernels) agree to 2 fp16 ULP, not bit for bit.  on != 0: every level in the shader's operation order
@@ -418,6 +405,25 @@ pbr_status pbr_membench_read(pbr_ctx* ctx, const void* buf, size_t bytes, uint32
  * ctx stream) this gives the chip's sustained issue rate in wave-instructions/s for that class AND the shader clock it holds
  * under that load — the denominators bench.py's `roofline.valu` needs from the box it runs on, not from a committed file. */
 pbr_status pbr_valubench(pbr_ctx* ctx, uint32_t op, uint32_t blocks, uint32_t iters, uint64_t* stamps);
+
+/* ---- Knobs build only (libpbr_hip_knobs.so, -DPBR_DEBUG_KNOBS): measurement entry points that are NOT part of the product library.
+ * Round 6: the CU partition left the product API — measured in rounds 4-5 on four boxes it never paid (throughput mode with the
+ * partition: +0 ... +8 % frame time; EXPERIMENTS.md), and a drop-in does not carry a switch nobody should flip. ---- */
+#ifdef PBR_DEBUG_KNOBS
+/* Partition the device's compute units between the context's private stream and its side stream (throughput mode: a frame's bloom +
+ * exposure tail on the side stream's CUs while the next frame's shade has the others to itself — two kernels that both want the whole
+ * chip only take turns otherwise).  masks: bit i = CU i (hipExtStreamCreateWithCUMask), `words` 32-bit words each; NULL = every CU.
+ * On MI355X the bits run XCD by XCD in groups of four (bits 0-3 = four CUs of XCD 0, 4-7 = of XCD 1, ... 32-35 = the next four of XCD 0),
+ * and a kernel's workgroups are dealt to the XCDs in equal shares whatever their CU counts: a partition must hold the same number of CUs
+ * of every XCD, and a group of four bits is honoured as a whole only — i.e. a multiple of 32 low bits — or its XCD with the fewest sets the
+ * pace (measured: profiles/r04_h_cu_partition_*.txt, r04_j_cu_partition_per_xcd.txt).
+ * Masked streams are created with hipExtStreamCreateWithCUMask, which takes no flags: unlike the non-blocking streams they replace, they
+ * SYNCHRONISE WITH THE LEGACY NULL STREAM — any null-stream work of the process (a hipMemset, a default-stream torch op or event record)
+ * serialises both partitions, so no default-stream work belongs inside a partitioned frame.
+ * Recreates both streams (the context must be idle on its private stream: pbr_ctx_use_own_stream, no side work pending) and
+ * waits for the device.  A context bound to a foreign stream (pbr_ctx_set_stream) keeps that stream: only the side stream is masked. */
+pbr_status  pbr_ctx_set_cu_masks(pbr_ctx* ctx, const uint32_t* main_mask, const uint32_t* side_mask, uint32_t words);
+#endif
 
 #ifdef __cplusplus
 }

@@ -290,8 +290,8 @@ def test_overlapped_frame_tail_equals_the_plain_order():
 
 @pytest.mark.timeout(400)
 def test_cu_partition_renders_the_same_frames():
-    """pbr_ctx_set_cu_masks: the device's CUs split between the context's private stream and its side stream (64 CUs = 8 per XCD for
-    the side stream) — in order and in post-shade throughput mode the frames are those of the unpartitioned in-order render; and the
+    """pbr_ctx_set_cu_masks (knobs build only since round 6: the subprocesses load libpbr_hip_knobs.so): the device's CUs split between
+    the context's private stream and its side stream (64 CUs = 8 per XCD for the side stream) — in order and in post-shade throughput mode the frames are those of the unpartitioned in-order render; and the
     contract: an empty mask, or a call while side work is pending, is refused.  Own process: the masks recreate the context's streams."""
     code = r"""
 import sys, numpy as np, torch
@@ -314,9 +314,14 @@ ctx.side_end(); ctx.side_join(); ctx.sync()
 ctx.close()
 print("contract ok")
 """ % ROOT
-    r = subprocess.run(["timeout", "-k", "10", "120", sys.executable, "-c", code], capture_output=True, text=True)
+    env = dict(os.environ, PBR_HIP_LIB=os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_hip_knobs.so"))
+    r = subprocess.run(["timeout", "-k", "10", "120", sys.executable, "-c", code], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "contract ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
-    r = subprocess.run(["timeout", "-k", "10", "300", sys.executable, os.path.join(ROOT, "tools", "cu_partition.py"), "low", "0", "64"], capture_output=True, text=True)
+    # the product library refuses with a pointer to the knobs build
+    r = subprocess.run(["timeout", "-k", "10", "120", sys.executable, "-c", "import sys; sys.path.insert(0, %r)\nfrom direct12pbrrenderer_amd.api import PbrContext, PbrError\n"
+                        "c = PbrContext(0)\ntry:\n    c.partition_cus(64); print('accepted')\nexcept PbrError as e:\n    print('refused:', e)" % ROOT], capture_output=True, text=True)
+    assert r.returncode == 0 and "refused:" in r.stdout and "knobs build" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+    r = subprocess.run(["timeout", "-k", "10", "300", sys.executable, os.path.join(ROOT, "tools", "cu_partition.py"), "low", "0", "64"], capture_output=True, text=True, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("[low] side CUs")]
     assert r.returncode == 0 and len(lines) == 2 and all(l.endswith("True") for l in lines), (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
 

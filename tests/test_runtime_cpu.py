@@ -14,11 +14,21 @@ def test_library_exports_every_declared_symbol():
     from direct12pbrrenderer_amd import _lib
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "pbr_hip.h")).read()
-    declared = set(re.findall(r"\b(pbr_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 45
+    # the header's last section (#ifdef PBR_DEBUG_KNOBS) declares the measurement entry points of the knobs build: not product exports
+    knobs_section = re.search(r"#ifdef PBR_DEBUG_KNOBS\n(.*?)#endif", header, re.S)
+    assert knobs_section
+    knobs_only = set(re.findall(r"\b(pbr_[a-z0-9_]+)\s*\(", knobs_section.group(1)))
+    declared = set(re.findall(r"\b(pbr_[a-z0-9_]+)\s*\(", header.replace(knobs_section.group(0), ""))) - knobs_only
+    assert len(declared) >= 45 and knobs_only == set(_lib.KNOBS_ONLY) == {"pbr_ctx_set_cu_masks"}
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/pbr_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.SIGNATURES"
+    import ctypes
+    knobs = ctypes.CDLL(os.path.join(ROOT, "direct12pbrrenderer_amd", "libpbr_hip_knobs.so"))
+    for name in knobs_only:     # ... exported by the knobs build, absent from the product library
+        assert hasattr(knobs, name) and not hasattr(lib, name), name
+    for name in declared:
+        assert hasattr(knobs, name), f"{name} missing from the knobs build"
     assert lib.pbr_runtime_error() is None          # torch first, then the library: one ROCm installation
 
 

@@ -2,7 +2,8 @@
 average + tone-map on the side stream's CUs while frame i + 1's cluster pass + shade have the others to themselves.
 python tools/cu_partition.py [side CU counts ...]   (default 0 24 32 40 48 64; 0 = no partition: the priority side stream)
 Prints ms per frame in order (on the main stream's CUs alone) and in post-shade throughput mode, and checks that the overlapped
-frames are the in-order frames."""
+frames are the in-order frames.
+pbr_ctx_set_cu_masks is an entry point of the KNOBS build only (round 6): run with PBR_HIP_LIB=$PWD/direct12pbrrenderer_amd/libpbr_hip_knobs.so."""
 import os
 import sys
 
