@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "pbr_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef PBR_DEBUG_KNOBS\n.*?#endif", "", text, flags=re.S)   # the knobs build's measurement entry points: not product exports (tests/test_runtime_cpu.py)
     return sorted(set(re.findall(r"\b(pbr_[a-z0-9_]+)\s*\(", text)))
 
 
