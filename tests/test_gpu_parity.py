@@ -1374,3 +1374,64 @@ def test_frame_8k_cfg5_full_size_band_properties_and_tiles(ctx, orc, ibl):
         assert d.max() <= 2 and (d > 0).mean() < 2e-3, (halo, d.max(), (d > 0).mean())
         assert t.hist.cpu().numpy().view(np.uint32).sum() == s.w * s.h
         del t
+
+
+_SHADE_SCHEDULE = r"""
+import hashlib, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import common
+from direct12pbrrenderer_amd.api import PbrContext
+from oracle import binding as orc
+ctx = PbrContext(0)
+sky, env, lut, sh = common.small_ibl(orc)
+up = lambda a: ctx.upload(np.ascontiguousarray(a, dtype=np.float16).view(np.uint16)).view(torch.float16)
+lut_d, env_d = up(lut), ctx.env_pad(up(env), common.ENV_SIZE, common.ENV_MIPS)
+out = []
+for (w, h, full, x0, y0, n) in %r:
+    cam, g, lights, gb, tile = common.shade_scene(w, h, n, sh, full=full, x0=x0, y0=y0)
+    cl = orc.cluster_build(g); orc.cluster_cull(g, lights, cl)
+    gbd = {k: ctx.upload(v) for k, v in gb.items()}
+    hdr = ctx.zeros((h, w, 4), torch.float16)
+    ctx.deferred_shade(g, tile, gbd, w, lut_d, lut.shape[0], env_d, common.ENV_SIZE, common.ENV_MIPS, ctx.upload(cl), ctx.upload(lights) if n else None, n, hdr, w)
+    ctx.sync()
+    got = hdr.cpu().view(torch.int16).numpy()
+    line = hashlib.sha1(got.tobytes()).hexdigest()
+    if %r:   # the oracle on the same inputs (stencil-masked pixels keep the zeros of the buffer on both sides)
+        want, _ = orc.deferred_shade(g, tile, gb, lut, env, common.ENV_SIZE, common.ENV_MIPS, cl, lights)
+        d = common.half_ulp_diff(got.view(np.float16)[..., :3], want[..., :3])
+        assert (d > 2).mean() <= 1e-3 and np.isfinite(got.view(np.float16).astype(np.float32)).all(), (w, h, int(d.max()), float((d > 2).mean()))
+    out.append(line)
+print("shade schedule", " ".join(out))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_deferred_shade_output_does_not_depend_on_the_launch_schedule():
+    """Round 6: the shade sizes its blocks by the render target (rows per long block: 8 where that makes >= 1.3 generations of resident
+    blocks, 2 .. 7 below — shade.hip, shade_launch).  Per-pixel arithmetic must not know: the same frames shaded by the product library
+    (rows by rule) and by the knobs build with every row count forced (PBR_SHADE_ROWS_BIG = 1 .. 8, and another two-zone split) are
+    bit-identical — odd sizes (last block row / column partial), a tile of a larger frame (global pixel coordinates), 0 / 1 / 256 lights;
+    and the product's frames agree with the oracle.  Own processes: the knobs are read once per process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(321, 187, None, 0, 0, 256), (1441, 97, None, 0, 0, 256), (257, 64, (1440, 960), 1100, 850, 256), (640, 360, None, 0, 0, 1), (96, 33, None, 0, 0, 0)]
+
+    def run(env_extra, check):
+        env = dict(os.environ)
+        for k in ("PBR_SHADE_ROWS_BIG", "PBR_SHADE_ROWS_SMALL", "PBR_SHADE_BIGFRAC", "PBR_HIP_LIB"):
+            env.pop(k, None)
+        if env_extra:
+            env.update(env_extra)
+            env["PBR_HIP_LIB"] = os.path.join(root, "direct12pbrrenderer_amd", "libpbr_hip_knobs.so")
+        r = subprocess.run(["timeout", "-k", "10", "600", sys.executable, "-c", _SHADE_SCHEDULE % (root, os.path.join(root, "tests"), cases, check)],
+                           capture_output=True, text=True, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("shade schedule")]
+        assert r.returncode == 0 and lines, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+        return lines[-1]
+
+    product = run(None, True)
+    for rows in (1, 2, 3, 5, 8):
+        assert run({"PBR_SHADE_ROWS_BIG": str(rows)}, False) == product, f"rows {rows}: another image"
+    assert run({"PBR_SHADE_ROWS_BIG": "4", "PBR_SHADE_BIGFRAC": "0.5", "PBR_SHADE_ROWS_SMALL": "3"}, False) == product
