@@ -132,3 +132,66 @@ def test_ranks_match_single_gpu_frame(ctx, ibl, world, layout, halo, tile_w, til
         a, b = r["ldr"], full_ldr[y0:y0 + h, x0:x0 + w]
         for k in range(3):
             assert np.abs(((a >> (8 * k)) & 255).astype(np.int32) - ((b >> (8 * k)) & 255).astype(np.int32)).max() <= 1
+
+
+_SHRINK = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from direct12pbrrenderer_amd.api import PbrContext
+from direct12pbrrenderer_amd.structs import bloom_level_offset
+ctx = PbrContext(0)
+rng = np.random.default_rng(20261005)
+out = []
+for case in range(%d):
+    ew, eh = 32 * int(rng.integers(4, 40)), 32 * int(rng.integers(4, 40))          # extended tile: 5 exact mips
+    # the rank's shaded rectangle inside E and the interior it merges inside that (even origins and sizes, as tile layouts have)
+    hx, hy = 2 * int(rng.integers(0, ew // 8)), 2 * int(rng.integers(0, eh // 8))
+    hw, hh = 2 * int(rng.integers(8, (ew - hx) // 2 + 1)), 2 * int(rng.integers(8, (eh - hy) // 2 + 1))
+    mx, my = hx + 2 * int(rng.integers(0, hw // 8 + 1)), hy + 2 * int(rng.integers(0, hh // 8 + 1))
+    mw, mh = 2 * int(rng.integers(4, (hx + hw - mx) // 2 + 1)), 2 * int(rng.integers(4, (hy + hh - my) // 2 + 1))
+    hdr_np = (rng.random((hh, hw, 4), dtype=np.float32) * 3.0).astype(np.float16)
+    hdr_np[..., 3] = 1.0
+    l1 = (rng.random(((eh // 2) * (ew // 2), 4), dtype=np.float32) * 2.0).astype(np.float16)
+    l1[:, 3] = 1.0
+    hdr = ctx.upload(hdr_np.view(np.uint16)).view(torch.float16)
+    A, B = ctx.alloc_bloom_chain(ew, eh), ctx.alloc_bloom_chain(ew, eh)
+    B.fill_(777.0)                                                                    # stale chain contents must not reach the merged interior
+    o = bloom_level_offset(ew, eh, 1)
+    A[o:o + l1.shape[0]] = ctx.upload(l1.view(np.uint16)).view(torch.float16)
+    hist = ctx.zeros((256,), torch.int32)
+    ctx.bloom_tiled(hdr, hw, (hx, hy, hw, hh), ew, eh, A, B, (mx, my, mw, mh), hist)
+    ctx.sync()
+    got = hdr.cpu().view(torch.int16).numpy()
+    assert int(hist.sum()) == mw * mh, (case, int(hist.sum()), mw * mh)
+    out.append(hashlib.sha1(got.tobytes()).hexdigest()[:16] + hashlib.sha1(hist.cpu().numpy().tobytes()).hexdigest()[:8])
+print("tiled bloom", " ".join(out))
+"""
+
+
+@pytest.mark.timeout(600)
+def test_tiled_bloom_up_pass_rectangles_leave_the_merged_interior_bit_identical():
+    """Round 6: pbr_bloom_tiled runs the up-pass of levels 1-3 only on the rectangles the merged interior depends on (bloom.hip,
+    bloom_pyramid(need0): need / 2 +- margins per level, clipped, whole tiles).  40 random extended tiles (128 .. 1248 on a side), shaded
+    rectangles and merge rectangles: the HDR buffer and the interior's histogram of the product library equal, bit for bit, those of the
+    knobs build with the rectangles switched off (PBR_BLOOM_SHRINK=0: every level on the whole extended tile) — with chain B pre-filled
+    with a sentinel, so a level that reads a texel its producer skipped cannot pass by luck.  Own processes (knobs are read once)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env_extra):
+        env = dict(os.environ)
+        for k in ("PBR_BLOOM_SHRINK", "PBR_HIP_LIB"):
+            env.pop(k, None)
+        if env_extra:
+            env.update(env_extra)
+            env["PBR_HIP_LIB"] = os.path.join(root, "direct12pbrrenderer_amd", "libpbr_hip_knobs.so")
+        r = subprocess.run(["timeout", "-k", "10", "500", sys.executable, "-c", _SHRINK % (root, 40)], capture_output=True, text=True, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("tiled bloom")]
+        assert r.returncode == 0 and lines, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+        return lines[-1].split()
+
+    product, full = run(None), run({"PBR_BLOOM_SHRINK": "0"})
+    differing = [i for i, (a, b) in enumerate(zip(product[2:], full[2:])) if a != b]
+    assert not differing, f"cases {differing} differ between the shrinking rectangles and the full up-pass"
+    assert run({"PBR_BLOOM_SHRINK": "1"}) == product
