@@ -526,12 +526,8 @@ template <bool STAGED_LISTS, int LSTRIDE, bool F32OUT>
 #ifndef SHADE_MIN_WAVES
 #define SHADE_MIN_WAVES 5   // 96 VGPRs; 2 dwords of scratch per lane are spilled OUTSIDE the light loop.  Best of 4..8 measured (tools/probe_shade.py)
 #endif
-#ifdef SHADE_NUM_VGPR   // experiment builds: an exact register budget (104 at SHADE_MIN_WAVES 4: four waves per SIMD and a 96-register hole for another kernel)
-#define SHADE_VGPR_ATTR __attribute__((amdgpu_num_vgpr(SHADE_NUM_VGPR)))
-#else
-#define SHADE_VGPR_ATTR
-#endif
-__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) SHADE_VGPR_ATTR void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
+// (an exact register budget cannot be asked for: `amdgpu_num_vgpr(104)` is ignored beside the waves-per-EU bound on gfx950 — round 6, EXPERIMENTS.md)
+__global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) void k_deferred_shade(ShadeParams p, int n_lights, int max_clusters, ShadeRects rc) {
     extern __shared__ float4 lds_raw[];
     __shared__ uint32_t s_mip_off[16];
     const unsigned long long t_start = SHADE_NOW();
@@ -585,8 +581,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) SHADE_VGPR_ATTR void 
         const int tile_y1 = max(ty_a, ty_b);
         tiles_x = tile_x1 - tile_x0 + 1;
         const int n_cl = min(tiles_x * (tile_y1 - tile_y0 + 1) * PBR_CLUSTER_Z, max_clusters);   // host sized the LDS for the worst case
-        // a thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry (round 5:
-        // ~170 instructions per thread and block less than the entry-major loop it replaces; shade in frame -0.4 %, profiles/r05_ac_stage_fast.txt)
         {
             static_assert(PBR_CLUSTER_Z == 8 && PBR_MAX_LIGHTS_PER_CLUSTER == 32, "staging map");
 #ifndef PBR_EXP_STAGE_R5   // (round 5's form below: a thread per entry, n_cl / 8 rounds of ~40 instructions; kept for A/B builds)
@@ -615,6 +609,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SHADE_MIN_WAVES) SHADE_VGPR_ATTR void 
                 if (part == 0) *reinterpret_cast<uint2*>(l) = make_uint2((uint32_t)max((cnt + 1) & ~1, 2), 0u);
             }
 #else
+            // a thread owns entry (tid & 31) of cluster (tid >> 5) + 8 k: no division by the list stride, one index load per entry (round 5)
             const int j = threadIdx.x & 31;
             for (int c = threadIdx.x >> 5; c < n_cl; c += SHADE_BLOCK / 32) {
                 const int z = c & 7, t = c >> 3;

@@ -144,7 +144,7 @@ ctx = PbrContext(0)
 rng = np.random.default_rng(20261005)
 out = []
 for case in range(%d):
-    ew, eh = 32 * int(rng.integers(4, 40)), 32 * int(rng.integers(4, 40))          # extended tile: 5 exact mips
+    ew, eh = 16 * int(rng.integers(8, 80)), 16 * int(rng.integers(8, 80))          # extended tile: multiples of 16, as tile layouts make them (level 4 may be odd-sized)
     # the rank's shaded rectangle inside E and the interior it merges inside that (even origins and sizes, as tile layouts have)
     hx, hy = 2 * int(rng.integers(0, ew // 8)), 2 * int(rng.integers(0, eh // 8))
     hw, hh = 2 * int(rng.integers(8, (ew - hx) // 2 + 1)), 2 * int(rng.integers(8, (eh - hy) // 2 + 1))
@@ -172,7 +172,7 @@ print("tiled bloom", " ".join(out))
 @pytest.mark.timeout(600)
 def test_tiled_bloom_up_pass_rectangles_leave_the_merged_interior_bit_identical():
     """Round 6: pbr_bloom_tiled runs the up-pass of levels 1-3 only on the rectangles the merged interior depends on (bloom.hip,
-    bloom_pyramid(need0): need / 2 +- margins per level, clipped, whole tiles).  40 random extended tiles (128 .. 1248 on a side), shaded
+    bloom_pyramid(need0): need / 2 +- margins per level, clipped, whole tiles).  40 random extended tiles (128 .. 1264 on a side, multiples of 16), shaded
     rectangles and merge rectangles: the HDR buffer and the interior's histogram of the product library equal, bit for bit, those of the
     knobs build with the rectangles switched off (PBR_BLOOM_SHRINK=0: every level on the whole extended tile) — with chain B pre-filled
     with a sentinel, so a level that reads a texel its producer skipped cannot pass by luck.  Own processes (knobs are read once)."""

@@ -14,7 +14,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 python3 bench.py --steps 50 --warmup 5 > $out/${tag}_bench_4k.json 2> $out/${tag}_bench.err && tail -c 600 $out/${tag}_bench_4k.json && echo &&
 cd /tmp &&
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-host-graph --no-shade-paths --no-tail-overlap > $out/${tag}_stats.log 2>&1 &&
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $root/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-host-graph --no-shade-paths --no-tail-overlap --no-configs > $out/${tag}_stats.log 2>&1 &&
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   d=$out/${tag}_pmc_$(echo $c | cut -d' ' -f1)
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $root/tools/profile_stage.py all > $d.log 2>&1 || exit 1
