@@ -107,7 +107,10 @@ def parse():
                    help="N > 1 on a box without N GPUs (or without any): the real rank processes, rendezvous (gloo), tile / halo plans, candidate "
                         "fall-back, verification frames, timed loops, cfg5 record and JSON assembly with every device call replaced by a host "
                         "stand-in (bench_dryrun.py) — the orchestration of the 8-GPU launch, rehearsed where 8 processes are allowed.  Not a measurement")
-    p.add_argument("--dry-fail", default=None, help="dry run only: '<rank>:<mode>/<transport>' — that rank's set-up of that candidate raises (fall-back test)")
+    p.add_argument("--dry-fail", default=None,
+                   help="dry run only, fault injection: '<rank>:<mode>/<transport>' — that rank's set-up of that candidate raises; '<rank>:miscount' — its first "
+                        "verification frame counts one pixel too many (every rank must fall back together); '<rank>:hang' — it never arrives at its first "
+                        "all-reduce (the watchdog's --deadline must end the launch)")
     return p.parse_args()
 
 
@@ -1089,7 +1092,10 @@ def main():
     dev = local_rank if world > 1 else 0
     if DRY:
         from bench_dryrun import DryContext
-        ctx = DryContext(dist, rank, world)
+        fault = None
+        if a.dry_fail and a.dry_fail.split(":", 1)[0] == str(rank) and a.dry_fail.split(":", 1)[1] in ("miscount", "hang"):
+            fault = a.dry_fail.split(":", 1)[1]
+        ctx = DryContext(dist, rank, world, fault)
     else:
         ctx = PbrContext(dev)
     flag_dev = "cpu" if (rehearsal or DRY) else f"cuda:{dev}"

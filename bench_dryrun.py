@@ -34,8 +34,12 @@ class DryContext:
 
     torch_device = "cpu"
 
-    def __init__(self, dist, rank, world):
+    def __init__(self, dist, rank, world, fault=None):
+        """fault: None, "miscount" (this rank's first interior histogram counts one pixel too many: the verification frame of the first
+        candidate fails on every rank) or "hang" (this rank never comes back from its first histogram all-reduce: the other ranks are
+        released by their watchdog)."""
         self.dist, self.rank, self.world = dist, rank, world
+        self.fault = fault
         self.lib = _lib.load()      # host-side helpers of the real library only (pbr_halo_staging_bytes); no context is created
         self.comm_id = None
         self.calls = {}
@@ -117,6 +121,9 @@ class DryContext:
         self._n("bloom_tiled")
         if hist is not None:
             hist[1] += int(merge_rect[2]) * int(merge_rect[3])
+            if self.fault == "miscount":
+                hist[1] += 1
+                self.fault = None
 
     def _stamp(self, out, out_pitch, out_x, out_y, rect):
         x, y, w, h = (int(v) for v in rect)
@@ -162,6 +169,10 @@ class DryContext:
 
     def allreduce_hist(self, hist):
         self._n("allreduce_hist")
+        if self.fault == "hang":
+            import time
+            while True:       # a rank that never arrives: only the watchdog's deadline ends this process (and its peers')
+                time.sleep(1.0)
         self.dist.all_reduce(hist)
 
     halo_peers = staticmethod(PbrContext.halo_peers)

@@ -94,3 +94,23 @@ def test_bench_n8_dry_run_every_rank_takes_the_next_candidate_when_one_rank_fail
     for c in (d["config"], d["config"]["cfg5"]):
         assert "rccl-torch" in c["collectives"] and c["bloom_borders"] == "halo" and c["layout_rows_x_cols"] == "2x4"
         assert any("halo/capi could not be set up" in n for n in c["notes"])
+
+
+def test_bench_n8_dry_run_failed_verification_sends_every_rank_to_the_next_candidate():
+    """One rank's tile counts one pixel too many in the first verification frame: the all-reduced histogram then disagrees with the frame's
+    pixel count on EVERY rank, all eight drop the candidate together (no rank is left inside its collectives) and the next one passes."""
+    r, lines, d = _dry_run(["--dry-fail", "5:miscount", "--no-cfg5"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1 and "rccl-torch" in d["config"]["collectives"]
+    assert any("failed verification" in n and "histogram counts 66498561 pixels, frame has 66498560" in n for n in d["config"]["notes"])
+
+
+def test_bench_n8_dry_run_a_rank_that_never_arrives_ends_the_launch_at_the_deadline():
+    """A rank that never reaches a collective (here: rank 5 sleeps in front of its first histogram all-reduce) cannot be waited for: every
+    phase with collectives runs under the watchdog's deadline, each rank gives up on its own, the launch ends with a non-zero exit code
+    within the deadline (+ start-up) instead of hanging, and no half-written record is taken for a result."""
+    import time
+    t0 = time.monotonic()
+    r, lines, d = _dry_run(["--dry-fail", "5:hang", "--deadline", "15", "--no-cfg5"], timeout=240)
+    assert r.returncode != 0 and time.monotonic() - t0 < 180
+    assert "did not finish before its deadline" in r.stderr and lines == []
