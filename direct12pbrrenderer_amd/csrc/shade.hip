@@ -88,27 +88,6 @@ __device__ __forceinline__ V3 decode_octahedron(float u, float v) {
 // "Padded" env chain = the footprint layout of pbr_device.hpp::env_padded_mip_offset: entry (face, yq, xq), xq, yq in
 // [0, s], holds the four texels of the bilinear footprint whose origin is tap (xq-1, yq-1), each resolved by the
 // seamless-cube rule.  One thread per stored texel.
-#ifdef PBR_ENV_APRON   // experiment (round 6): border layout — every face with a 1-texel border, (s + 2)^2 texels, a quarter of the footprint layout's bytes
-__global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ src, pbr_half* __restrict__ dst, int s) {
-    const int sp = s + 2;
-    const size_t n = (size_t)6 * sp * sp;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    uint32_t face = (uint32_t)(t / ((size_t)sp * sp));
-    int x = (int)(t % sp) - 1, y = (int)((t / sp) % sp) - 1;
-    const bool xo = (x < 0) | (x >= s), yo = (y < 0) | (y >= s);
-    if (xo | yo) {   // same rule as pbr::cube_fetch_seamless / the oracle
-        if (xo & yo) y = clampi(y, 0, s - 1);
-        const float uu = 2.0f * ((float)x + 0.5f) / (float)s - 1.0f;
-        const float vv = 2.0f * ((float)y + 0.5f) / (float)s - 1.0f;
-        float u2, v2;
-        cube_face_uv(cube_dir_raw(face, uu, vv), face, u2, v2);
-        x = clampi((int)floorf(u2 * (float)s), 0, s - 1);
-        y = clampi((int)floorf(v2 * (float)s), 0, s - 1);
-    }
-    reinterpret_cast<H4*>(dst)[t] = reinterpret_cast<const H4*>(src)[((size_t)face * s + y) * s + x];
-}
-#else
 __global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ src, pbr_half* __restrict__ dst, int s) {
     const int sq = s + 1;
     const size_t n = (size_t)6 * sq * sq * 4;
@@ -129,7 +108,6 @@ __global__ __launch_bounds__(256) void k_env_pad(const pbr_half* __restrict__ sr
     }
     reinterpret_cast<H4*>(dst)[t] = reinterpret_cast<const H4*>(src)[((size_t)face * s + y) * s + x];
 }
-#endif
 
 // Light table in LDS, structure-of-arrays: 9 planes of LSTRIDE floats
 //   0..2 position, 3..5 color*intensity, 6..8 attenuation C0,C1,C2
@@ -450,20 +428,11 @@ __device__ __forceinline__ void shade_pixel(const ShadeParams& p, const float* l
             // footprint layout: the four texels of this tap are 32 contiguous bytes.  24-bit multiplies (every factor < 2^24;
             // v_mul_lo_u32 / v_mad_u64_u32 are multi-pass instructions) and a 32-bit byte offset from the chain's base
             // (host-checked: the padded chain is smaller than 4 GiB)
-#ifdef PBR_ENV_APRON
-            const uint32_t sp = (uint32_t)s + 2u;
-            const uint32_t o = __umul24(__umul24(face, sp) + (uint32_t)((int)fly + 1), sp) + (uint32_t)((int)flx + 1);
-            const char* q = reinterpret_cast<const char*>(p.env) + (mip_off + o) * 8u;
-            Foot f;
-            f.r0 = *reinterpret_cast<const H4x2*>(q);
-            f.r1 = *reinterpret_cast<const H4x2*>(q + sp * 8u);
-#else
             const uint32_t o = __umul24(__umul24(face, (uint32_t)sq) + (uint32_t)((int)fly + 1), (uint32_t)sq) + (uint32_t)((int)flx + 1);
             const char* q = reinterpret_cast<const char*>(p.env) + (mip_off + o * 4u) * 8u;
             Foot f;
             f.r0 = *reinterpret_cast<const H4x2*>(q);
             f.r1 = *reinterpret_cast<const H4x2*>(q + 16);
-#endif
             const float wy1 = fy * wl, wy0 = wl - wy1;         // (1 - fy) wl, fy wl
             f.w10 = fx * wy0; f.w00 = wy0 - f.w10;             // (1 - fx)(1 - fy) wl, fx (1 - fy) wl
             f.w11 = fx * wy1; f.w01 = wy1 - f.w11;
@@ -689,15 +658,9 @@ pbr_status pbr_env_pad(pbr_ctx* ctx, const pbr_half* env, uint32_t size, uint32_
     PBR_REQUIRE(ctx, size >= 1 && size <= 8192 && mips >= 1 && mips <= 16 && (size >> (mips - 1)) >= 1, "pbr_env_pad: bad size/mips");
     for (uint32_t m = 0; m < mips; m++) {
         const int s = (int)(size >> m);
-#ifdef PBR_ENV_APRON
-        const size_t n = (size_t)6 * (s + 2) * (s + 2);
-        hipLaunchKernelGGL(k_env_pad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                           env + 4 * cube_mip_offset(size, m), out_padded + 4 * cube_border_mip_offset(size, m), s);
-#else
         const size_t n = (size_t)6 * (s + 1) * (s + 1) * 4;
         hipLaunchKernelGGL(k_env_pad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                            env + 4 * cube_mip_offset(size, m), out_padded + 4 * env_padded_mip_offset(size, m), s);
-#endif
         pbr_status r = launched(ctx, "k_env_pad");
         if (r) return r;
     }
@@ -743,11 +706,7 @@ static pbr_status shade_launch(pbr_ctx* ctx, const pbr_global* g, const pbr_tile
     p.x0 = tile->x0; p.y0 = tile->y0; p.w = tile->w; p.h = tile->h; p.full_w = tile->full_w; p.full_h = tile->full_h;
     p.A = gb->A; p.B = gb->B; p.C = gb->C; p.depth = gb->depth; p.stencil = gb->stencil; p.pitch = gb->pitch;
     p.lut = lut; p.lut_res = lut_res; p.env = env; p.env_size = env_size; p.env_mips = env_mips;
-#ifdef PBR_ENV_APRON
-    for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)cube_border_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
-#else
     for (uint32_t m = 0; m < 16; m++) p.env_mip_off[m] = (uint32_t)env_padded_mip_offset(env_size, m < env_mips ? m : env_mips - 1);
-#endif
     p.clusters = clusters; p.lights = lights; p.hdr = hdr; p.hdr_pitch = hdr_pitch; p.hdr_f32 = hdr_f32;
     // schedule (see the kernel): long blocks first, short ones for the tail
     static const float big_frac = pbr::knob_float("PBR_SHADE_BIGFRAC", 0.92f);   // re-swept after the per-pixel trims (the knobs build): 0.9-0.95 with 1-row tail blocks beats 0.85 / 2 by ~0.4 %
