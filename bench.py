@@ -820,7 +820,7 @@ def configs_block(job):
                        "traffic_GBps": round(traffic / (shade_ms * 1e-3) / 1e9, 1) if traffic else None,
                        "traffic_source": "profiles/pmc_cfg2_latest.json (tools/pmc_cfg.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections), stamp-checked against shade.hip"
                                          if traffic else "no counter profile of this shade.hip committed",
-                       "kernel_limited_by": "texture addresser / L1 (the IBL footprint gathers): DESIGN.md section 4"}}
+                       "kernel_limited_by": "cache lines pulled by the IBL footprint gathers (texture addresser / L1 line handling, 65-80 % of the streaming rate in fabric traffic; not occupancy, not the walk): DESIGN.md section 4"}}
     if v and prof:
         for k in ("TA_BUSY_avr", "TCP_PENDING_STALL_CYCLES_sum", "TCC_HIT_sum", "TCC_MISS_sum", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"):
             if k in v:
