@@ -39,6 +39,20 @@ def test_bench_prints_one_json_line(extra, n):
         assert box["shade_simd_cycles_per_pixel"] > 10
         if "valu" in rec["roofline"]:                                  # (needs a committed counter profile of this very shade.hip)
             assert rec["roofline"]["valu"]["shade_simd_cycles_per_pixel"] > 0
+        # round 6: every single-GPU BASELINE config and the reference's own operating point in the same line (no CPU legs here: --no-cpu-baseline)
+        cf = rec["configs"]
+        assert "error" not in cf, cf
+        assert cf["cfg1_brdf_lut"]["lut256"]["ms"] > 0 and cf["cfg1_brdf_lut"]["lut512"]["Msamples_per_s"] > 1e4
+        c2 = cf["cfg2_1080p_1_light"]
+        assert 0 < c2["shade_ms"] < 1 and c2["unit"] == "Mpixel/s" and abs(c2["value"] * c2["shade_ms"] * 1e3 / (1920 * 1080) - 1.0) < 1e-2   # (both are rounded in the record)
+        r2 = c2["roofline"]
+        assert r2["bound"] == "hbm" and r2["algorithmic_bytes"] == 25 * 1920 * 1080 and abs(r2["frac"] - r2["achieved"] / r2["peak"]) < 1e-3
+        assert r2["traffic"] is None or r2["traffic"] > r2["algorithmic_bytes"]      # (None: no counter profile of this very shade.hip committed)
+        c3 = cf["cfg3_prefilter_sh9"]
+        assert c3["prefilter_fp32_source"]["ms"] > c3["prefilter_half_representable_source"]["ms"] > 0 and c3["sh9"]["ms"] > 0
+        rp = cf["reference_operating_point"]
+        assert "error" not in rp and rp["dispatch_by_dispatch"]["dispatches_per_frame"] == 23 and rp["fused_passes"]["dispatches_per_frame"] == 7
+        assert rp["dispatch_by_dispatch"]["ms_per_frame"] >= rp["fused_passes"]["ms_per_frame"] > 0
     if n > 1:
         # the multi-rank orchestration, rehearsed on the one GPU (gloo + host copies): the grid, the cfg5 sub-record with its single-GPU
         # denominator, and the C++ pass graph leg (loopback halo transport) all come back in the one record.  (Three ranks, not four: the
