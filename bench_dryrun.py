@@ -29,8 +29,8 @@ ENV_MIPS = 5
 
 
 class DryContext:
-    """Host stand-in for PbrContext (see the module docstring).  fail_setup: "<rank>:<mode>/<transport>" makes build_frame's LOCAL half
-    raise on that rank for that candidate — the fall-back path of run_workload is then taken by every rank together."""
+    """Host stand-in for PbrContext (see the module docstring).  Fault injection (bench.py --dry-fail): a set-up failure of one candidate on
+    one rank is raised by bench.build_frame itself; `fault` below makes this rank miscount or hang inside a frame."""
 
     torch_device = "cpu"
 
